@@ -1,0 +1,449 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REFERENCE (BIT-Vision/EventPretrain, mounted
+read-only at /root/reference) on deterministic inputs and writes plain-array
+fixtures under tests/golden/.
+
+TEST INFRASTRUCTURE ONLY. Runs only in the build container (the reference does
+not exist on the GPU box). Nothing from the reference is copied: the fixtures
+hold inputs, outputs and checksums as numpy arrays. Pickled modules are never
+written.
+
+The reference's model files import three names from `timm.models.layers`
+(model/sub_module/vit_block.py:5). timm is not installed here; an in-memory
+module object supplying `to_2tuple`, `trunc_normal_` and a `DropPath` that is
+never executed (all drop rates are 0 -> nn.Identity, vit_block.py:241) is put
+in sys.modules for the duration of this script.
+
+Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con]
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("EVP_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from eventpretrain_amd.testing import (det_fill_module_, det_normalish, det_uniform,  # noqa: E402
+                                       make_args, synthetic_events)
+
+
+def _install_timm_standin():
+    if "timm" in sys.modules:
+        return
+    import collections.abc
+    from itertools import repeat
+
+    def to_2tuple(x):
+        if isinstance(x, collections.abc.Iterable) and not isinstance(x, str):
+            return tuple(x)
+        return tuple(repeat(x, 2))
+
+    class DropPath(torch.nn.Module):  # never executed: rate 0 -> nn.Identity in the reference
+        def __init__(self, p=0.0):
+            super().__init__()
+            self.p = p
+
+        def forward(self, x):
+            if self.p == 0.0 or not self.training:
+                return x
+            raise RuntimeError("DropPath stand-in executed with p>0")
+
+    def trunc_normal_(t, mean=0.0, std=1.0, a=-2.0, b=2.0):
+        return torch.nn.init.trunc_normal_(t, mean=mean, std=std, a=a, b=b)
+
+    timm = types.ModuleType("timm")
+    models = types.ModuleType("timm.models")
+    layers = types.ModuleType("timm.models.layers")
+    layers.DropPath, layers.to_2tuple, layers.trunc_normal_ = DropPath, to_2tuple, trunc_normal_
+    timm.models, models.layers = models, layers
+    timm.__version__ = "0.3.2"
+    sys.modules.update({"timm": timm, "timm.models": models, "timm.models.layers": layers})
+
+
+def _ref():
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    _install_timm_standin()
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def checksums(t: torch.Tensor):
+    """Layout-sensitive checksums of a tensor in float64."""
+    d = t.detach().double().flatten()
+    w = det_uniform("checksum.weights", (d.numel(),)).double()
+    return np.array([d.sum().item(), d.abs().sum().item(), (d * w).sum().item(), (d * d).sum().item()])
+
+
+# --------------------------------------------------------------------------- voxel
+def gen_voxel():
+    _ref()
+    torch.set_num_threads(1)     # the reference's shipped setting (main_pretrain.py:12): sequential index_add_
+    from dataset.dataset_utils.events_to_voxel_grid import events_to_voxel_grid
+    out = {}
+    args = make_args(num_bins=5)
+    # known-answer test from SURVEY.md section 4
+    kat = np.array([[0, 0, 0.0, 1], [1, 0, 0.25, 0], [2, 1, 0.5, 1], [3, 3, 0.9, 0], [3, 3, 1.0, 1]], dtype=np.float64)
+    out["kat_events"] = kat
+    out["kat_grid"] = events_to_voxel_grid(args, kat.copy(), (4, 4))
+    cases = []
+
+    def case(tag, ev, size, bins=5, is_txyp=False):
+        a = make_args(num_bins=bins)
+        g = events_to_voxel_grid(a, ev.copy(), size, is_txyp=is_txyp)
+        out[f"{tag}_events"] = ev
+        out[f"{tag}_grid"] = g
+        cases.append(dict(tag=tag, H=size[0], W=size[1], bins=bins, is_txyp=bool(is_txyp)))
+
+    # small clips, non-square grid so that H/W mix-ups show up
+    for i in range(3):
+        case(f"rand{i}", synthetic_events(100 + i, 5000, width=48, height=32), (32, 48))
+    case("signed", synthetic_events(110, 4000, width=48, height=32, signed_polarity=True), (32, 48))
+    ev = synthetic_events(111, 3000, width=40, height=24)
+    case("txyp", ev[:, [2, 0, 1, 3]].copy(), (24, 40), is_txyp=True)
+    ev = synthetic_events(112, 2000, width=16, height=16)
+    ev[:, 2] = 0.125                                            # deltaT == 0 -> 1.0
+    case("samet", ev, (16, 16))
+    case("single", synthetic_events(113, 1, width=8, height=8), (8, 8))
+    ev = synthetic_events(114, 6000, width=640, height=480)       # sensor->input rescale leaves fractions
+    ev[:, 0] *= 48 / 640
+    ev[:, 1] *= 32 / 480
+    case("frac", ev, (32, 48))
+    case("bins3", synthetic_events(115, 3000, width=20, height=12), (12, 20), bins=3)
+    case("bins9", synthetic_events(116, 3000, width=20, height=12), (12, 20), bins=9)
+    ev = synthetic_events(117, 4000, width=48, height=32)         # microsecond-scale stamps, large offset
+    ev[:, 2] = ev[:, 2] * 1e6 + 1.7e9
+    case("bigt", ev, (32, 48))
+    # full-size clip: keep checksums + a strided sample, not the 1 MB grid
+    ev = synthetic_events(0, 100_000)
+    g = events_to_voxel_grid(args, ev.copy(), (224, 224))
+    out["full0_checksums"] = checksums(g)
+    out["full0_sample"] = g[:, ::7, ::5].contiguous()
+    out["cases"] = np.array(json.dumps(cases))
+    save("voxel", **out)
+    torch.set_num_threads(8)
+
+
+# --------------------------------------------------------------------------- pos embed
+def gen_pos():
+    _ref()
+    from utils.pos_embed import get_2d_sincos_pos_embed
+    out = {}
+    for d, g in [(64, 4), (128, 4), (192, 4), (384, 14), (512, 14), (768, 14), (256, 7)]:
+        pe = get_2d_sincos_pos_embed(d, g)
+        out[f"d{d}_g{g}_dtype"] = np.array(str(pe.dtype))
+        t = torch.from_numpy(pe).float()
+        out[f"d{d}_g{g}_checksums"] = checksums(t)
+        if d * g * g <= 192 * 16:
+            out[f"d{d}_g{g}_table"] = t
+        else:
+            out[f"d{d}_g{g}_rows"] = t[[0, 1, 17, g * g - 1]]
+    save("pos_embed", **out)
+
+
+# --------------------------------------------------------------------------- masking
+def gen_mask():
+    _ref()
+    from model.backbone.vit import ViT
+    out = {}
+    cases = []
+    for tag, inp, L, ratio, B, seed in [("l16", 64, 16, 0.5, 4, 11), ("l196", 224, 196, 0.5, 8, 12),
+                                         ("l196r75", 224, 196, 0.75, 3, 13), ("l196r10", 224, 196, 0.1, 2, 14)]:
+        a = make_args(mask_ratio=ratio)
+        m = ViT(a, input_size=inp, patch_size=16, embed_dim=32, depth=1, num_heads=1, mask_ratio=ratio)
+        x = torch.zeros(B, 5, inp, inp)
+        torch.manual_seed(seed)
+        ids_keep, mask, ids_restore = m.random_masking(x)
+        torch.manual_seed(seed)
+        noise = torch.rand(B, L)                 # same CPU stream the reference just consumed (vit.py:78)
+        assert torch.equal(torch.argsort(noise, dim=1)[:, :ids_keep.shape[1]], ids_keep)
+        srt = torch.sort(noise, dim=1).values
+        assert (srt[:, 1:] > srt[:, :-1]).all(), "tie in noise; pick another seed"
+        out[f"{tag}_noise"], out[f"{tag}_ids_keep"] = noise, ids_keep
+        out[f"{tag}_mask"], out[f"{tag}_ids_restore"] = mask, ids_restore
+        cases.append(dict(tag=tag, L=L, ratio=ratio, B=B))
+    out["cases"] = np.array(json.dumps(cases))
+    save("masking", **out)
+
+
+# --------------------------------------------------------------------------- model compositions
+def _compose(cfg):
+    """Hand-compose backbone + decoder from the reference CLASSES (SURVEY.md header: the hub factories cannot
+    build ViT-Base or the 64x64 tiny model)."""
+    _ref()
+    from functools import partial
+    from model.backbone.vit import ViT
+    from model.pretrain.pr_rec_decoder import PrRecDecoder
+    a = make_args(mask_ratio=cfg["mask_ratio"], patch_size=cfg["patch"])
+    ln = partial(torch.nn.LayerNorm, eps=1e-6)
+    bb = ViT(a, input_size=cfg["input"], patch_size=cfg["patch"], embed_dim=cfg["dim"], depth=cfg["depth"],
+             num_heads=cfg["heads"], mlp_ratio=4, norm_layer=ln, num_bins=5, mask_ratio=cfg["mask_ratio"])
+    L = (cfg["input"] // cfg["patch"]) ** 2
+    dec = PrRecDecoder(patch_size=cfg["patch"], num_patches=L, encoder_embed_dim=[cfg["dim"]],
+                       embed_dim=cfg["dec_dim"], depth=cfg["dec_depth"], num_heads=cfg["dec_heads"],
+                       mlp_ratio=[4, 4, 4], norm_layer=ln, frame_chans=1)
+
+    class Hub(torch.nn.Module):  # state-dict keys as PrHubModel: backbone.*, pretrain_rec_decoder.*
+        def __init__(self):
+            super().__init__()
+            self.backbone, self.pretrain_rec_decoder = bb, dec
+
+    hub = Hub()
+    det_fill_module_(hub)
+    return a, hub
+
+
+def _rec_loss_ref(a, patch, pred, target, mask):
+    """PrHubModel.reconstruct_loss called unbound on a stub (pr_hub_model.py:125-141)."""
+    from model.pretrain.pr_hub_model import PrHubModel
+    stub = types.SimpleNamespace(patch_size=patch, norm_pix_loss=a.norm_pix_loss, mask_ratio=a.mask_ratio)
+    return PrHubModel.reconstruct_loss(stub, pred, target, mask)
+
+
+CFGS = {
+    "tiny": dict(input=64, patch=16, dim=192, depth=12, heads=3, dec_dim=128, dec_depth=4, dec_heads=4,
+                 mask_ratio=0.5, B=2),
+    "base": dict(input=224, patch=16, dim=768, depth=12, heads=12, dec_dim=512, dec_depth=8, dec_heads=16,
+                 mask_ratio=0.5, B=2),
+}
+
+
+def _inputs(tag, cfg):
+    B, S = cfg["B"], cfg["input"]
+    L = (S // cfg["patch"]) ** 2
+    x = det_normalish(f"{tag}.voxels", (B, 5, S, S)) * 0.5
+    y = det_normalish(f"{tag}.sub_frame", (B, 1, S, S))
+    noise = det_uniform(f"{tag}.noise", (B, L), 0.0, 1.0)
+    return x, y, noise
+
+
+def _run_rec(tag, cfg, hub_forward, named_params, extra=None):
+    """Shared: forward with explicit noise (torch.rand patched for the one call), backward, collect."""
+    x, y, noise = _inputs(tag, cfg)
+    real_rand = torch.rand
+    calls = []
+
+    def fake_rand(*shape, **kw):
+        calls.append(shape)
+        assert tuple(shape) == tuple(noise.shape), shape
+        return noise.clone()
+
+    torch.rand = fake_rand
+    try:
+        res = hub_forward(x, y)
+    finally:
+        torch.rand = real_rand
+    assert len(calls) == 1
+    loss, emb_l1, emb_l2, emb_lh, pred, mask, ids_restore = res
+    loss.backward()
+    out = dict(noise=noise, loss=loss.detach().double(), mask=mask, ids_restore=ids_restore)
+    out["pred_checksums"] = checksums(pred)
+    out["emb_l1_checksums"], out["emb_l2_checksums"] = checksums(emb_l1), checksums(emb_l2)
+    out["emb_lh_checksums"] = checksums(emb_lh)
+    names, gnorms, gsums = [], [], []
+    for n, p in named_params:
+        if p.grad is None:
+            continue
+        names.append(n)
+        gnorms.append(p.grad.double().norm().item())
+        gsums.append(checksums(p.grad)[2])
+    out["grad_names"] = np.array(json.dumps(names))
+    out["grad_norms"] = np.array(gnorms)
+    out["grad_wsums"] = np.array(gsums)
+    out["total_grad_norm"] = np.array(float(np.sqrt(np.sum(np.square(gnorms)))))
+    if extra:
+        out.update(extra(res))
+    return out
+
+
+def gen_composed(tag):
+    cfg = CFGS[tag]
+    a, hub = _compose(cfg)
+
+    def fwd(x, y):
+        emb_l1, emb_l2, emb_lh, mask, ids_restore = hub.backbone(x, mask=True)
+        pred = hub.pretrain_rec_decoder(emb_lh, ids_restore)
+        loss = _rec_loss_ref(a, cfg["patch"], pred, y, mask)
+        return loss, emb_l1, emb_l2, emb_lh, pred, mask, ids_restore
+
+    def extra(res):
+        if tag != "tiny":
+            return {}
+        loss, emb_l1, emb_l2, emb_lh, pred, mask, ids_restore = res
+        sd = dict(hub.named_parameters())
+        e = dict(pred=pred, emb_lh=emb_lh, emb_l1=emb_l1)
+        for n in ["backbone.patch_embed.proj.weight", "backbone.vit_block.0.attn.qkv.weight",
+                  "backbone.vit_block.0.norm1.weight", "backbone.vit_block.11.mlp.fc2.bias",
+                  "pretrain_rec_decoder.mask_token", "pretrain_rec_decoder.pred.weight",
+                  "backbone.norm_layer.bias", "backbone.patch_embed.norm.weight"]:
+            e["grad::" + n] = sd[n].grad
+        return e
+
+    out = _run_rec(tag, cfg, fwd, list(hub.named_parameters()), extra)
+    out["cfg"] = np.array(json.dumps(cfg))
+    save(f"rec_{tag}", **out)
+
+
+def gen_small():
+    """The as-shipped path: pretrain_hub_model_small_patch16 -> PrHubModel.forward(is_rec=True)."""
+    _ref()
+    from model.pretrain.pr_hub_model import pretrain_hub_model_small_patch16
+    cfg = dict(input=224, patch=16, dim=384, depth=12, heads=12, dec_dim=256, dec_depth=8, dec_heads=8,
+               mask_ratio=0.5, B=2)
+    a = make_args(model_size="small", pr_phase="rec")
+    hub = pretrain_hub_model_small_patch16(a, emb_frames_dim=512, queue_length=1024, T=0.07)
+    det_fill_module_(hub)
+    hub.train(True)
+    out = _run_rec("small", cfg, lambda x, y: hub(x, y, is_rec=True), list(hub.named_parameters()))
+    out["cfg"] = np.array(json.dumps(cfg))
+    out["state_keys"] = np.array(json.dumps({k: list(v.shape) for k, v in hub.state_dict().items()}))
+    save("rec_small", **out)
+
+
+# --------------------------------------------------------------------------- trainer trajectory
+def gen_train():
+    """5 optimiser steps of the reference's own pr_rec_one_epoch (trainer/pretrain/pr_trainer.py:9-89) with
+    param_groups_lrd + AdamW(betas=(0.9,0.95)) as main_pretrain.py:323-343 sets them up, on the tiny model."""
+    _ref()
+    import utils.lr_decay as lrd
+    from trainer.pretrain.pr_trainer import pr_rec_one_epoch
+    from utils.misc import NativeScalerWithGradNormCount
+    from utils.lr_sched import adjust_learning_rate
+    cfg = CFGS["tiny"]
+    a, hub = _compose(cfg)
+    a.batch_size, a.epochs, a.warmup_epochs, a.accum_iter = cfg["B"], 4, 1, 1
+    a.lr = a.blr * a.batch_size * a.accum_iter / 256 * 64     # x64 so that 3 steps move the loss visibly
+    a.min_lr = 1e-6
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone, self.pretrain_rec_decoder = hub.backbone, hub.pretrain_rec_decoder
+
+        def forward(self, x, y, is_rec=True):
+            emb_l1, emb_l2, emb_lh, mask, ids_restore = self.backbone(x, mask=True)
+            pred = self.pretrain_rec_decoder(emb_lh, ids_restore)
+            loss = _rec_loss_ref(a, cfg["patch"], pred, y, mask)
+            return loss, emb_l1, emb_l2, emb_lh, pred, mask, ids_restore
+
+    model = Model()
+    groups = lrd.param_groups_lrd(a, model, a.weight_decay, layer_decay=1)
+    opt = torch.optim.AdamW(groups, lr=a.lr, betas=(0.9, 0.95))
+    scaler = NativeScalerWithGradNormCount()
+    steps, noises, batches = 5, [], []
+    for s in range(steps):
+        x = det_normalish(f"train.voxels.{s}", (cfg["B"], 5, 64, 64)) * 0.5
+        y = det_normalish(f"train.sub_frame.{s}", (cfg["B"], 1, 64, 64))
+        noises.append(det_uniform(f"train.noise.{s}", (cfg["B"], 16), 0.0, 1.0))
+        batches.append(dict(events_voxel_grid=x, sub_frame=y, image_name=[f"s{s}"] * cfg["B"]))
+    it = iter(noises)
+    real_rand = torch.rand
+    torch.rand = lambda *s, **k: next(it).clone()
+    losses, lrs = [], []
+    real_step = opt.step
+
+    def spy_step(*aa, **kk):
+        lrs.append(opt.param_groups[0]["lr"])
+        return real_step(*aa, **kk)
+
+    opt.step = spy_step
+    fwd = model.forward
+
+    def spy_fwd(*aa, **kk):
+        r = fwd(*aa, **kk)
+        losses.append(r[0].item())
+        return r
+
+    model.forward = spy_fwd
+    try:
+        stats = pr_rec_one_epoch(a, model, batches, opt, 0, scaler, log_writer=None)
+    finally:
+        torch.rand = real_rand
+    out = dict(losses=np.array(losses), lrs=np.array(lrs), noise=torch.stack(noises),
+               stats=np.array(json.dumps(stats)), lr=np.array(a.lr), min_lr=np.array(a.min_lr),
+               warmup_epochs=np.array(a.warmup_epochs), epochs=np.array(a.epochs),
+               weight_decay=np.array(a.weight_decay))
+    names, psums = [], []
+    for n, p in model.named_parameters():
+        names.append(n)
+        psums.append(checksums(p)[2])
+    out["param_names"] = np.array(json.dumps(names))
+    out["param_wsums"] = np.array(psums)
+    cnt = {"decay": 0, "no_decay": 0}
+    for g in groups:
+        cnt["decay" if g["weight_decay"] > 0 else "no_decay"] += len(g["params"])
+    out["group_decay"] = np.array(json.dumps(cnt))
+    out["n_groups"] = np.array(len(groups))
+    # LR schedule samples (utils/lr_sched.py:3-16)
+    sched = []
+    fake_opt = types.SimpleNamespace(param_groups=[{"lr": 0.0}, {"lr": 0.0, "lr_scale": 0.5}])
+    sa = make_args(lr=2e-3, min_lr=1e-5, warmup_epochs=5, epochs=40)
+    for e in [0.0, 0.25, 2.5, 4.999, 5.0, 5.5, 20.0, 39.0, 39.99]:
+        lr = adjust_learning_rate(fake_opt, e, sa)
+        sched.append([e, lr, fake_opt.param_groups[0]["lr"], fake_opt.param_groups[1]["lr"]])
+    out["sched"] = np.array(sched)
+    save("train_tiny", **out)
+
+
+# --------------------------------------------------------------------------- contrastive stage
+def gen_con():
+    """PrHubModel.forward(is_rec=False) with and without the queue (pr_hub_model.py:208-245) on ViT-Small 224
+    (the only size the hub factory builds), B=2, queue_length=4."""
+    _ref()
+    from model.pretrain.pr_hub_model import pretrain_hub_model_small_patch16
+    for use_queue in (True, False):
+        a = make_args(model_size="small", pr_phase="con", use_queue=use_queue, mask_ratio=0.0)
+        hub = pretrain_hub_model_small_patch16(a, emb_frames_dim=512, queue_length=4, T=0.07)
+        if not use_queue:
+            pass
+        det_fill_module_(hub)
+        hub.train(True)
+        x = det_normalish("con.voxels", (2, 5, 224, 224)) * 0.5
+        clip = det_normalish("con.clip_emb", (2, 197, 512))
+        q0 = hub.queue.clone() if use_queue else None
+        loss, emb_h_org, emb_h_proj, clip_org, clip_proj, attn = hub(x, clip)
+        loss.backward()
+        out = dict(loss=loss.detach().double(), emb_h_org_checksums=checksums(emb_h_org),
+                   emb_h_proj_checksums=checksums(emb_h_proj), clip_org_checksums=checksums(clip_org),
+                   clip_proj_checksums=checksums(clip_proj), attn_checksums=checksums(attn))
+        names, gn = [], []
+        for n, p in hub.named_parameters():
+            if p.grad is not None:
+                names.append(n)
+                gn.append(p.grad.double().norm().item())
+        out["grad_names"], out["grad_norms"] = np.array(json.dumps(names)), np.array(gn)
+        if use_queue:
+            out["queue_after_checksums"] = checksums(hub.queue)
+            out["queue_ptr_after"] = hub.queue_ptr.clone()
+            out["queue_changed"] = np.array(float((hub.queue - q0).abs().sum()))
+        bn = {k: checksums(v) for k, v in hub.state_dict().items() if "running_" in k}
+        out["bn_keys"] = np.array(json.dumps(list(bn.keys())))
+        out["bn_checksums"] = np.stack(list(bn.values()))
+        out["state_keys"] = np.array(json.dumps({k: list(v.shape) for k, v in hub.state_dict().items()}))
+        save("con_small_queue" if use_queue else "con_small_noqueue", **out)
+
+
+GENS = dict(voxel=gen_voxel, pos=gen_pos, mask=gen_mask, tiny=lambda: gen_composed("tiny"), small=gen_small,
+            base=lambda: gen_composed("base"), train=gen_train, con=gen_con)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=",".join(GENS))
+    ns = ap.parse_args()
+    torch.set_num_threads(8)
+    for k in ns.only.split(","):
+        print(f"== {k}")
+        GENS[k]()

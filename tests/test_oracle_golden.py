@@ -1,0 +1,195 @@
+"""Pins the oracle (oracle/*.py, oracle/voxel_oracle.c) against fixtures produced by the reference itself
+(oracle/gen_golden.py). CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import assert_checksums, checksums, jl, rec_inputs, rec_state_dict
+from oracle import model_oracle as mo
+from oracle.voxel_oracle import voxel_grid
+
+
+def test_voxel_kat_exact():
+    d = load_golden("voxel")
+    g = voxel_grid(d["kat_events"], 5, (4, 4))
+    assert np.array_equal(g, d["kat_grid"])
+    nz = {(int(b), int(y), int(x)): float(g[b, y, x]) for b, y, x in zip(*np.nonzero(g))}
+    # SURVEY.md section 4 known answers
+    assert nz == pytest.approx({(0, 0, 0): 1.0, (1, 0, 1): -1.0, (2, 1, 2): 1.0, (3, 3, 3): -0.4, (4, 3, 3): 0.4}, abs=1e-6)
+
+
+def test_voxel_cases_bit_exact():
+    d = load_golden("voxel")
+    for c in jl(d["cases"]):
+        g = voxel_grid(d[c["tag"] + "_events"], c["bins"], (c["H"], c["W"]), c["is_txyp"])
+        assert np.array_equal(g, d[c["tag"] + "_grid"]), c["tag"]
+
+
+def test_voxel_full_clip():
+    from eventpretrain_amd.testing import synthetic_events
+    d = load_golden("voxel")
+    g = voxel_grid(synthetic_events(0), 5, (224, 224))
+    assert np.array_equal(g[:, ::7, ::5], d["full0_sample"])
+    assert np.allclose(checksums(torch.from_numpy(g)), d["full0_checksums"], rtol=1e-12)
+
+
+def test_pos_embed():
+    d = load_golden("pos_embed")
+    for dim, g in [(64, 4), (128, 4), (192, 4), (384, 14), (512, 14), (768, 14), (256, 7)]:
+        t = torch.from_numpy(mo.sincos_2d(dim, g)).float()
+        assert mo.sincos_2d(dim, g).dtype == np.float32
+        assert np.allclose(checksums(t), d[f"d{dim}_g{g}_checksums"], rtol=0, atol=0), (dim, g)
+        if f"d{dim}_g{g}_table" in d.files:
+            assert np.array_equal(t.numpy(), d[f"d{dim}_g{g}_table"])
+        else:
+            assert np.array_equal(t[[0, 1, 17, g * g - 1]].numpy(), d[f"d{dim}_g{g}_rows"])
+    # first half encodes w
+    t = mo.sincos_2d(384, 14)
+    assert np.allclose(t[17, :4], [0.14112, 0.40414152, 0.6173581, 0.7782725], atol=1e-6)
+    assert np.allclose(t[17, 192:196], [0.841471, 0.78859305, 0.73482203, 0.68156135], atol=1e-6)
+
+
+def test_masking_bit_exact():
+    d = load_golden("masking")
+    for c in jl(d["cases"]):
+        t = c["tag"]
+        keep, mask, restore = mo.masking_from_noise(torch.from_numpy(d[t + "_noise"]), c["ratio"])
+        assert np.array_equal(keep.numpy(), d[t + "_ids_keep"])
+        assert np.array_equal(restore.numpy(), d[t + "_ids_restore"])
+        assert np.array_equal(mask.numpy(), d[t + "_mask"])
+
+
+def _check_rec(tag, rtol_loss=2e-6, rtol_cs=2e-5):
+    d = load_golden(f"rec_{tag}")
+    cfg = jl(d["cfg"])
+    sd = {k: v.requires_grad_(v.is_floating_point() and "pos_embed" not in k) for k, v in rec_state_dict(cfg).items()}
+    x, y, noise = rec_inputs(tag, cfg)
+    assert np.array_equal(noise.numpy(), d["noise"])
+    loss, l1, l2, lh, pred, mask, restore = mo.rec_step(sd, x, y, noise, cfg)
+    assert np.array_equal(mask.numpy(), d["mask"])
+    assert np.array_equal(restore.numpy(), d["ids_restore"])
+    assert abs(loss.item() - float(d["loss"])) <= rtol_loss * abs(float(d["loss"]))
+    assert_checksums(pred, d["pred_checksums"], rtol_cs, "pred")
+    assert_checksums(lh, d["emb_lh_checksums"], rtol_cs, "emb_lh")
+    assert_checksums(l1, d["emb_l1_checksums"], rtol_cs, "emb_l1")
+    assert_checksums(l2, d["emb_l2_checksums"], rtol_cs, "emb_l2")
+    loss.backward()
+    names = jl(d["grad_names"])
+    for n, gn, ws in zip(names, d["grad_norms"], d["grad_wsums"]):
+        g = sd[n].grad
+        assert g is not None, n
+        assert abs(g.double().norm().item() - gn) <= 1e-4 * gn + 1e-9, n
+    return d, sd, (loss, l1, l2, lh, pred)
+
+
+def test_rec_tiny_matches_reference():
+    d, sd, (loss, l1, l2, lh, pred) = _check_rec("tiny")
+    assert torch.allclose(pred, torch.from_numpy(d["pred"]), atol=2e-5, rtol=1e-5)
+    assert torch.allclose(lh, torch.from_numpy(d["emb_lh"]), atol=2e-5, rtol=1e-5)
+    for k in d.files:
+        if k.startswith("grad::"):
+            ref = torch.from_numpy(d[k])
+            assert torch.allclose(sd[k[6:]].grad, ref, atol=1e-6 + 1e-4 * ref.abs().max().item(), rtol=1e-4), k
+
+
+def test_rec_small_matches_reference():
+    _check_rec("small")
+
+
+def test_rec_small_state_keys():
+    d = load_golden("rec_small")
+    cfg = jl(d["cfg"])
+    ref = jl(d["state_keys"])
+    sd = rec_state_dict(cfg)
+    assert {k: list(v.shape) for k, v in sd.items()} == ref
+
+
+@pytest.mark.slow
+def test_rec_base_matches_reference():
+    _check_rec("base")
+
+
+def test_lr_schedule():
+    d = load_golden("train_tiny")
+    for e, lr, g0, g1 in d["sched"]:
+        got = mo.cosine_lr(e, 2e-3, 1e-5, 5, 40)
+        assert got == pytest.approx(lr, rel=1e-12, abs=1e-18)
+        assert g0 == pytest.approx(lr) and g1 == pytest.approx(0.5 * lr)
+
+
+def test_train_trajectory_tiny():
+    """5 AdamW steps restated with the oracle's own update rule reproduce the reference trainer's loss sequence,
+    LR sequence and final parameters."""
+    from eventpretrain_amd.testing import det_normalish
+    d = load_golden("train_tiny")
+    cfg = dict(input=64, patch=16, dim=192, depth=12, heads=3, dec_dim=128, dec_depth=4, dec_heads=4, mask_ratio=0.5, B=2)
+    sd = rec_state_dict(cfg)
+    train = [k for k in sd if "pos_embed" not in k]
+    decay, no_decay = mo.decay_split([(k, tuple(sd[k].shape)) for k in train])
+    assert jl(d["group_decay"]) == {"decay": len(decay), "no_decay": len(no_decay)}
+    m = {k: torch.zeros_like(sd[k]) for k in train}
+    v = {k: torch.zeros_like(sd[k]) for k in train}
+    lr0, min_lr = float(d["lr"]), float(d["min_lr"])
+    n_steps = len(d["losses"])
+    for s in range(n_steps):
+        lr = mo.cosine_lr(s / n_steps + 0, lr0, min_lr, int(d["warmup_epochs"]), int(d["epochs"]))
+        assert lr == pytest.approx(d["lrs"][s], rel=1e-12, abs=1e-18)
+        for k in train:
+            sd[k] = sd[k].detach().requires_grad_(True)
+        x = det_normalish(f"train.voxels.{s}", (2, 5, 64, 64)) * 0.5
+        y = det_normalish(f"train.sub_frame.{s}", (2, 1, 64, 64))
+        loss = mo.rec_step(sd, x, y, torch.from_numpy(d["noise"][s]), cfg)[0]
+        assert loss.item() == pytest.approx(d["losses"][s], rel=2e-5), s
+        loss.backward()
+        with torch.no_grad():
+            for k in train:
+                wd = float(d["weight_decay"]) if k in decay else 0.0
+                p, m[k], v[k] = mo.adamw_step(sd[k], sd[k].grad, m[k], v[k], s + 1, lr, wd)
+                sd[k] = p
+    names = jl(d["param_names"])
+    for n, ws in zip(names, d["param_wsums"]):
+        got = checksums(sd[n])[2]
+        # the key third of qkv.bias has a mathematically zero gradient (softmax shift invariance); Adam turns its
+        # rounding noise into +-lr steps, so that parameter is only checked loosely.
+        tol = 5e-4 if n.endswith("attn.qkv.bias") else 1e-5
+        assert got == pytest.approx(ws, rel=1e-4, abs=tol), n
+
+
+@pytest.mark.parametrize("use_queue", [True, False])
+def test_con_small_matches_reference(use_queue):
+    from eventpretrain_amd.testing import det_normalish, det_value_for, det_uniform
+    d = load_golden("con_small_queue" if use_queue else "con_small_noqueue")
+    keys = jl(d["state_keys"])
+    sd = {}
+    for k, shp in keys.items():
+        leaf = k.split(".")[-1]
+        if leaf == "pos_embed":
+            sd[k] = torch.from_numpy(mo.sincos_2d(shp[-1], 14)).float().unsqueeze(0)
+        elif leaf == "queue":
+            sd[k] = torch.nn.functional.normalize(det_uniform(k, shp, -1.0, 1.0), dim=0)
+        elif leaf == "queue_ptr":
+            sd[k] = torch.zeros(1, dtype=torch.long)
+        else:
+            sd[k] = det_value_for(k, shp)
+        if sd[k].is_floating_point() and leaf not in ("pos_embed", "queue", "running_mean", "running_var"):
+            sd[k].requires_grad_(True)
+    x = det_normalish("con.voxels", (2, 5, 224, 224)) * 0.5
+    clip = det_normalish("con.clip_emb", (2, 197, 512))
+    cfg = dict(patch=16, heads=12, T=0.07, use_queue=use_queue)
+    loss, h_org, h_proj, c_org, c_proj, attn, side = mo.con_step(sd, x, clip, cfg)
+    assert loss.item() == pytest.approx(float(d["loss"]), rel=5e-6)
+    assert_checksums(h_org, d["emb_h_org_checksums"], 2e-5)
+    assert_checksums(h_proj, d["emb_h_proj_checksums"], 5e-5)
+    assert_checksums(c_org, d["clip_org_checksums"], 2e-5)
+    assert_checksums(c_proj, d["clip_proj_checksums"], 2e-5)
+    assert_checksums(attn, d["attn_checksums"], 2e-5)
+    loss.backward()
+    for n, gn in zip(jl(d["grad_names"]), d["grad_norms"]):
+        assert sd[n].grad is not None, n
+        assert sd[n].grad.double().norm().item() == pytest.approx(gn, rel=3e-3, abs=1e-6), n  # BN backward amplifies fp32 rounding
+    for k, cs in zip(jl(d["bn_keys"]), d["bn_checksums"]):
+        assert_checksums(side[k], cs, 2e-5, k)
+    if use_queue:
+        assert_checksums(side["queue"], d["queue_after_checksums"], 1e-6)
+        assert int(side["queue_ptr"]) == int(d["queue_ptr_after"][0])
