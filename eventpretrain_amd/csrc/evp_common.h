@@ -1,0 +1,89 @@
+// Internal helpers shared by the gfx950 kernels of libevtpretrain.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+
+#include "../../include/evtpretrain.h"
+
+#define EVP_WAVE 64
+
+typedef uint16_t bf16_t;  // raw storage
+
+void evp_set_error(const char *fmt, ...);
+
+#define EVP_CHECK_ARG(cond, code, ...)      \
+  do {                                      \
+    if (!(cond)) {                          \
+      evp_set_error(__VA_ARGS__);           \
+      return (code);                        \
+    }                                       \
+  } while (0)
+
+#define EVP_CHECK_LAUNCH(name)                                                       \
+  do {                                                                               \
+    hipError_t e_ = hipGetLastError();                                               \
+    if (e_ != hipSuccess) {                                                          \
+      evp_set_error("%s: launch failed: %s", (name), hipGetErrorString(e_));         \
+      return EVP_ELAUNCH;                                                            \
+    }                                                                                \
+  } while (0)
+
+// ---- bf16 <-> f32 (round to nearest even; NaN stays NaN via the compiler's own cast) ------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;  // hipcc lowers to v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+  return __builtin_bit_cast(bf16_t, b);
+}
+
+template <typename T> struct ElemIO;
+template <> struct ElemIO<float> {
+  static __device__ __forceinline__ float ld(const float *p) { return *p; }
+  static __device__ __forceinline__ void st(float *p, float v) { *p = v; }
+};
+template <> struct ElemIO<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t *p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st(bf16_t *p, float v) { *p = f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float ld_any(const void *p, int dtype, int64_t i) {
+  return dtype == EVP_BF16 ? bf16_to_f32(((const bf16_t *)p)[i]) : ((const float *)p)[i];
+}
+__device__ __forceinline__ void st_any(void *p, int dtype, int64_t i, float v) {
+  if (dtype == EVP_BF16) ((bf16_t *)p)[i] = f32_to_bf16(v);
+  else ((float *)p)[i] = v;
+}
+
+// ---- wave / block reductions (wave = 64 lanes) --------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// Block-wide sum for blockDim.x <= 1024; `red` is >= 16 floats of LDS. All threads get the result.
+__device__ __forceinline__ float block_sum(float v, float *red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+// exact erf GELU (nn.GELU default) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,558 @@
+// Row-wise (LayerNorm family) and column-wise (bias-gradient, BatchNorm) reductions for gfx950.
+// All HBM-bound: one 64-lane wave owns one row, holds it in registers as float4 chunks (lane-strided, so every
+// wave-instruction moves 1 KiB contiguous), reduces with cross-lane shuffles, writes once.
+#include "evp_common.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;  // 4 waves / 256 threads
+constexpr int LN_MAX_BLOCKS = 1024;
+
+// Number of float4 chunks a lane holds for a row of D floats
+static inline int vpl_for(int D) {
+  const int chunks = D / 4;
+  const int v = (chunks + 63) / 64;
+  int r = 1;
+  while (r < v) r <<= 1;
+  return r;
+}
+
+template <int VPL> struct Row {
+  float4 v[VPL];
+  __device__ __forceinline__ void load(const float *p, int D, int lane) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = (c * 4 < D) ? *reinterpret_cast<const float4 *>(p + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void add(const float *p, int D, int lane) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c * 4 < D) {
+        const float4 t = *reinterpret_cast<const float4 *>(p + c * 4);
+        v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+      }
+    }
+  }
+  __device__ __forceinline__ void load_any(const void *p, int dtype, int64_t off, int D, int lane) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c * 4 < D) {
+        if (dtype == EVP_F32) v[i] = *reinterpret_cast<const float4 *>((const float *)p + off + c * 4);
+        else {
+          const uint2 u = *reinterpret_cast<const uint2 *>((const bf16_t *)p + off + c * 4);
+          v[i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
+                             __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+        }
+      } else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ float sum(int D, int lane) const {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+      if ((lane + 64 * i) * 4 < D) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    return wave_sum(s);
+  }
+  __device__ __forceinline__ float sumsq_centered(float mu, int D, int lane) const {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+      if ((lane + 64 * i) * 4 < D) {
+        const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+        s += (a * a + b * b) + (c * c + d * d);
+      }
+    return wave_sum(s);
+  }
+};
+
+__device__ __forceinline__ void store4_any(void *p, int dtype, int64_t off, float4 v) {
+  if (dtype == EVP_F32) *reinterpret_cast<float4 *>((float *)p + off) = v;
+  else {
+    uint2 u;
+    u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2 *>((bf16_t *)p + off) = u;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ LN forward
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float *x, const float *x2, const float *x3, const float *gamma,
+                                                     const float *beta, int64_t M, int D, float eps, void *y, int y_dtype,
+                                                     float *mean, float *rstd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; r < M; r += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
+    Row<VPL> row;
+    row.load(x + r * D, D, lane);
+    if (x2) row.add(x2 + r * D, D, lane);
+    if (x3) row.add(x3 + r * D, D, lane);
+    const float mu = row.sum(D, lane) / (float)D;
+    const float var = row.sumsq_centered(mu, D, lane) / (float)D;
+    const float rs = 1.0f / sqrtf(var + eps);
+    if (lane == 0) {
+      if (mean) mean[r] = mu;
+      if (rstd) rstd[r] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c * 4 < D) {
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + c * 4);
+        const float4 b = *reinterpret_cast<const float4 *>(beta + c * 4);
+        float4 o;
+        o.x = (row.v[i].x - mu) * rs * g.x + b.x;
+        o.y = (row.v[i].y - mu) * rs * g.y + b.y;
+        o.z = (row.v[i].z - mu) * rs * g.z + b.z;
+        o.w = (row.v[i].w - mu) * rs * g.w + b.w;
+        store4_any(y, y_dtype, r * D + c * 4, o);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ LN backward
+// partial layout: part[blk][0][D] = dgamma partial, part[blk][1][D] = dbeta partial
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void *dy, int dy_dtype, const float *x, const float *x2,
+                                                     const float *x3, const float *gamma, const float *mean,
+                                                     const float *rstd, const float *gres, int64_t M, int D, float *dx,
+                                                     void *dx_lp, float *part) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *sh = reinterpret_cast<float *>(smem_raw);  // [ROWS_PER_BLOCK][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 dg[VPL], db[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) dg[i] = db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; r < M; r += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
+    Row<VPL> xr, gr;
+    xr.load(x + r * D, D, lane);
+    if (x2) xr.add(x2 + r * D, D, lane);
+    if (x3) xr.add(x3 + r * D, D, lane);
+    gr.load_any(dy, dy_dtype, r * D, D, lane);
+    const float mu = mean[r], rs = rstd[r];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c * 4 < D) {
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + c * 4);
+        float4 xh;
+        xh.x = (xr.v[i].x - mu) * rs; xh.y = (xr.v[i].y - mu) * rs;
+        xh.z = (xr.v[i].z - mu) * rs; xh.w = (xr.v[i].w - mu) * rs;
+        const float4 d = gr.v[i];
+        dg[i].x += d.x * xh.x; dg[i].y += d.y * xh.y; dg[i].z += d.z * xh.z; dg[i].w += d.w * xh.w;
+        db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+        float4 t;  // dy * gamma
+        t.x = d.x * g.x; t.y = d.y * g.y; t.z = d.z * g.z; t.w = d.w * g.w;
+        s1 += (t.x + t.y) + (t.z + t.w);
+        s2 += (t.x * xh.x + t.y * xh.y) + (t.z * xh.z + t.w * xh.w);
+        gr.v[i] = t;
+        xr.v[i] = xh;
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c * 4 < D) {
+        float4 o;
+        o.x = rs * (gr.v[i].x - s1 - xr.v[i].x * s2);
+        o.y = rs * (gr.v[i].y - s1 - xr.v[i].y * s2);
+        o.z = rs * (gr.v[i].z - s1 - xr.v[i].z * s2);
+        o.w = rs * (gr.v[i].w - s1 - xr.v[i].w * s2);
+        if (gres) {
+          const float4 q = *reinterpret_cast<const float4 *>(gres + r * D + c * 4);
+          o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+        }
+        if (dx) *reinterpret_cast<float4 *>(dx + r * D + c * 4) = o;
+        if (dx_lp) store4_any(dx_lp, EVP_BF16, r * D + c * 4, o);
+      }
+    }
+  }
+  // combine the 4 waves' column partials through LDS, then one store per block
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c * 4 < D) {
+      *reinterpret_cast<float4 *>(sh + (wave * 2 + 0) * D + c * 4) = dg[i];
+      *reinterpret_cast<float4 *>(sh + (wave * 2 + 1) * D + c * 4) = db[i];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < ROWS_PER_BLOCK; ++w) s += sh[w * 2 * D + e];
+    part[(int64_t)blockIdx.x * 2 * D + e] = s;
+  }
+}
+
+// out0[d] = sum_blk part[blk][0][d], out1[d] = sum_blk part[blk][1][d]
+__global__ void ln_bwd_finalize(const float *part, int nblk, int D, float *out0, float *out1) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * D) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * 2 * D + e];
+  if (e < D) { if (out0) out0[e] = s; }
+  else { if (out1) out1[e - D] = s; }
+}
+
+static inline int ln_grid(int64_t M) {
+  int64_t g = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  if (g > LN_MAX_BLOCKS) g = LN_MAX_BLOCKS;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+constexpr int CS_ROWS = 64;  // rows per partial block
+__global__ __launch_bounds__(256) void colsum_partial(const void *x, int dtype, int64_t M, int N, int64_t ld, float *part) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+  const int64_t r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
+  float s = 0.f;
+  for (int64_t r = r0; r < r1; ++r) s += ld_any(x, dtype, r * ld + n);
+  part[(int64_t)blockIdx.y * N + n] = s;
+}
+__global__ void colsum_finalize(const float *part, int nblk, int N, float *out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * N + n];
+  out[n] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ patch-embed post-op
+template <int VPL>
+__global__ __launch_bounds__(256) void embed_post_fwd_kernel(const float *y, const float *gamma, const float *beta,
+                                                             const float *pos, const int64_t *ids_keep, int64_t M,
+                                                             int n_keep, int L, int D, float eps, float *out, float *mean,
+                                                             float *rstd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; r < M; r += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
+    Row<VPL> row;
+    row.load(y + r * D, D, lane);
+    const float mu = row.sum(D, lane) / (float)D;
+    const float var = row.sumsq_centered(mu, D, lane) / (float)D;
+    const float rs = 1.0f / sqrtf(var + eps);
+    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+    const int64_t tok = ids_keep ? ids_keep[r] : (r % L);
+    const float *pr = pos + tok * D;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c * 4 < D) {
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + c * 4);
+        const float4 b = *reinterpret_cast<const float4 *>(beta + c * 4);
+        const float4 pe = *reinterpret_cast<const float4 *>(pr + c * 4);
+        float4 o;
+        o.x = gelu_f((row.v[i].x - mu) * rs * g.x + b.x) + pe.x;
+        o.y = gelu_f((row.v[i].y - mu) * rs * g.y + b.y) + pe.y;
+        o.z = gelu_f((row.v[i].z - mu) * rs * g.z + b.z) + pe.z;
+        o.w = gelu_f((row.v[i].w - mu) * rs * g.w + b.w) + pe.w;
+        *reinterpret_cast<float4 *>(out + r * D + c * 4) = o;
+      }
+    }
+  }
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void embed_post_bwd_kernel(const float *g_in, const float *y, const float *gamma,
+                                                             const float *beta, const float *mean, const float *rstd,
+                                                             int64_t M, int D, void *dy, int dy_dtype, float *part) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *sh = reinterpret_cast<float *>(smem_raw);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 dg[VPL], db[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) dg[i] = db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; r < M; r += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
+    Row<VPL> xr, gr;
+    xr.load(y + r * D, D, lane);
+    gr.load(g_in + r * D, D, lane);
+    const float mu = mean[r], rs = rstd[r];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c * 4 < D) {
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + c * 4);
+        const float4 b = *reinterpret_cast<const float4 *>(beta + c * 4);
+        float4 xh;
+        xh.x = (xr.v[i].x - mu) * rs; xh.y = (xr.v[i].y - mu) * rs;
+        xh.z = (xr.v[i].z - mu) * rs; xh.w = (xr.v[i].w - mu) * rs;
+        float4 d;  // gradient w.r.t. the LayerNorm output z = xh*gamma+beta
+        d.x = gr.v[i].x * dgelu_f(xh.x * g.x + b.x);
+        d.y = gr.v[i].y * dgelu_f(xh.y * g.y + b.y);
+        d.z = gr.v[i].z * dgelu_f(xh.z * g.z + b.z);
+        d.w = gr.v[i].w * dgelu_f(xh.w * g.w + b.w);
+        dg[i].x += d.x * xh.x; dg[i].y += d.y * xh.y; dg[i].z += d.z * xh.z; dg[i].w += d.w * xh.w;
+        db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+        float4 t;
+        t.x = d.x * g.x; t.y = d.y * g.y; t.z = d.z * g.z; t.w = d.w * g.w;
+        s1 += (t.x + t.y) + (t.z + t.w);
+        s2 += (t.x * xh.x + t.y * xh.y) + (t.z * xh.z + t.w * xh.w);
+        gr.v[i] = t;
+        xr.v[i] = xh;
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c * 4 < D) {
+        float4 o;
+        o.x = rs * (gr.v[i].x - s1 - xr.v[i].x * s2);
+        o.y = rs * (gr.v[i].y - s1 - xr.v[i].y * s2);
+        o.z = rs * (gr.v[i].z - s1 - xr.v[i].z * s2);
+        o.w = rs * (gr.v[i].w - s1 - xr.v[i].w * s2);
+        store4_any(dy, dy_dtype, r * D + c * 4, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c * 4 < D) {
+      *reinterpret_cast<float4 *>(sh + (wave * 2 + 0) * D + c * 4) = dg[i];
+      *reinterpret_cast<float4 *>(sh + (wave * 2 + 1) * D + c * 4) = db[i];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < ROWS_PER_BLOCK; ++w) s += sh[w * 2 * D + e];
+    part[(int64_t)blockIdx.x * 2 * D + e] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm over rows
+constexpr int BN_ROWS = 64;
+// Welford per (slab, column): part[slab][0][C] = mean, part[slab][1][C] = M2, count = rows in slab
+__global__ __launch_bounds__(256) void bn_stats_partial(const void *x, int dtype, int64_t R, int C, float *part) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int64_t r0 = (int64_t)blockIdx.y * BN_ROWS;
+  const int64_t r1 = r0 + BN_ROWS < R ? r0 + BN_ROWS : R;
+  float mean = 0.f, m2 = 0.f;
+  int n = 0;
+  for (int64_t r = r0; r < r1; ++r) {
+    const float v = ld_any(x, dtype, r * C + c);
+    ++n;
+    const float d = v - mean;
+    mean += d / (float)n;
+    m2 += d * (v - mean);
+  }
+  part[((int64_t)blockIdx.y * 2 + 0) * C + c] = mean;
+  part[((int64_t)blockIdx.y * 2 + 1) * C + c] = m2;
+}
+__global__ void bn_stats_finalize(const float *part, int nslab, int64_t R, int C, float eps, float momentum, float *mean_out,
+                                  float *invstd_out, float *running_mean, float *running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mean = 0.0, m2 = 0.0, n = 0.0;
+  for (int s = 0; s < nslab; ++s) {
+    const int64_t r0 = (int64_t)s * BN_ROWS;
+    const double nb = (double)((r0 + BN_ROWS < R ? r0 + BN_ROWS : R) - r0);
+    const double mb = part[((int64_t)s * 2 + 0) * C + c], m2b = part[((int64_t)s * 2 + 1) * C + c];
+    const double delta = mb - mean, tot = n + nb;
+    mean += delta * nb / tot;
+    m2 += m2b + delta * delta * n * nb / tot;
+    n = tot;
+  }
+  const float var_b = (float)(m2 / n);
+  mean_out[c] = (float)mean;
+  invstd_out[c] = 1.0f / sqrtf(var_b + eps);
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(m2 / (n > 1.0 ? n - 1.0 : 1.0));
+}
+__global__ __launch_bounds__(256) void bn_apply(const void *x, int dtype, int64_t total, int C, const float *gamma,
+                                                const float *beta, const float *mean, const float *invstd, int relu, void *y) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    float v = (ld_any(x, dtype, i) - mean[c]) * invstd[c];
+    if (gamma) v = v * gamma[c] + beta[c];
+    if (relu) v = fmaxf(v, 0.f);
+    st_any(y, dtype, i, v);
+  }
+}
+// part[slab][0][C] = sum dy', part[slab][1][C] = sum dy' * xhat
+__global__ __launch_bounds__(256) void bn_bwd_partial(const void *dy, const void *x, const void *y, int dtype, int64_t R, int C,
+                                                      const float *mean, const float *invstd, int relu, float *part) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int64_t r0 = (int64_t)blockIdx.y * BN_ROWS;
+  const int64_t r1 = r0 + BN_ROWS < R ? r0 + BN_ROWS : R;
+  const float mu = mean[c], is = invstd[c];
+  float s0 = 0.f, s1 = 0.f;
+  for (int64_t r = r0; r < r1; ++r) {
+    float d = ld_any(dy, dtype, r * C + c);
+    if (relu && !(ld_any(y, dtype, r * C + c) > 0.f)) d = 0.f;
+    s0 += d;
+    s1 += d * (ld_any(x, dtype, r * C + c) - mu) * is;
+  }
+  part[((int64_t)blockIdx.y * 2 + 0) * C + c] = s0;
+  part[((int64_t)blockIdx.y * 2 + 1) * C + c] = s1;
+}
+__global__ void bn_bwd_finalize(const float *part, int nslab, int C, float *sum_dy, float *sum_dy_xhat) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int s = 0; s < nslab; ++s) {
+    a += part[((int64_t)s * 2 + 0) * C + c];
+    b += part[((int64_t)s * 2 + 1) * C + c];
+  }
+  sum_dy[c] = a;
+  sum_dy_xhat[c] = b;
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply(const void *dy, const void *x, const void *y, int dtype, int64_t R, int C,
+                                                    const float *gamma, const float *mean, const float *invstd, int relu,
+                                                    const float *sum_dy, const float *sum_dy_xhat, void *dx) {
+  const int64_t total = R * C;
+  const float invR = 1.0f / (float)R;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    float d = ld_any(dy, dtype, i);
+    if (relu && !(ld_any(y, dtype, i) > 0.f)) d = 0.f;
+    const float xh = (ld_any(x, dtype, i) - mean[c]) * invstd[c];
+    const float g = gamma ? gamma[c] : 1.f;
+    st_any(dx, dtype, i, g * invstd[c] * (d - sum_dy[c] * invR - xh * sum_dy_xhat[c] * invR));
+  }
+}
+
+}  // namespace
+
+#define DISPATCH_VPL(D, CALL)                                   \
+  switch (vpl_for(D)) {                                         \
+    case 1: { constexpr int V = 1; CALL; } break;               \
+    case 2: { constexpr int V = 2; CALL; } break;               \
+    case 4: { constexpr int V = 4; CALL; } break;               \
+    case 8: { constexpr int V = 8; CALL; } break;               \
+    default: { constexpr int V = 16; CALL; } break;             \
+  }
+
+extern "C" int evp_layernorm_fwd(const float *x, const float *x2, const float *x3, const float *gamma, const float *beta,
+                                 int64_t M, int D, float eps, void *y, int y_dtype, float *mean, float *rstd, void *stream) {
+  EVP_CHECK_ARG(x && gamma && beta && y, EVP_EINVAL, "evp_layernorm_fwd: null pointer");
+  EVP_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 4096, EVP_ESHAPE, "evp_layernorm_fwd: need M>0, D%%4==0, D<=4096 (M=%lld D=%d)", (long long)M, D);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_VPL(D, hipLaunchKernelGGL(ln_fwd_kernel<V>, dim3(ln_grid(M)), dim3(256), 0, s, x, x2, x3, gamma, beta, M, D, eps, y, y_dtype, mean, rstd));
+  EVP_CHECK_LAUNCH("evp_layernorm_fwd");
+  return EVP_OK;
+}
+
+extern "C" int evp_layernorm_bwd_nblk(int64_t M) { return ln_grid(M); }
+
+extern "C" int evp_layernorm_bwd(const void *dy, int dy_dtype, const float *x, const float *x2, const float *x3,
+                                 const float *gamma, const float *mean, const float *rstd, const float *gres, int64_t M, int D,
+                                 float *dx, void *dx_lp, float *dgamma, float *dbeta, float *workspace, void *stream) {
+  EVP_CHECK_ARG(dy && x && gamma && mean && rstd && workspace, EVP_EINVAL, "evp_layernorm_bwd: null pointer");
+  EVP_CHECK_ARG(dx || dx_lp, EVP_EINVAL, "evp_layernorm_bwd: no output requested");
+  EVP_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 4096, EVP_ESHAPE, "evp_layernorm_bwd: need D%%4==0, D<=4096 (D=%d)", D);
+  hipStream_t s = (hipStream_t)stream;
+  const int g = ln_grid(M);
+  const size_t sh = (size_t)ROWS_PER_BLOCK * 2 * D * sizeof(float);
+  DISPATCH_VPL(D, {
+    if (sh > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ln_bwd_kernel<V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(ln_bwd_kernel<V>, dim3(g), dim3(256), sh, s, dy, dy_dtype, x, x2, x3, gamma, mean, rstd, gres, M, D, dx, dx_lp, workspace);
+  });
+  EVP_CHECK_LAUNCH("evp_layernorm_bwd");
+  hipLaunchKernelGGL(ln_bwd_finalize, dim3((2 * D + 255) / 256), dim3(256), 0, s, workspace, g, D, dgamma, dbeta);
+  EVP_CHECK_LAUNCH("evp_layernorm_bwd(finalize)");
+  return EVP_OK;
+}
+
+extern "C" int evp_colsum_nblk(int64_t M) { return (int)((M + CS_ROWS - 1) / CS_ROWS); }
+
+extern "C" int evp_colsum(const void *x, int x_dtype, int64_t M, int N, int64_t ld, float *out, float *workspace, void *stream) {
+  EVP_CHECK_ARG(x && out && workspace, EVP_EINVAL, "evp_colsum: null pointer");
+  EVP_CHECK_ARG(M > 0 && N > 0 && ld >= N, EVP_ESHAPE, "evp_colsum: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = evp_colsum_nblk(M);
+  hipLaunchKernelGGL(colsum_partial, dim3((N + 255) / 256, nb), dim3(256), 0, s, x, x_dtype, M, N, ld, workspace);
+  EVP_CHECK_LAUNCH("evp_colsum");
+  hipLaunchKernelGGL(colsum_finalize, dim3((N + 255) / 256), dim3(256), 0, s, workspace, nb, N, out);
+  EVP_CHECK_LAUNCH("evp_colsum(finalize)");
+  return EVP_OK;
+}
+
+extern "C" int evp_embed_post_fwd(const float *y, const float *gamma, const float *beta, const float *pos,
+                                  const int64_t *ids_keep, int B, int n_keep, int L, int D, float eps, float *out, float *mean,
+                                  float *rstd, void *stream) {
+  EVP_CHECK_ARG(y && gamma && beta && pos && out && mean && rstd, EVP_EINVAL, "evp_embed_post_fwd: null pointer");
+  EVP_CHECK_ARG(B > 0 && n_keep > 0 && n_keep <= L && D > 0 && D % 4 == 0 && D <= 4096, EVP_ESHAPE, "evp_embed_post_fwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t M = (int64_t)B * n_keep;
+  DISPATCH_VPL(D, hipLaunchKernelGGL(embed_post_fwd_kernel<V>, dim3(ln_grid(M)), dim3(256), 0, s, y, gamma, beta, pos, ids_keep, M, n_keep, L, D, eps, out, mean, rstd));
+  EVP_CHECK_LAUNCH("evp_embed_post_fwd");
+  return EVP_OK;
+}
+
+extern "C" int evp_embed_post_bwd(const float *g, const float *y, const float *gamma, const float *beta, const float *mean,
+                                  const float *rstd, int64_t M, int D, void *dy, int dy_dtype, float *dgamma, float *dbeta,
+                                  float *workspace, void *stream) {
+  EVP_CHECK_ARG(g && y && gamma && beta && mean && rstd && dy && workspace, EVP_EINVAL, "evp_embed_post_bwd: null pointer");
+  EVP_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 4096, EVP_ESHAPE, "evp_embed_post_bwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int gsz = ln_grid(M);
+  const size_t sh = (size_t)ROWS_PER_BLOCK * 2 * D * sizeof(float);
+  DISPATCH_VPL(D, {
+    if (sh > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(embed_post_bwd_kernel<V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(embed_post_bwd_kernel<V>, dim3(gsz), dim3(256), sh, s, g, y, gamma, beta, mean, rstd, M, D, dy, dy_dtype, workspace);
+  });
+  EVP_CHECK_LAUNCH("evp_embed_post_bwd");
+  hipLaunchKernelGGL(ln_bwd_finalize, dim3((2 * D + 255) / 256), dim3(256), 0, s, workspace, gsz, D, dgamma, dbeta);
+  EVP_CHECK_LAUNCH("evp_embed_post_bwd(finalize)");
+  return EVP_OK;
+}
+
+extern "C" int evp_batchnorm_nblk(int64_t R) { return (int)((R + BN_ROWS - 1) / BN_ROWS); }
+
+extern "C" int evp_batchnorm_fwd(const void *x, int dtype, int64_t R, int C, const float *gamma, const float *beta, float eps,
+                                 float momentum, int relu, void *y, float *mean, float *invstd, float *running_mean,
+                                 float *running_var, float *workspace, void *stream) {
+  EVP_CHECK_ARG(x && y && mean && invstd && workspace, EVP_EINVAL, "evp_batchnorm_fwd: null pointer");
+  EVP_CHECK_ARG(R > 1 && C > 0, EVP_ESHAPE, "evp_batchnorm_fwd: need R>1 rows");
+  EVP_CHECK_ARG((gamma == nullptr) == (beta == nullptr), EVP_EINVAL, "evp_batchnorm_fwd: gamma and beta go together");
+  hipStream_t s = (hipStream_t)stream;
+  const int ns = evp_batchnorm_nblk(R);
+  hipLaunchKernelGGL(bn_stats_partial, dim3((C + 255) / 256, ns), dim3(256), 0, s, x, dtype, R, C, workspace);
+  EVP_CHECK_LAUNCH("evp_batchnorm_fwd(stats)");
+  hipLaunchKernelGGL(bn_stats_finalize, dim3((C + 255) / 256), dim3(256), 0, s, workspace, ns, R, C, eps, momentum, mean, invstd, running_mean, running_var);
+  EVP_CHECK_LAUNCH("evp_batchnorm_fwd(finalize)");
+  const int64_t total = R * C;
+  int64_t g = (total + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(bn_apply, dim3((int)g), dim3(256), 0, s, x, dtype, total, C, gamma, beta, mean, invstd, relu, y);
+  EVP_CHECK_LAUNCH("evp_batchnorm_fwd(apply)");
+  return EVP_OK;
+}
+
+extern "C" int evp_batchnorm_bwd(const void *dy, const void *x, const void *y, int dtype, int64_t R, int C, const float *gamma,
+                                 const float *mean, const float *invstd, int relu, void *dx, float *dgamma, float *dbeta,
+                                 float *workspace, void *stream) {
+  EVP_CHECK_ARG(dy && x && mean && invstd && dx && workspace, EVP_EINVAL, "evp_batchnorm_bwd: null pointer");
+  EVP_CHECK_ARG(!relu || y, EVP_EINVAL, "evp_batchnorm_bwd: relu needs y");
+  hipStream_t s = (hipStream_t)stream;
+  const int ns = evp_batchnorm_nblk(R);
+  float *sum_dy = workspace + (int64_t)ns * 2 * C, *sum_dy_xhat = sum_dy + C;
+  hipLaunchKernelGGL(bn_bwd_partial, dim3((C + 255) / 256, ns), dim3(256), 0, s, dy, x, y, dtype, R, C, mean, invstd, relu, workspace);
+  EVP_CHECK_LAUNCH("evp_batchnorm_bwd(partial)");
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, workspace, ns, C, sum_dy, sum_dy_xhat);
+  EVP_CHECK_LAUNCH("evp_batchnorm_bwd(finalize)");
+  const int64_t total = R * C;
+  int64_t g = (total + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(bn_bwd_apply, dim3((int)g), dim3(256), 0, s, dy, x, y, dtype, R, C, gamma, mean, invstd, relu, sum_dy, sum_dy_xhat, dx);
+  EVP_CHECK_LAUNCH("evp_batchnorm_bwd(apply)");
+  if (dgamma) hipMemcpyAsync(dgamma, sum_dy_xhat, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
+  if (dbeta) hipMemcpyAsync(dbeta, sum_dy, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
+  return EVP_OK;
+}

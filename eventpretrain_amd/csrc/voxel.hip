@@ -1,0 +1,245 @@
+// K1: event stream -> voxel grid (bilinear-in-time polarity histogram) for a batch of clips, gfx950.
+//
+// Restates dataset/dataset_utils/events_to_voxel_grid.py:4-61 of the reference (two index_add_ scatters) as
+//   1. voxel_cuts_kernel : per clip, a 64-ary wave search over the (time-sorted) stamps for the first event with
+//                          ts >= k, k = 0..bins  -> the contiguous event slab that can touch bin plane b.
+//   2. voxel_bin_kernel  : one workgroup per (clip, bin, y-tile). The tile of the bin plane lives in LDS
+//                          (ds_add_f32), the workgroup streams its event slab with coalesced 32-byte rows, and the
+//                          tile is flushed ONCE with coalesced 16-byte stores -- no global atomics, no memset,
+//                          every output byte written exactly once.
+//      Blocks of one clip are mapped to one XCD (blockIdx % 8) so the slab re-reads (one per bin / y-tile) are
+//      served by that XCD's L2, not by HBM.
+// algo 1 keeps the plain global-atomic formulation (memset + 2 atomics per event) for A/B measurements.
+//
+// HBM-bound. Algorithmic bytes per clip: n*32 B of events read + bins*H*W*4 B written.
+#include "evp_common.h"
+
+namespace {
+
+struct Event { double x, y, t, p; };
+// rows are (x,y,t,p), or (t,x,y,p) when is_txyp (events_to_voxel_grid.py:14-34)
+__device__ __forceinline__ Event load_event(const double *ev, int64_t i, int is_txyp) {
+  const double2 a = *reinterpret_cast<const double2 *>(ev + i * 4);
+  const double2 b = *reinterpret_cast<const double2 *>(ev + i * 4 + 2);
+  Event e;
+  e.x = is_txyp ? a.y : a.x;
+  e.y = is_txyp ? b.x : a.y;
+  e.t = is_txyp ? a.x : b.x;
+  e.p = b.y;
+  return e;
+}
+__device__ __forceinline__ double stamp(const double *ev, int64_t i, int is_txyp) { return ev[i * 4 + (is_txyp ? 0 : 2)]; }
+
+// ts exactly as events_to_voxel_grid.py:30/34 computes it (float64): (bins-1) * (t - t0) / dT
+__device__ __forceinline__ double ts_of(double t, double t0, double dT, int bins) { return (double)(bins - 1) * (t - t0) / dT; }
+
+// cuts[c][k], k = 0..bins: first row i (clip-relative) with ts_i >= k; cuts[c][bins+1] = n (unused sentinel)
+__global__ __launch_bounds__(256) void voxel_cuts_kernel(const double *events, const int64_t *offsets, int bins, int is_txyp,
+                                                         int64_t *cuts) {
+  const int c = blockIdx.x;
+  const int64_t beg = offsets[c], n = offsets[c + 1] - beg;
+  const double *ev = events + beg * 4;
+  int64_t *out = cuts + (int64_t)c * (bins + 2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (n <= 0) {
+    for (int k = threadIdx.x; k <= bins + 1; k += blockDim.x) out[k] = 0;
+    return;
+  }
+  const double t0 = stamp(ev, 0, is_txyp), t1 = stamp(ev, n - 1, is_txyp);
+  double dT = t1 - t0;
+  if (dT == 0) dT = 1.0;
+  for (int k = wave; k <= bins; k += nw) {
+    int64_t lo = 0, hi = n;  // answer in [lo, hi]
+    while (hi > lo) {
+      const int64_t step = (hi - lo + 63) / 64;
+      const int64_t idx = lo + (int64_t)lane * step;
+      bool pred = false;
+      if (idx < hi) pred = ts_of(stamp(ev, idx, is_txyp), t0, dT, bins) >= (double)k;
+      const unsigned long long m = __ballot(pred);
+      // lanes whose probe is out of range report false; they sit after every in-range probe
+      if (m == 0ull) {
+        const int64_t last = lo + ((hi - 1 - lo) / step) * step;  // last in-range probe
+        lo = last + 1;
+      } else {
+        const int f = __ffsll((long long)m) - 1;
+        const int64_t pf = lo + (int64_t)f * step;
+        if (f > 0) lo = pf - step + 1;
+        hi = pf;
+      }
+    }
+    if (lane == 0) out[k] = lo;
+  }
+  if (threadIdx.x == 0) out[bins + 1] = n;
+}
+
+// Contribution of one event to bin plane `b`: returns false if none. pix = x + y*W (flat, as the reference).
+__device__ __forceinline__ bool contribution(const Event &e, double t0, double dT, int bins, int b, int W, int64_t &pix,
+                                             float &val) {
+  const double ts = ts_of(e.t, t0, dT, bins);
+  const double tf = floor(ts);
+  if (!(tf >= 0.0)) return false;  // also rejects NaN
+  float p = (float)e.p;
+  if (p == 0.0f) p = -1.0f;
+  const float dt = (float)(ts - tf);
+  if (tf == (double)b) val = p * (1.0f - dt);          // left neighbour, valid since b < bins
+  else if (tf + 1.0 == (double)b) val = p * dt;         // right neighbour
+  else return false;
+  pix = (int64_t)e.x + (int64_t)e.y * (int64_t)W;
+  return true;
+}
+
+constexpr int VB_THREADS = 512;
+constexpr int VB_UNROLL = 4;
+
+__global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *events, const int64_t *offsets, const int64_t *cuts,
+                                                               int n_clips, int bins, int H, int W, int is_txyp,
+                                                               int assume_sorted, int tile_rows, int n_yt, float *out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *tile = reinterpret_cast<float *>(smem_raw);
+  const int per_clip = bins * n_yt;
+  int clip, sub;
+  if ((n_clips & 7) == 0) {  // keep one clip's blocks on one XCD (blocks b and b+8 share an XCD)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    clip = (slot / per_clip) * 8 + xcd;
+    sub = slot % per_clip;
+  } else {
+    clip = blockIdx.x / per_clip;
+    sub = blockIdx.x % per_clip;
+  }
+  const int b = sub / n_yt, yt = sub % n_yt;
+  const int y0 = yt * tile_rows, y1 = (y0 + tile_rows < H) ? y0 + tile_rows : H;
+  const int tile_elems = (y1 - y0) * W;
+  for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) tile[i] = 0.f;
+  __syncthreads();
+
+  const int64_t beg = offsets[clip], n = offsets[clip + 1] - beg;
+  float *dst = out + (((int64_t)clip * bins + b) * H + y0) * W;
+  if (n > 0) {
+    const double *ev = events + beg * 4;
+    const double t0 = stamp(ev, 0, is_txyp), t1 = stamp(ev, n - 1, is_txyp);
+    double dT = t1 - t0;
+    if (dT == 0) dT = 1.0;
+    const int64_t *cc = cuts + (int64_t)clip * (bins + 2);
+    // sorted: only rows with floor(ts) in {b-1, b} can touch plane b; unsorted: scan the whole clip
+    const int64_t lo = assume_sorted ? cc[b > 0 ? b - 1 : 0] : 0;
+    const int64_t hi = assume_sorted ? cc[b + 1] : n;
+    const int64_t pix0 = (int64_t)y0 * W, pix1 = (int64_t)y1 * W;
+    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)VB_THREADS * VB_UNROLL) {
+      Event e[VB_UNROLL];
+      bool live[VB_UNROLL];
+#pragma unroll
+      for (int u = 0; u < VB_UNROLL; ++u) {
+        const int64_t i = i0 + (int64_t)u * VB_THREADS;
+        live[u] = i < hi;
+        e[u] = load_event(ev, live[u] ? i : lo, is_txyp);
+      }
+#pragma unroll
+      for (int u = 0; u < VB_UNROLL; ++u) {
+        int64_t pix;
+        float val;
+        if (live[u] && contribution(e[u], t0, dT, bins, b, W, pix, val) && pix >= pix0 && pix < pix1)
+          atomicAdd(&tile[pix - pix0], val);
+      }
+    }
+  }
+  __syncthreads();
+  if ((W & 3) == 0) {
+    for (int i = threadIdx.x; i < tile_elems / 4; i += VB_THREADS)
+      reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(tile)[i];
+  } else {
+    for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) dst[i] = tile[i];
+  }
+}
+
+// algo 1: two global float atomics per event into a pre-zeroed grid
+__global__ __launch_bounds__(256) void voxel_atomic_kernel(const double *events, const int64_t *offsets, int bins, int H, int W,
+                                                           int is_txyp, float *out) {
+  const int clip = blockIdx.y;
+  const int64_t beg = offsets[clip], n = offsets[clip + 1] - beg;
+  if (n <= 0) return;
+  const double *ev = events + beg * 4;
+  const double t0 = stamp(ev, 0, is_txyp), t1 = stamp(ev, n - 1, is_txyp);
+  double dT = t1 - t0;
+  if (dT == 0) dT = 1.0;
+  const int64_t plane = (int64_t)H * W;
+  float *grid = out + (int64_t)clip * bins * plane;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const Event e = load_event(ev, i, is_txyp);
+    const double ts = ts_of(e.t, t0, dT, bins);
+    const double tf = floor(ts);
+    if (!(tf >= 0.0)) continue;
+    float p = (float)e.p;
+    if (p == 0.0f) p = -1.0f;
+    const float dt = (float)(ts - tf);
+    const int64_t pix = (int64_t)e.x + (int64_t)e.y * (int64_t)W;
+    if (pix < 0 || pix >= plane) continue;
+    if (tf < (double)bins) atomicAdd(&grid[(int64_t)tf * plane + pix], p * (1.0f - dt));
+    if (tf + 1.0 < (double)bins) atomicAdd(&grid[((int64_t)tf + 1) * plane + pix], p * dt);
+  }
+}
+
+__global__ __launch_bounds__(256) void sorted_check_kernel(const double *events, const int64_t *offsets, int is_txyp, int32_t *flags) {
+  __shared__ int bad;
+  const int clip = blockIdx.x;
+  const int64_t beg = offsets[clip], n = offsets[clip + 1] - beg;
+  const int ct = is_txyp ? 0 : 2;
+  if (threadIdx.x == 0) bad = 0;
+  __syncthreads();
+  const double *ev = events + beg * 4;
+  int mybad = 0;
+  for (int64_t i = threadIdx.x + 1; i < n; i += blockDim.x)
+    if (!(ev[i * 4 + ct] >= ev[(i - 1) * 4 + ct])) mybad = 1;
+  if (mybad) atomicOr(&bad, 1);
+  __syncthreads();
+  if (threadIdx.x == 0) flags[clip] = bad ? 0 : 1;
+}
+
+}  // namespace
+
+extern "C" int evp_voxel_scatter_f32(const double *events, const int64_t *clip_offsets, int n_clips, int bins, int H, int W,
+                                     int is_txyp, int assume_sorted, int algo, int tile_rows, int64_t *workspace, float *out,
+                                     void *stream) {
+  EVP_CHECK_ARG(events && clip_offsets && out, EVP_EINVAL, "evp_voxel_scatter_f32: null pointer");
+  EVP_CHECK_ARG(n_clips > 0 && bins > 0 && bins <= 64 && H > 0 && W > 0, EVP_ESHAPE,
+                "evp_voxel_scatter_f32: need n_clips>0, 0<bins<=64, H,W>0 (got %d,%d,%d,%d)", n_clips, bins, H, W);
+  EVP_CHECK_ARG(((uintptr_t)events & 15) == 0, EVP_EINVAL, "evp_voxel_scatter_f32: events must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (algo == 1) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)n_clips * bins * H * W, s);
+    EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_voxel_scatter_f32: memset failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(voxel_atomic_kernel, dim3(64, n_clips), dim3(256), 0, s, events, clip_offsets, bins, H, W, is_txyp, out);
+    EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(atomic)");
+    return EVP_OK;
+  }
+  EVP_CHECK_ARG(algo == 0, EVP_EINVAL, "evp_voxel_scatter_f32: unknown algo %d", algo);
+  EVP_CHECK_ARG(workspace, EVP_EINVAL, "evp_voxel_scatter_f32: workspace (int64[n_clips*(bins+2)]) required for algo 0");
+  if (tile_rows <= 0) {
+    const int max_rows = (56 * 1024) / (W * 4);  // <= 56 KiB of LDS per block: 2-3 blocks per CU
+    tile_rows = max_rows < 1 ? 1 : (max_rows > H ? H : max_rows);
+    const int nyt = (H + tile_rows - 1) / tile_rows;
+    tile_rows = (H + nyt - 1) / nyt;  // balance the tiles
+  }
+  EVP_CHECK_ARG((size_t)tile_rows * W * 4 <= 160 * 1024, EVP_ESHAPE, "evp_voxel_scatter_f32: tile of %d rows x %d exceeds LDS", tile_rows, W);
+  const int n_yt = (H + tile_rows - 1) / tile_rows;
+  const size_t smem = (size_t)tile_rows * W * sizeof(float);
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(voxel_bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_voxel_scatter_f32: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
+  }
+  if (assume_sorted) {
+    hipLaunchKernelGGL(voxel_cuts_kernel, dim3(n_clips), dim3(256), 0, s, events, clip_offsets, bins, is_txyp, workspace);
+    EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(cuts)");
+  }
+  hipLaunchKernelGGL(voxel_bin_kernel, dim3(n_clips * bins * n_yt), dim3(VB_THREADS), smem, s, events, clip_offsets, workspace, n_clips,
+                     bins, H, W, is_txyp, assume_sorted, tile_rows, n_yt, out);
+  EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(bin)");
+  return EVP_OK;
+}
+
+extern "C" int evp_events_sorted_check(const double *events, const int64_t *clip_offsets, int n_clips, int is_txyp,
+                                       int32_t *sorted_flags, void *stream) {
+  EVP_CHECK_ARG(events && clip_offsets && sorted_flags && n_clips > 0, EVP_EINVAL, "evp_events_sorted_check: bad argument");
+  hipLaunchKernelGGL(sorted_check_kernel, dim3(n_clips), dim3(256), 0, (hipStream_t)stream, events, clip_offsets, is_txyp, sorted_flags);
+  EVP_CHECK_LAUNCH("evp_events_sorted_check");
+  return EVP_OK;
+}

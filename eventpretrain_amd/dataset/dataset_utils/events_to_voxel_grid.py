@@ -1,0 +1,43 @@
+"""Event stream -> voxel grid on the GPU (csrc/voxel.hip), behind the reference's function name and arguments
+(reference dataset/dataset_utils/events_to_voxel_grid.py:4-61), plus a batched device-resident entry point that the
+input pipeline / bench uses (one launch for a whole batch of clips)."""
+import numpy as np
+import torch
+
+from ... import _lib
+from ..._lib import call, ptr, stream_ptr
+
+
+def voxel_grid_batch(events, clip_offsets, num_bins, size, is_txyp=False, assume_sorted=True, algo=0, tile_rows=0, out=None):
+    """events: float64 CUDA tensor [n_total,4]; clip_offsets: int64 CUDA tensor [n_clips+1] -> float32
+    [n_clips, num_bins, H, W]. Rows of each clip must be time-sorted unless assume_sorted=False."""
+    _lib.require_device()
+    if events.dtype != torch.float64 or events.dim() != 2 or events.shape[1] != 4 or not events.is_contiguous():
+        raise _lib.EvpError("events must be a contiguous float64 [N,4] tensor")
+    if clip_offsets.dtype != torch.int64:
+        raise _lib.EvpError("clip_offsets must be int64")
+    H, W = int(size[0]), int(size[1])
+    n_clips = clip_offsets.numel() - 1
+    dev = events.device
+    if out is None:
+        out = torch.empty(n_clips, num_bins, H, W, dtype=torch.float32, device=dev)
+    ws = torch.empty(n_clips * (num_bins + 2), dtype=torch.int64, device=dev)
+    call("evp_voxel_scatter_f32", ptr(events), ptr(clip_offsets), n_clips, int(num_bins), H, W, int(bool(is_txyp)),
+         int(bool(assume_sorted)), int(algo), int(tile_rows), ptr(ws), ptr(out), stream_ptr())
+    return out
+
+
+def events_to_voxel_grid(args, events, size, is_txyp=False):
+    """Drop-in for the reference function: events is a numpy float64 [N,4] array (x,y,t,p) or (t,x,y,p); returns a
+    float32 [num_bins,H,W] tensor -- in device memory (the next consumer is the GPU model). Sortedness of the
+    stamps is checked on the host array so that unsorted input still gives the reference's result."""
+    _lib.require_device()
+    ev = np.ascontiguousarray(events, dtype=np.float64)
+    if ev.ndim != 2 or ev.shape[1] != 4:
+        raise AssertionError("events must be [N,4]")
+    t = ev[:, 0 if is_txyp else 2]
+    is_sorted = bool(np.all(t[1:] >= t[:-1])) if ev.shape[0] > 1 else True
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ev_d = torch.from_numpy(ev).to(dev)
+    off = torch.tensor([0, ev.shape[0]], dtype=torch.int64, device=dev)
+    return voxel_grid_batch(ev_d, off, args.num_bins, size, is_txyp=is_txyp, assume_sorted=is_sorted)[0]

@@ -1,0 +1,139 @@
+"""Hub model of the pre-training stages (reference model/pretrain/pr_hub_model.py:14-281): backbone + difference-map
+decoder (masked modeling, `is_rec=True`) or backbone + MoCo-v3 heads + CLIP-token branch (contrastive stages).
+Same constructor arguments, factories, forward signature, return tuples and state-dict keys as the reference."""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..backbone import vit
+from ..backbone.vit import init_linear_and_norm
+from ..sub_module.mlp_head import _build_mlp_2d, run_mlp_2d
+from . import pr_rec_decoder
+
+_CON_PHASES = ("adj", "_adj", "con", "adj-n", "con-n", "rec+con")
+_REC_PHASES = ("rec", "rec+con", "rec-n")
+
+
+class PrHubModel(nn.Module):
+    def __init__(self, args, patch_size=16, num_patches=196, embed_dim=1024, mlp_dim=4096,
+                 proj_mlp_layers=3, pred_mlp_layers=2, norm_layer=nn.LayerNorm,
+                 emb_frames_dim=512, queue_length=65536, T=0.07, rec_decoder_factory=None):
+        super().__init__()
+        self.args = args
+        self.patch_size = patch_size
+        self.T = T
+        self.backbone_type = args.backbone_type
+        self.mask_ratio = args.mask_ratio
+        self.norm_pix_loss = args.norm_pix_loss
+        common = dict(args=args, num_bins=args.num_bins, mask_ratio=args.mask_ratio, drop_rate=args.drop_rate,
+                      attn_drop_rate=args.attn_drop_rate, drop_path_rate=args.drop_path_rate)
+        if args.backbone_type == "vit":
+            factory = {"small": "vit_small_patch16", "base": "vit_base_patch16", "tiny": "vit_tiny_patch16_64"}
+            if args.model_size not in factory:
+                raise ValueError(args.model_size)
+            self.backbone = vit.__dict__[factory[args.model_size]](**common)
+        elif args.backbone_type in ("convvit", "swin"):
+            raise NotImplementedError(f"backbone_type={args.backbone_type}: not built yet on the MI355X path "
+                                      "(DESIGN.md, scope table rows a14/a15)")
+        else:
+            raise ValueError(args.backbone_type)
+
+        if args.pr_phase in _REC_PHASES:
+            # The reference always builds the 384-wide "small" decoder here (pr_hub_model.py:77), which cannot take
+            # a 768-wide backbone (SURVEY.md header). `rec_decoder_factory` lets the base / tiny factories pick the
+            # decoder that fits; the default reproduces the reference.
+            name = rec_decoder_factory or "pretrain_rec_decoder_small_patch16"
+            self.pretrain_rec_decoder = pr_rec_decoder.__dict__[name](frame_chans=args.frame_chans)
+
+        if args.pr_phase in _CON_PHASES:
+            C_out = embed_dim[-1]
+            if args.use_queue:
+                self.queue_length = queue_length
+                q = torch.randn(C_out, num_patches, queue_length)
+                self.register_buffer("queue", nn.functional.normalize(q, dim=0))
+                self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+            self.emb_h_proj = _build_mlp_2d(proj_mlp_layers, C_out, mlp_dim, C_out)
+            self.emb_h_pred = _build_mlp_2d(pred_mlp_layers, C_out, mlp_dim, C_out)
+            self.norm_clip_emb = norm_layer(emb_frames_dim)
+            self.clip_emb_proj = nn.Linear(emb_frames_dim, C_out, bias=False)
+        self.apply(init_linear_and_norm)
+
+    # ------------------------------------------------------------------------------------------------ losses
+    def reconstruct_loss(self, reconstruct_pred, sub_frame, mask):
+        """Per-patch-normalised masked MSE against the patchified difference map (pr_hub_model.py:125-141)."""
+        m = None if self.mask_ratio == 0 else mask.contiguous()
+        return ops.RecLossFn.apply(reconstruct_pred, sub_frame, m, self.patch_size, self.norm_pix_loss)
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, keys):
+        """queue[:, :, ptr:ptr+B] = keys^T with all three dims reversed ((B,L,C) -> (C,L,B)), pointer advances
+        modulo the queue length (pr_hub_model.py:112-122)."""
+        B = keys.shape[0]
+        ptr_ = int(self.queue_ptr)
+        if self.queue_length % B:
+            raise AssertionError("queue_length must be a multiple of the batch size")
+        ops.enqueue_keys(self.queue, keys, ptr_)
+        self.queue_ptr[0] = (ptr_ + B) % self.queue_length
+
+    def contrastive_loss_queue(self, emb_h, clip_emb):
+        loss, k = ops.info_nce_queue(emb_h, clip_emb, self.queue, self.T)
+        self._dequeue_and_enqueue(k)
+        return loss
+
+    def contrastive_loss(self, emb_h, clip_emb):
+        return ops.info_nce_inbatch(emb_h, clip_emb, self.T, distributed=bool(self.args.distributed))
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, events_voxel_grid, supp_data, is_rec=False, noise=None):
+        if is_rec:
+            emb_l1, emb_l2, emb_lh, mask, ids_restore = self.backbone(events_voxel_grid, mask=True, noise=noise)
+            reconstruct_pred = self.pretrain_rec_decoder(emb_lh, ids_restore)
+            reconstruct_loss = self.reconstruct_loss(reconstruct_pred, supp_data, mask)
+            return reconstruct_loss, emb_l1, emb_l2, emb_lh, reconstruct_pred, mask, ids_restore
+
+        _, _, emb_h, attn = self.backbone(events_voxel_grid)
+        emb_h_org = emb_h.detach().clone()
+        clip_emb = ops.LayerNormFn.apply(supp_data[:, 1:, :], None, None, self.norm_clip_emb.weight,
+                                         self.norm_clip_emb.bias, self.norm_clip_emb.eps)
+        clip_emb_org = clip_emb.detach().clone()
+        clip_emb_proj = ops.LinearFn.apply(clip_emb, self.clip_emb_proj.weight, None)
+        emb_h = run_mlp_2d(self.emb_h_proj, emb_h)
+        emb_h_proj = run_mlp_2d(self.emb_h_pred, emb_h)
+        if self.args.use_queue:
+            contrastive_loss = self.contrastive_loss_queue(emb_h_proj, clip_emb_proj)
+        else:
+            contrastive_loss = self.contrastive_loss(emb_h_proj, clip_emb_proj)
+        return contrastive_loss, emb_h_org, emb_h_proj, clip_emb_org, clip_emb_proj, attn
+
+
+@torch.no_grad()
+def concat_all_gather(tensor):
+    """all_gather along dim 0 without gradient (pr_hub_model.py:248-259) -- RCCL over xGMI under backend 'nccl'."""
+    import torch.distributed as dist
+    world = dist.get_world_size()
+    out = torch.empty((world * tensor.shape[0],) + tuple(tensor.shape[1:]), dtype=tensor.dtype, device=tensor.device)
+    dist.all_gather_into_tensor(out, tensor.contiguous())
+    return out
+
+
+def pretrain_hub_model_small_patch16(args, **kwargs):
+    return PrHubModel(args=args, patch_size=16, num_patches=196, embed_dim=[128, 256, 384], mlp_dim=4096,
+                      proj_mlp_layers=3, pred_mlp_layers=2, norm_layer=nn.LayerNorm, **kwargs)
+
+
+def pretrain_hub_model_base_patch16(args, **kwargs):
+    """ViT-Base hub. The reference's factory of this name builds the 384-wide decoder and cannot run
+    (SURVEY.md header); here the base decoder (pr_rec_decoder.py:89-95) is attached, which is the composition
+    BASELINE.json config 2 names."""
+    kwargs.setdefault("rec_decoder_factory", "pretrain_rec_decoder_base_patch16")
+    return PrHubModel(args=args, patch_size=16, num_patches=196, embed_dim=[256, 384, 768], mlp_dim=4096,
+                      proj_mlp_layers=3, pred_mlp_layers=2, norm_layer=nn.LayerNorm, **kwargs)
+
+
+def pretrain_hub_model_tiny_patch16_64(args, **kwargs):
+    """BASELINE.json config 1 plumbing model (64x64 voxels, 16 patches)."""
+    kwargs.setdefault("rec_decoder_factory", "pretrain_rec_decoder_tiny_patch16_64")
+    return PrHubModel(args=args, patch_size=16, num_patches=16, embed_dim=[192], mlp_dim=512,
+                      proj_mlp_layers=3, pred_mlp_layers=2, norm_layer=nn.LayerNorm, **kwargs)

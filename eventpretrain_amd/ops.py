@@ -1,0 +1,441 @@
+"""Thin Python layer over the C-ABI: tensor -> pointer plumbing and the torch.autograd.Function wrappers that make
+the HIP kernels differentiable building blocks of the reference's modules.
+
+Precision modes (set with `set_compute_dtype`):
+  * torch.float32  -- "parity mode": exact-f32 MFMA GEMMs, f32 activations; checked against the CPU oracle to 1e-4.
+  * torch.bfloat16 -- "throughput mode": bf16 MFMA GEMMs with f32 accumulation, bf16 GEMM operands, f32 residual
+                      stream / LayerNorm statistics / softmax / loss / optimizer state.
+Every tensor handed to a kernel is allocated by PyTorch; all arithmetic happens in libevtpretrain.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_DGELU, ACT_DRELU, ACT_GELU, ACT_NONE, ACT_RELU, EVP_BF16, EVP_F32, GemmDesc, call, dt, ptr,
+                   stream_ptr)
+
+_compute_dtype = torch.float32
+
+
+def set_compute_dtype(dtype):
+    """torch.float32 (parity mode) or torch.bfloat16 (throughput mode)."""
+    global _compute_dtype
+    if isinstance(dtype, str):
+        dtype = {"fp32": torch.float32, "f32": torch.float32, "float32": torch.float32,
+                 "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}[dtype]
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be float32 or bfloat16")
+    _compute_dtype = dtype
+
+
+def get_compute_dtype():
+    return _compute_dtype
+
+
+def _code(dtype):
+    return EVP_BF16 if dtype == torch.bfloat16 else EVP_F32
+
+
+def _chk(t, dtype=None):
+    if not t.is_cuda:
+        raise _lib.EvpError("tensor is not in device memory; eventpretrain_amd has no CPU path")
+    if not t.is_contiguous():
+        raise _lib.EvpError("kernel operand must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.EvpError(f"expected {dtype}, got {t.dtype}")
+    return t
+
+
+# ----------------------------------------------------------------------------------------------------- raw calls
+def gemm(a, b, out, *, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, bias=None, act=ACT_NONE,
+         aux=None, residual=None, alpha=1.0, accumulate=False, batch=(1, 1), stride_a=(0, 0), stride_b=(0, 0),
+         stride_c=(0, 0), a_off=0, b_off=0, c_off=0, tile=0):
+    """out = epilogue(alpha * A . B^T); offsets/strides in ELEMENTS. See include/evtpretrain.h (evp_gemm)."""
+    if not (a.is_cuda and b.is_cuda and out.is_cuda):
+        raise _lib.EvpError("gemm operands must be in device memory; eventpretrain_amd has no CPU path")
+    if a.dtype != b.dtype:
+        raise _lib.EvpError("gemm: A and B must share a dtype")
+    d = GemmDesc()
+    d.dtype = dt(a)
+    d.transA, d.transB = int(trans_a), int(trans_b)
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    es = a.element_size()
+    d.A = a.data_ptr() + a_off * es
+    d.lda = int(lda if lda is not None else (M if trans_a else K))
+    d.strideA0, d.strideA1 = int(stride_a[0]), int(stride_a[1])
+    d.B = b.data_ptr() + b_off * es
+    d.ldb = int(ldb if ldb is not None else (N if trans_b else K))
+    d.strideB0, d.strideB1 = int(stride_b[0]), int(stride_b[1])
+    d.C = out.data_ptr() + c_off * out.element_size()
+    d.c_dtype = dt(out)
+    d.ldc = int(ldc if ldc is not None else N)
+    d.strideC0, d.strideC1 = int(stride_c[0]), int(stride_c[1])
+    d.batch0, d.batch1 = int(batch[0]), int(batch[1])
+    d.alpha = float(alpha)
+    d.bias = ptr(bias)
+    d.act = int(act)
+    d.aux = ptr(aux)
+    d.ldaux = d.ldc
+    d.residual = ptr(residual)
+    d.ldres = d.ldc
+    d.accumulate = int(accumulate)
+    d.tile = int(tile)
+    call("evp_gemm", C.byref(d), stream_ptr())
+    return out
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    out = torch.empty_like(x, dtype=dtype)
+    call("evp_cast", ptr(_chk(x)), dt(x), ptr(out), dt(out), x.numel(), stream_ptr())
+    return out
+
+
+def lp_weight(w):
+    """Weight in the compute dtype. In bf16 mode the shadow copy is cached on the Parameter and kept current by
+    FusedAdamW (which writes it in the same kernel that updates the f32 master weight)."""
+    if _compute_dtype == torch.float32:
+        return w.detach()
+    sh = getattr(w, "_evp_lp", None)
+    if sh is None or getattr(w, "_evp_lp_version", -1) != w._version or sh.device != w.device:
+        sh = torch.empty(w.shape, dtype=torch.bfloat16, device=w.device)
+        call("evp_cast", ptr(_chk(w.detach())), EVP_F32, ptr(sh), EVP_BF16, w.numel(), stream_ptr())
+        w._evp_lp = sh
+        w._evp_lp_version = w._version
+    return sh
+
+
+def colsum(x2d, out=None):
+    M, N = x2d.shape
+    out = torch.empty(N, dtype=torch.float32, device=x2d.device) if out is None else out
+    nb = call("evp_colsum_nblk", M)
+    ws = torch.empty(nb * N, dtype=torch.float32, device=x2d.device)
+    call("evp_colsum", ptr(_chk(x2d)), dt(x2d), M, N, N, ptr(out), ptr(ws), stream_ptr())
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps, out_dtype, x2=None, x3=None):
+    M, D = x.shape
+    y = torch.empty(M, D, dtype=out_dtype, device=x.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    call("evp_layernorm_fwd", ptr(_chk(x, torch.float32)), ptr(x2), ptr(x3), ptr(gamma), ptr(beta), M, D, float(eps),
+         ptr(y), dt(y), ptr(mean), ptr(rstd), stream_ptr())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, gres=None, x2=None, x3=None, want_lp=False):
+    """Returns (dx f32, dx_lp bf16|None, dgamma, dbeta)."""
+    M, D = x.shape
+    dx = torch.empty(M, D, dtype=torch.float32, device=x.device)
+    dx_lp = torch.empty(M, D, dtype=torch.bfloat16, device=x.device) if want_lp else None
+    dgamma = torch.empty(D, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(D, dtype=torch.float32, device=x.device)
+    nb = call("evp_layernorm_bwd_nblk", M)
+    ws = torch.empty(2 * nb * D, dtype=torch.float32, device=x.device)
+    call("evp_layernorm_bwd", ptr(_chk(dy)), dt(dy), ptr(x), ptr(x2), ptr(x3), ptr(gamma), ptr(mean), ptr(rstd),
+         ptr(gres), M, D, ptr(dx), ptr(dx_lp), ptr(dgamma), ptr(dbeta), ptr(ws), stream_ptr())
+    return dx, dx_lp, dgamma, dbeta
+
+
+def attention_fwd(qkv, B, N, heads, dh):
+    """qkv [B*N, 3*h*dh] (compute dtype) -> (probs [B,h,N,ldp], out [B*N, h*dh])."""
+    ldp = (N + 7) // 8 * 8
+    dev = qkv.device
+    scores = torch.empty(B * heads * N * ldp, dtype=torch.float32, device=dev)
+    probs = torch.empty(B, heads, N, ldp, dtype=qkv.dtype, device=dev)
+    out = torch.empty(B * N, heads * dh, dtype=qkv.dtype, device=dev)
+    call("evp_attention_fwd", ptr(_chk(qkv)), dt(qkv), B, N, heads, dh, float(dh) ** -0.5, ptr(scores), ptr(probs), ldp,
+         ptr(out), stream_ptr())
+    return probs, out
+
+
+def attention_bwd(qkv, probs, dout, B, N, heads, dh):
+    ldp = probs.shape[-1]
+    dev = qkv.device
+    dp = torch.empty(B * heads * N * ldp, dtype=torch.float32, device=dev)
+    ds = dp if qkv.dtype == torch.float32 else torch.empty(B * heads * N * ldp, dtype=qkv.dtype, device=dev)
+    dqkv = torch.empty_like(qkv)
+    call("evp_attention_bwd", ptr(qkv), ptr(probs), ptr(_chk(dout)), dt(qkv), B, N, heads, dh, float(dh) ** -0.5, ldp,
+         ptr(dp), ptr(ds), ptr(dqkv), stream_ptr())
+    return dqkv
+
+
+def mask_from_noise(noise, mask_ratio):
+    """vit.py:75-103 on an explicit noise tensor -> (ids_keep int64, mask f32, ids_restore int64)."""
+    B, L = noise.shape
+    keep = int(L * (1 - mask_ratio))
+    dev = noise.device
+    ids_keep = torch.empty(B, keep, dtype=torch.int64, device=dev)
+    mask = torch.empty(B, L, dtype=torch.float32, device=dev)
+    ids_restore = torch.empty(B, L, dtype=torch.int64, device=dev)
+    call("evp_mask_from_noise", ptr(_chk(noise, torch.float32)), B, L, keep, ptr(ids_keep), ptr(mask), ptr(ids_restore),
+         stream_ptr())
+    return ids_keep, mask, ids_restore
+
+
+def density_noise(x, patch, sign):
+    B, Cc, H, W = x.shape
+    out = torch.empty(B, (H // patch) * (W // patch), dtype=torch.float32, device=x.device)
+    call("evp_density_noise", ptr(_chk(x, torch.float32)), B, Cc, H, W, patch, float(sign), ptr(out), stream_ptr())
+    return out
+
+
+def add(a, b, c=None):
+    out = torch.empty_like(a)
+    call("evp_add_f32", ptr(_chk(a, torch.float32)), ptr(_chk(b, torch.float32)), ptr(c), a.numel(), ptr(out), stream_ptr())
+    return out
+
+
+def _wgrad(dy, x, n_out, k_in, rows):
+    """dW[n_out,k_in] = dy^T x, f32."""
+    dw = torch.empty(n_out, k_in, dtype=torch.float32, device=dy.device)
+    return gemm(dy, x, dw, M=n_out, N=k_in, K=rows, trans_a=True, trans_b=True, lda=n_out, ldb=k_in)
+
+
+# ----------------------------------------------------------------------------------------------------- autograd
+class ViTBlockFn(torch.autograd.Function):
+    """Pre-LN transformer block (model/sub_module/vit_block.py:246-254) on a [B,N,D] f32 residual stream."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, heads, eps, want_attn):
+        B, N, D = x.shape
+        M = B * N
+        dh = D // heads
+        T = _compute_dtype
+        x2d = _chk(x.detach()).view(M, D)
+        dev = x.device
+        wq, wp, w1, w2 = lp_weight(qkvw), lp_weight(pw), lp_weight(f1w), lp_weight(f2w)
+        ln1, mean1, rstd1 = layernorm_fwd(x2d, n1w, n1b, eps, T)
+        qkv = torch.empty(M, 3 * D, dtype=T, device=dev)
+        gemm(ln1, wq, qkv, M=M, N=3 * D, K=D, bias=qkvb)
+        probs, att = attention_fwd(qkv, B, N, heads, dh)
+        x1 = torch.empty(M, D, dtype=torch.float32, device=dev)
+        gemm(att, wp, x1, M=M, N=D, K=D, bias=pb, residual=x2d)
+        ln2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, eps, T)
+        Hd = f1w.shape[0]
+        h_pre = torch.empty(M, Hd, dtype=T, device=dev)
+        h_act = torch.empty(M, Hd, dtype=T, device=dev)
+        gemm(ln2, w1, h_act, M=M, N=Hd, K=D, bias=f1b, act=ACT_GELU, aux=h_pre)
+        x2 = torch.empty(M, D, dtype=torch.float32, device=dev)
+        gemm(h_act, w2, x2, M=M, N=D, K=Hd, bias=f2b, residual=x1)
+        ctx.save_for_backward(x2d, n1w, n2w, mean1, rstd1, ln1, qkv, probs, att, x1, mean2, rstd2, ln2, h_pre, h_act,
+                              wq, wp, w1, w2)
+        ctx.dims = (B, N, D, heads, dh, Hd)
+        out = x2.view(B, N, D)
+        if want_attn:
+            attn = probs[..., :N]
+            ctx.mark_non_differentiable(attn)
+            return out, attn
+        return out
+
+    @staticmethod
+    def backward(ctx, g2, *_):
+        (x2d, n1w, n2w, mean1, rstd1, ln1, qkv, probs, att, x1, mean2, rstd2, ln2, h_pre, h_act, wq, wp, w1, w2) = \
+            ctx.saved_tensors
+        B, N, D, heads, dh, Hd = ctx.dims
+        M = B * N
+        T = qkv.dtype
+        dev = g2.device
+        bf = T == torch.bfloat16
+        g2 = _chk(g2.contiguous(), torch.float32).view(M, D)
+        g2_lp = cast(g2, T)
+        # MLP
+        db2 = colsum(g2)
+        dw2 = _wgrad(g2_lp, h_act, D, Hd, M)
+        dh_pre = torch.empty(M, Hd, dtype=T, device=dev)
+        gemm(g2_lp, w2, dh_pre, M=M, N=Hd, K=D, trans_b=True, ldb=Hd, act=ACT_DGELU, aux=h_pre)
+        db1 = colsum(dh_pre)
+        dw1 = _wgrad(dh_pre, ln2, Hd, D, M)
+        dln2 = torch.empty(M, D, dtype=T, device=dev)
+        gemm(dh_pre, w1, dln2, M=M, N=D, K=Hd, trans_b=True, ldb=D)
+        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf)
+        if not bf:
+            g1_lp = g1
+        # attention
+        dbp = colsum(g1)
+        dwp = _wgrad(g1_lp, att, D, D, M)
+        datt = torch.empty(M, D, dtype=T, device=dev)
+        gemm(g1_lp, wp, datt, M=M, N=D, K=D, trans_b=True, ldb=D)
+        dqkv = attention_bwd(qkv, probs, datt, B, N, heads, dh)
+        dbq = colsum(dqkv)
+        dwq = _wgrad(dqkv, ln1, 3 * D, D, M)
+        dln1 = torch.empty(M, D, dtype=T, device=dev)
+        gemm(dqkv, wq, dln1, M=M, N=D, K=3 * D, trans_b=True, ldb=D)
+        g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1)
+        return (g0.view(B, N, D), dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None)
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """Conv2d(k=s=p) + LayerNorm(eps 1e-5) + GELU (vit_block.py:60-68), + pos_embed, keeping only ids_keep tokens
+    (vit.py:110-115; gathering first is equivalent because every step is per token)."""
+
+    @staticmethod
+    def forward(ctx, x, ids_keep, w, b, gamma, beta, pos, patch):
+        B, Cc, H, W = x.shape
+        L = (H // patch) * (W // patch)
+        n_keep = L if ids_keep is None else ids_keep.shape[1]
+        D = w.shape[0]
+        Kc = Cc * patch * patch
+        M = B * n_keep
+        T = _compute_dtype
+        dev = x.device
+        cols = torch.empty(M, Kc, dtype=T, device=dev)
+        call("evp_patchify", ptr(_chk(x.detach(), torch.float32)), ptr(ids_keep), B, Cc, H, W, patch, n_keep, ptr(cols),
+             dt(cols), stream_ptr())
+        wl = lp_weight(w).view(D, Kc)
+        y = torch.empty(M, D, dtype=torch.float32, device=dev)
+        gemm(cols, wl, y, M=M, N=D, K=Kc, bias=b)
+        out = torch.empty(M, D, dtype=torch.float32, device=dev)
+        mean = torch.empty(M, dtype=torch.float32, device=dev)
+        rstd = torch.empty(M, dtype=torch.float32, device=dev)
+        pos2d = _chk(pos.detach().view(L, D), torch.float32)
+        call("evp_embed_post_fwd", ptr(y), ptr(gamma), ptr(beta), ptr(pos2d), ptr(ids_keep), B, n_keep, L, D, 1e-5,
+             ptr(out), ptr(mean), ptr(rstd), stream_ptr())
+        ctx.save_for_backward(cols, y, gamma, beta, mean, rstd)
+        ctx.wshape = tuple(w.shape)
+        return out.view(B, n_keep, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        cols, y, gamma, beta, mean, rstd = ctx.saved_tensors
+        M, D = y.shape
+        Kc = cols.shape[1]
+        dev = g.device
+        g = _chk(g.contiguous(), torch.float32).view(M, D)
+        dy = torch.empty(M, D, dtype=cols.dtype, device=dev)
+        dgamma = torch.empty(D, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(D, dtype=torch.float32, device=dev)
+        nb = call("evp_layernorm_bwd_nblk", M)
+        ws = torch.empty(2 * nb * D, dtype=torch.float32, device=dev)
+        call("evp_embed_post_bwd", ptr(g), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), M, D, ptr(dy), dt(dy),
+             ptr(dgamma), ptr(dbeta), ptr(ws), stream_ptr())
+        dw = _wgrad(dy, cols, D, Kc, M).view(ctx.wshape)
+        db = colsum(dy)
+        return None, None, dw, db, dgamma, dbeta, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dim of f32 tokens; up to three inputs are summed first (vit.py:125-128)."""
+
+    @staticmethod
+    def forward(ctx, x, x2, x3, gamma, beta, eps):
+        shp = x.shape
+        D = shp[-1]
+        xs = [None if t is None else _chk(t.detach().contiguous(), torch.float32).view(-1, D) for t in (x, x2, x3)]
+        y, mean, rstd = layernorm_fwd(xs[0], gamma, beta, eps, torch.float32, xs[1], xs[2])
+        ctx.save_for_backward(gamma, mean, rstd, *[t for t in xs if t is not None])
+        ctx.n_in = sum(t is not None for t in xs)
+        ctx.has = (x2 is not None, x3 is not None)
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, g):
+        gamma, mean, rstd, *xs = ctx.saved_tensors
+        D = gamma.shape[0]
+        x = xs[0]
+        rest = xs[1:]
+        x2 = rest.pop(0) if ctx.has[0] else None
+        x3 = rest.pop(0) if ctx.has[1] else None
+        g2d = _chk(g.contiguous(), torch.float32).view(-1, D)
+        dx, _, dgamma, dbeta = layernorm_bwd(g2d, x, gamma, mean, rstd, x2=x2, x3=x3)
+        dx = dx.view(g.shape)
+        return dx, (dx if ctx.has[0] else None), (dx if ctx.has[1] else None), dgamma, dbeta, None
+
+
+class LinearFn(torch.autograd.Function):
+    """nn.Linear on f32 tokens (f32 in / f32 out; operands rounded to the compute dtype for the MFMA)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        shp = x.shape
+        K = shp[-1]
+        N = w.shape[0]
+        x2d = _chk(x.detach().contiguous(), torch.float32).view(-1, K)
+        M = x2d.shape[0]
+        xl = cast(x2d, _compute_dtype)
+        wl = lp_weight(w)
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        gemm(xl, wl, y, M=M, N=N, K=K, bias=b)
+        ctx.save_for_backward(xl, wl)
+        ctx.has_bias = b is not None
+        ctx.needs_dx = x.requires_grad
+        return y.view(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        xl, wl = ctx.saved_tensors
+        M, K = xl.shape
+        N = wl.shape[0]
+        g2d = _chk(g.contiguous(), torch.float32).view(M, N)
+        gl = cast(g2d, xl.dtype)
+        dw = _wgrad(gl, xl, N, K, M)
+        db = colsum(g2d) if ctx.has_bias else None
+        dx = None
+        if ctx.needs_dx:
+            dx = torch.empty(M, K, dtype=torch.float32, device=g.device)
+            gemm(gl, wl, dx, M=M, N=K, K=N, trans_b=True, ldb=K)
+            dx = dx.view(*g.shape[:-1], K)
+        return dx, dw, db
+
+
+class UnshuffleFn(torch.autograd.Function):
+    """Decoder input assembly (pr_rec_decoder.py:56-62): mask tokens, un-shuffle by ids_restore, + pos_embed."""
+
+    @staticmethod
+    def forward(ctx, emb, mask_token, pos, ids_restore):
+        B, n_keep, D = emb.shape
+        L = ids_restore.shape[1]
+        out = torch.empty(B, L, D, dtype=torch.float32, device=emb.device)
+        call("evp_unshuffle_fwd", ptr(_chk(emb.detach().contiguous(), torch.float32)), ptr(_chk(mask_token.detach())),
+             ptr(_chk(pos.detach())), ptr(_chk(ids_restore)), B, n_keep, L, D, ptr(out), stream_ptr())
+        ctx.save_for_backward(ids_restore)
+        ctx.dims = (B, n_keep, L, D)
+        ctx.mt_shape = tuple(mask_token.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids_restore,) = ctx.saved_tensors
+        B, n_keep, L, D = ctx.dims
+        g = _chk(g.contiguous(), torch.float32)
+        demb = torch.empty(B, n_keep, D, dtype=torch.float32, device=g.device)
+        dmt = torch.empty(D, dtype=torch.float32, device=g.device)
+        nb = (B * L + 63) // 64
+        ws = torch.empty(nb * D, dtype=torch.float32, device=g.device)
+        call("evp_unshuffle_bwd", ptr(g), ptr(ids_restore), B, n_keep, L, D, ptr(demb), ptr(dmt), ptr(ws), stream_ptr())
+        return demb, dmt.view(ctx.mt_shape), None, None
+
+
+class RecLossFn(torch.autograd.Function):
+    """PrHubModel.reconstruct_loss (pr_hub_model.py:125-141) fused with frame2emb; returns a 0-dim f32 tensor."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mask, patch, norm_pix):
+        B, L, P = pred.shape
+        _, Cc, H, W = target.shape
+        dev = pred.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dpred = torch.empty(B, L, P, dtype=torch.float32, device=dev)
+        ws = torch.empty(2 * B * L + 4, dtype=torch.float32, device=dev)
+        call("evp_rec_loss", ptr(_chk(pred.detach().contiguous(), torch.float32)),
+             ptr(_chk(target.detach().contiguous(), torch.float32)), ptr(mask), B, Cc, H, W, patch, int(bool(norm_pix)),
+             ptr(loss), ptr(dpred), ptr(ws), stream_ptr())
+        ctx.save_for_backward(dpred)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        # upstream gradient is a device scalar (1, or 1/accum_iter): scale in place without a host sync
+        call("evp_scale_f32", ptr(dpred), ptr(_chk(g.contiguous().view(1), torch.float32)), dpred.numel(), stream_ptr())
+        return dpred, None, None, None, None
+
+
+def vit_block(x, blk, heads, eps, want_attn=False):
+    return ViTBlockFn.apply(x, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias,
+                            blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias,
+                            blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias,
+                            heads, eps, want_attn)

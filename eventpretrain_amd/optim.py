@@ -1,0 +1,144 @@
+"""FusedAdamW: torch.optim.AdamW semantics (the optimizer main_pretrain.py:341-343 builds) executed by ONE HIP launch
+over every parameter (csrc/optim.hip), which also refreshes the bf16 weight shadows the MFMA GEMMs read.
+
+Subclasses torch.optim.Optimizer only for the param_groups / state_dict plumbing; the arithmetic is evp_adamw_multi.
+Per-group `lr` (already multiplied by `lr_scale` by utils.lr_sched.adjust_learning_rate) and `weight_decay` are read
+every step. Gradient pointers are re-read every step (autograd may hand out new buffers); under HIP-graph capture use
+`refresh()` outside the graph and `launch()` inside it.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, stream_ptr
+
+CHUNK = 16384
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        b = {tuple(g["betas"]) for g in self.param_groups}
+        e = {g["eps"] for g in self.param_groups}
+        if len(b) != 1 or len(e) != 1:
+            raise ValueError("FusedAdamW needs one (betas, eps) for all groups")
+        self.grad_scale = float(grad_scale)
+        self._step = 0
+        self._tabs = None
+        self._sig = None
+
+    # ------------------------------------------------------------------------------------------------ tables
+    def _active(self):
+        out = []
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                if p.grad is not None:
+                    out.append((gi, p))
+        return out
+
+    def _build(self, act):
+        dev = act[0][1].device
+        n = len(act)
+        for _, p in act:
+            if p.dtype != torch.float32 or not p.is_contiguous() or not p.is_cuda:
+                raise _lib.EvpError("FusedAdamW: parameters must be contiguous float32 tensors in device memory")
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["step"] = torch.zeros((), dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        numel = np.array([p.numel() for _, p in act], dtype=np.int64)
+        chunk_t, chunk_o = [], []
+        for t, ne in enumerate(numel):
+            offs = np.arange(0, ne, CHUNK, dtype=np.int64)
+            chunk_t.append(np.full(offs.shape, t, dtype=np.int32))
+            chunk_o.append(offs)
+        T = dict(
+            n=n, dev=dev,
+            params=torch.tensor([p.data_ptr() for _, p in act], dtype=torch.int64, device=dev),
+            m=torch.tensor([self.state[p]["exp_avg"].data_ptr() for _, p in act], dtype=torch.int64, device=dev),
+            v=torch.tensor([self.state[p]["exp_avg_sq"].data_ptr() for _, p in act], dtype=torch.int64, device=dev),
+            numel=torch.from_numpy(numel).to(dev),
+            chunk_t=torch.from_numpy(np.concatenate(chunk_t)).to(dev),
+            chunk_o=torch.from_numpy(np.concatenate(chunk_o)).to(dev),
+            grads=torch.zeros(n, dtype=torch.int64, device=dev),
+            lp=torch.zeros(n, dtype=torch.int64, device=dev),
+            wd=torch.zeros(n, dtype=torch.float32, device=dev),
+            lr=torch.zeros(n, dtype=torch.float32, device=dev),
+            hyper=torch.zeros(4, dtype=torch.float32, device=dev),
+            norm_ws=torch.empty(sum(len(c) for c in chunk_t), dtype=torch.float32, device=dev),
+            norm_out=torch.empty(1, dtype=torch.float32, device=dev),
+        )
+        T["n_chunks"] = int(T["chunk_t"].numel())
+        # pinned staging for the per-step refresh
+        T["h_grads"] = torch.zeros(n, dtype=torch.int64).pin_memory()
+        T["h_lp"] = torch.zeros(n, dtype=torch.int64).pin_memory()
+        T["h_wd"] = torch.zeros(n, dtype=torch.float32).pin_memory()
+        T["h_lr"] = torch.zeros(n, dtype=torch.float32).pin_memory()
+        T["h_hyper"] = torch.zeros(4, dtype=torch.float32).pin_memory()
+        return T
+
+    def refresh(self, advance=True):
+        """Host side of a step: (re)build tables if the set of parameters with gradients changed, bump the step
+        counter, stage gradient pointers / lr / weight decay / bias corrections into device tables (async H2D)."""
+        act = self._active()
+        if not act:
+            return False
+        sig = tuple(id(p) for _, p in act)
+        if sig != self._sig:
+            self._tabs, self._sig = self._build(act), sig
+        T = self._tabs
+        if advance:
+            self._step += 1
+        b1, b2 = self.param_groups[0]["betas"]
+        for i, (gi, p) in enumerate(act):
+            g = self.param_groups[gi]
+            if p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+                raise _lib.EvpError("FusedAdamW: gradients must be contiguous float32")
+            T["h_grads"][i] = p.grad.data_ptr()
+            sh = getattr(p, "_evp_lp", None)
+            T["h_lp"][i] = sh.data_ptr() if (sh is not None and getattr(p, "_evp_lp_version", -1) == p._version) else 0
+            T["h_wd"][i] = g["weight_decay"]
+            T["h_lr"][i] = g["lr"]
+            self.state[p]["step"] += 1 if advance else 0
+        step = max(self._step, 1)
+        T["h_hyper"][0] = 1.0 - b1 ** step
+        T["h_hyper"][1] = math.sqrt(1.0 - b2 ** step)
+        T["h_hyper"][2] = self.grad_scale
+        T["h_hyper"][3] = 1.0
+        for k in ("grads", "lp", "wd", "lr", "hyper"):
+            T[k].copy_(T["h_" + k], non_blocking=True)
+        return True
+
+    def launch(self):
+        """Device side of a step (graph-capturable): one evp_adamw_multi over all chunks."""
+        T = self._tabs
+        b1, b2 = self.param_groups[0]["betas"]
+        call("evp_adamw_multi", T["params"].data_ptr(), T["grads"].data_ptr(), T["m"].data_ptr(), T["v"].data_ptr(),
+             T["lp"].data_ptr(), T["numel"].data_ptr(), T["wd"].data_ptr(), T["lr"].data_ptr(), T["chunk_t"].data_ptr(),
+             T["chunk_o"].data_ptr(), T["n_chunks"], CHUNK, 1.0, float(b1), float(b2), float(self.param_groups[0]["eps"]),
+             max(self._step, 1), self.grad_scale, T["hyper"].data_ptr(), stream_ptr())
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self.refresh():
+            self.launch()
+        return loss
+
+    @torch.no_grad()
+    def grad_norm(self):
+        """Global 2-norm of all gradients (= norm of per-parameter norms, utils/misc.py:303-315) as a device scalar.
+        Uses the tables of the last refresh()."""
+        if not self.refresh(advance=False):     # gradient buffers can move between steps: always re-read pointers
+            raise _lib.EvpError("grad_norm: no parameter has a gradient")
+        T = self._tabs
+        call("evp_grad_norm_multi", T["grads"].data_ptr(), T["numel"].data_ptr(), T["chunk_t"].data_ptr(),
+             T["chunk_o"].data_ptr(), T["n_chunks"], CHUNK, T["norm_ws"].data_ptr(), T["norm_out"].data_ptr(), stream_ptr())
+        return T["norm_out"]

@@ -1,0 +1,63 @@
+"""One-epoch loops of the pre-training stages with the reference's signatures and return dicts
+(reference trainer/pretrain/pr_trainer.py:9-89,91-155): per-iteration LR schedule, loss / accum_iter, optimizer step
+cadence, metric all-reduce. The matplotlib visualisation the reference calls from inside the loop is an optional
+`vis_hook` (default off)."""
+import torch
+
+from ...utils import misc
+from ...utils.lr_sched import adjust_learning_rate
+
+
+def _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, loss_name, forward, vis_hook):
+    model.train(True)
+    logger = misc.MetricLogger(delimiter="  ")
+    logger.add_meter("lr", misc.SmoothedValue(window_size=1, fmt="{value:.6f}"))
+    header = "Epoch: [{}]".format(epoch + 1)
+    optimizer.zero_grad()
+    if log_writer is not None:
+        print("log_dir: {}".format(log_writer.log_dir))
+    n_iter = len(data_loader)
+    last = None
+    for it, batch in enumerate(logger.log_every(args, data_loader, args.print_freq, header)):
+        if it % args.accum_iter == 0:
+            adjust_learning_rate(optimizer, it / n_iter + epoch, args)
+        events_voxel_grid = batch[0].to(args.device, non_blocking=True)
+        supp = batch[1].to(args.device, non_blocking=True)
+        outputs = forward(events_voxel_grid, supp)
+        loss = outputs[0]
+        last = (events_voxel_grid, supp, outputs, batch[-1])
+        if vis_hook is not None and args.test_experiment and args.visualize:
+            vis_hook(args, *last, epoch)
+        logger.update(**{loss_name: loss.item()})
+        loss = loss / args.accum_iter
+        step_now = (it + 1) % args.accum_iter == 0
+        if args.backward:
+            loss_scaler(loss, optimizer, parameters=model.parameters(), update_grad=step_now)
+            if step_now:
+                optimizer.zero_grad()
+        if str(args.device).startswith("cuda"):
+            torch.cuda.synchronize()
+        lr = optimizer.param_groups[0]["lr"]
+        logger.update(lr=lr)
+        reduced = misc.all_reduce_mean(loss.item())
+        if log_writer is not None and (it + 1) % args.log_freq == 0 and step_now:
+            x = int((it / n_iter + epoch) * 1000)        # "epoch_1000x" axis
+            log_writer.add_scalar(loss_name, reduced, x)
+            log_writer.add_scalar("lr", lr, x)
+    if vis_hook is not None and args.visualize and (epoch + 1) % args.vis_train_freq == 0 and last is not None:
+        vis_hook(args, *last, epoch)
+    logger.synchronize_between_processes()
+    print("Averaged stats:", logger)
+    return {k: m.global_avg for k, m in logger.meters.items()}
+
+
+def pr_rec_one_epoch(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer=None, vis_hook=None):
+    """Masked-modeling epoch: model(events_voxel_grid, sub_frame, is_rec=True)."""
+    return _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, "reconstruct_loss",
+                 lambda x, y: model(x, y, is_rec=True), vis_hook)
+
+
+def pr_con_one_epoch(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer=None, vis_hook=None):
+    """Contrastive / transfer epoch: model(events_voxel_grid, clip_emb)."""
+    return _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, "contrastive_loss",
+                 lambda x, y: model(x, y), vis_hook)

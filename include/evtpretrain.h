@@ -1,0 +1,215 @@
+/* evtpretrain.h -- C-ABI of libevtpretrain.so: the MI355X (gfx950) kernels behind the event pre-training hot
+ * path of BIT-Vision/EventPretrain (main_pretrain.py -> trainer/pretrain -> model/pretrain).
+ *
+ * The reference is 100 % Python on stock ATen ops; it has NO plugin/operator/FFI interface for this path
+ * (SURVEY.md 8b). Each entry point below therefore cites the reference *Python* lines whose ATen composition it
+ * replaces (paths relative to the reference root). The Python layer in eventpretrain_amd/ binds these with ctypes
+ * (eventpretrain_amd/_lib.py) and wraps them in torch.autograd.Function objects (eventpretrain_amd/ops.py).
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer owned by the caller (PyTorch allocates; the library never allocates,
+ *    frees or keeps a pointer after the call returns).
+ *  - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (no host sync), so calls are
+ *    capturable in a HIP graph.
+ *  - Return value: EVP_OK (0) or a negative evp_status; evp_last_error() gives a thread-local message. Nothing
+ *    throws across the ABI.
+ *  - dtype codes: EVP_F32 = 0 (float), EVP_BF16 = 1 (bfloat16, raw uint16 storage).
+ *  - Row-major everywhere; "ld*" are leading dimensions in ELEMENTS.
+ */
+#ifndef EVTPRETRAIN_H
+#define EVTPRETRAIN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { EVP_OK = 0, EVP_EINVAL = -1, EVP_ESHAPE = -2, EVP_ELAUNCH = -3, EVP_EUNSUPPORTED = -4 } evp_status;
+enum { EVP_F32 = 0, EVP_BF16 = 1 };
+enum { EVP_ACT_NONE = 0, EVP_ACT_GELU = 1, EVP_ACT_DGELU = 2, EVP_ACT_RELU = 3, EVP_ACT_DRELU = 4 };
+
+const char *evp_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int evp_abi_version(void);
+/* Name of the code object's target ("gfx950"). */
+const char *evp_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------------ K1 voxel
+ * Replaces dataset/dataset_utils/events_to_voxel_grid.py:4-61 (two index_add_ scatters, :46-57) for a BATCH of
+ * clips. events: float64 [n_total,4], columns (x,y,t,p) or (t,x,y,p) if is_txyp; clip c owns rows
+ * [clip_offsets[c], clip_offsets[c+1]). out: float32 [n_clips,bins,H,W], fully overwritten.
+ * assume_sorted != 0: rows of each clip are non-decreasing in t (what every reference dataset produces; the
+ * reference itself relies on it for t0/t1, :19-22) -> each block scans only its time slab. assume_sorted == 0:
+ * correct for any row order (every block scans the whole clip).
+ * workspace: int64 [n_clips*(bins+2)] scratch. algo: 0 = LDS-binned (default), 1 = global float atomics.
+ * tile_rows: rows of one bin plane held in LDS per block (0 = auto). */
+int evp_voxel_scatter_f32(const double *events, const int64_t *clip_offsets, int n_clips, int bins, int H, int W,
+                          int is_txyp, int assume_sorted, int algo, int tile_rows, int64_t *workspace, float *out,
+                          void *stream);
+/* sorted_flags[c] = 1 if clip c's stamps are non-decreasing, else 0 (device int32 [n_clips]). */
+int evp_events_sorted_check(const double *events, const int64_t *clip_offsets, int n_clips, int is_txyp,
+                            int32_t *sorted_flags, void *stream);
+
+/* ------------------------------------------------------------------------------------------------ K2 masking
+ * Replaces ViT.random_masking, model/backbone/vit.py:91-103 (argsort, argsort, slice, gather) with the noise as an
+ * explicit input. Stable ascending order (ties: lower index first; NaN last). noise float32 [B,L] ->
+ * ids_keep int64 [B,len_keep], mask float32 [B,L] (1 = removed), ids_restore int64 [B,L]. L <= 4096. */
+int evp_mask_from_noise(const float *noise, int B, int L, int len_keep, int64_t *ids_keep, float *mask,
+                        int64_t *ids_restore, void *stream);
+/* vit.py:80-89 density / anti-density noise: |sum_c x| average-pooled over patch x patch; sign = +1 / -1.
+ * x float32 [B,C,H,W] -> noise float32 [B,(H/p)*(W/p)]. */
+int evp_density_noise(const float *x, int B, int C, int H, int W, int patch, float sign, float *noise, void *stream);
+
+/* ------------------------------------------------------------------------------------------------ GEMM family
+ * One batched, strided GEMM:  C[b0,b1] = epilogue(alpha * A[b0,b1] (M x K) . B[b0,b1]^T (N x K))
+ *   transA = 0: A stored [M][K] (K contiguous);  transA = 1: A stored [K][M].
+ *   transB = 0: B stored [N][K] (nn.Linear weight layout);  transB = 1: B stored [K][N].
+ * Replaces every nn.Linear / matmul / einsum on the path: model/sub_module/vit_block.py:133,136,140,141,226,230,
+ * model/pretrain/pr_rec_decoder.py:54,68, the Conv2d-as-GEMM of vit_block.py:65, mlp_head.py:10 and the logits of
+ * model/pretrain/pr_hub_model.py:153-155,179, plus their autograd backward (dgrad: transB=1, wgrad: transA=transB=1).
+ * dtype is the A/B element type (EVP_F32 -> exact f32 MFMA, EVP_BF16 -> bf16 MFMA, f32 accumulate).
+ * Epilogue, in order: v = alpha*acc; v += bias[n]; if aux (ACT_GELU/RELU) aux[m,n] = v; v = act(v) or
+ * v *= act'(aux[m,n]) (ACT_DGELU/DRELU); v += residual[m,n]; if accumulate C += v else C = v.
+ * Contiguous dimensions of A, B, C, aux and residual must be multiples of 8 elements (16-byte chunks for bf16)
+ * except M/N/K edges handled by predication as documented in DESIGN.md. */
+typedef struct {
+  int dtype, transA, transB;
+  int M, N, K;
+  const void *A; int64_t lda, strideA0, strideA1;
+  const void *B; int64_t ldb, strideB0, strideB1;
+  void *C; int c_dtype; int64_t ldc, strideC0, strideC1;
+  int batch0, batch1;
+  float alpha;
+  const float *bias;
+  int act;
+  void *aux; int64_t ldaux;            /* element type = c_dtype; batch strides = C's */
+  const float *residual; int64_t ldres; /* batch strides = C's */
+  int accumulate;
+  int tile;                             /* 0 auto, 1 = 128x128, 2 = 64x64 */
+} evp_gemm_desc;
+int evp_gemm(const evp_gemm_desc *d, void *stream);
+
+/* ------------------------------------------------------------------------------------------------ K4/K9 LayerNorm
+ * Replaces nn.LayerNorm over the last dim (vit_block.py:247,249; vit.py:126-128 with the 3-tap sum fused:
+ * y = LN(x + x2 + x3), x2/x3 may be NULL). x*: float32 [M,D]; y: y_dtype [M,D]; mean/rstd float32 [M]. */
+int evp_layernorm_fwd(const float *x, const float *x2, const float *x3, const float *gamma, const float *beta,
+                      int64_t M, int D, float eps, void *y, int y_dtype, float *mean, float *rstd, void *stream);
+/* dx = (gres ? gres : 0) + LN'(dy): dy dy_dtype [M,D]; x.. as forward; dx float32 [M,D]; dx_lp (optional, bf16) a
+ * low-precision copy of dx for the next GEMM; dgamma/dbeta float32 [D] are OVERWRITTEN (partials: workspace float32
+ * [2*nblk*D], nblk = evp_layernorm_bwd_nblk(M)). */
+int evp_layernorm_bwd_nblk(int64_t M);
+int evp_layernorm_bwd(const void *dy, int dy_dtype, const float *x, const float *x2, const float *x3,
+                      const float *gamma, const float *mean, const float *rstd, const float *gres, int64_t M, int D,
+                      float *dx, void *dx_lp, float *dgamma, float *dbeta, float *workspace, void *stream);
+
+/* column sums: out[n] (+)= sum_m x[m,n]  (bias gradients). x dtype [M,N] with ld. workspace float32 [nblk*N],
+ * nblk = evp_colsum_nblk(M). */
+int evp_colsum_nblk(int64_t M);
+int evp_colsum(const void *x, int x_dtype, int64_t M, int N, int64_t ld, float *out, float *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------------------ K6 attention core
+ * Replaces vit_block.py:134-140 on the packed qkv tensor ([B,N,3,h,dh], element type dtype) of the fused qkv Linear:
+ * scores = q k^T * scale (batched GEMM), row softmax, out = probs v. probs: dtype [B,h,N,ldp] (ldp = N rounded up
+ * to 8, pad columns zero) is both the saved tensor for backward and the tensor the dense branch returns
+ * (vit.py:144). out: dtype [B,N,h*dh]. */
+int evp_attention_fwd(const void *qkv, int dtype, int B, int N, int heads, int dh, float scale, float *scores_ws,
+                      void *probs, int64_t ldp, void *out, void *stream);
+/* dqkv (dtype, [B,N,3,h,dh]) from dout (dtype [B,N,h*dh]). Scratch: scores_ws / dp_ws float32 [B,h,N,ldp] (the
+ * logits are kept in f32 between the GEMM and the softmax in both precisions); ds_ws dtype [B,h,N,ldp]. */
+int evp_attention_bwd(const void *qkv, const void *probs, const void *dout, int dtype, int B, int N, int heads, int dh,
+                      float scale, int64_t ldp, float *dp_ws, void *ds_ws, void *dqkv, void *stream);
+/* p[r,:] = softmax(s[r,:n_valid]) with s float32 [rows,ld], p dtype [rows,ld]; pad columns [n_valid,ld) = 0. */
+int evp_softmax_rows(const float *s, void *p, int dtype, int64_t rows, int n_valid, int64_t ld, void *stream);
+/* ds = p * (dp - rowsum(p*dp)); dp float32, p/ds dtype; pad columns = 0. */
+int evp_softmax_rows_bwd(const void *p, const float *dp, void *ds, int dtype, int64_t rows, int n_valid, int64_t ld,
+                         void *stream);
+
+/* ------------------------------------------------------------------------------------------------ K3 patch embed
+ * vit_block.py:60-68 + vit.py:110-115. Non-overlapping patches make Conv2d(k=s=p) a GEMM on a patch matrix:
+ * evp_patchify gathers ONLY the kept tokens (ids_keep int64 [B,n_keep], NULL = all L tokens in order) of
+ * x float32 [B,C,H,W] into cols: dtype [B*n_keep, C*p*p], inner order (c,py,px) = Conv2d weight.view(D,-1). */
+int evp_patchify(const float *x, const int64_t *ids_keep, int B, int C, int H, int W, int patch, int n_keep,
+                 void *cols, int dtype, void *stream);
+/* tokens = GELU(LN_{eps}(y)) + pos[token id]: y float32 [M,D] (conv output incl. bias), pos float32 [L,D],
+ * ids_keep as above (NULL = identity, M = B*L). Saves mean/rstd. out float32 [M,D]. */
+int evp_embed_post_fwd(const float *y, const float *gamma, const float *beta, const float *pos, const int64_t *ids_keep,
+                       int B, int n_keep, int L, int D, float eps, float *out, float *mean, float *rstd, void *stream);
+/* dy (dtype [M,D]) = LN'(GELU'(LN(y)) * g); dgamma/dbeta overwritten (workspace as evp_layernorm_bwd). */
+int evp_embed_post_bwd(const float *g, const float *y, const float *gamma, const float *beta, const float *mean,
+                       const float *rstd, int64_t M, int D, void *dy, int dy_dtype, float *dgamma, float *dbeta,
+                       float *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------------------ K10 decoder unshuffle
+ * pr_rec_decoder.py:56-62: out[b,l,:] = (ids_restore[b,l] < n_keep ? emb[b,ids_restore[b,l],:] : mask_token) + pos[l].
+ * emb float32 [B,n_keep,D] -> out float32 [B,L,D]. */
+int evp_unshuffle_fwd(const float *emb, const float *mask_token, const float *pos, const int64_t *ids_restore, int B,
+                      int n_keep, int L, int D, float *out, void *stream);
+/* demb[b,ids_restore[b,l],:] = g[b,l,:] for kept positions (ids_restore[b,l] < n_keep); dmask_token[d] = sum of g
+ * over removed positions (overwritten; workspace float32 [evp_colsum_nblk(B*L)*D]). */
+int evp_unshuffle_bwd(const float *g, const int64_t *ids_restore, int B, int n_keep, int L, int D, float *demb,
+                      float *dmask_token, float *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------------------ K12 reconstruction loss
+ * pr_hub_model.py:125-141 + utils/reshape.py:15-22: patchify target (B,C,H,W) -> (B,L,p*p*C) order (py,px,c);
+ * per-patch normalise with UNBIASED variance (+1e-6) when norm_pix; per-patch MSE; loss = sum(mask*l)/sum(mask)
+ * (mask NULL or mask_ratio==0 path: mean). pred: float32 [B,L,P]. loss: float32 [1]. dpred (optional, float32
+ * [B,L,P]) = d loss / d pred (scaled by upstream gradient 1). workspace float32 [2*B*L + 4]. */
+int evp_rec_loss(const float *pred, const float *target, const float *mask, int B, int C, int H, int W, int patch,
+                 int norm_pix, float *loss, float *dpred, float *workspace, void *stream);
+
+/* ------------------------------------------------------------------------------------------------ small helpers
+ * out = a + b (+ c) float32, n elements. */
+int evp_add_f32(const float *a, const float *b, const float *c, int64_t n, float *out, void *stream);
+int evp_cast(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, void *stream);
+/* x[i] *= scalar[0] with the scalar in device memory (upstream gradient of a scalar loss, no host sync). */
+int evp_scale_f32(float *x, const float *scalar, int64_t n, void *stream);
+/* dst[c][r] = src[r][c] for a [rows, cols] matrix of `dtype` (used for weight shadows). */
+int evp_transpose(const void *src, void *dst, int dtype, int64_t rows, int64_t cols, void *stream);
+
+/* ------------------------------------------------------------------------------------------------ K21 optimiser
+ * torch.optim.AdamW step as main_pretrain.py:341-343 configures it, over a list of tensors in ONE launch.
+ * Per-tensor tables (device memory, one entry per tensor): params/grads/exp_avg/exp_avg_sq float32*, lp_shadow
+ * (bf16*, table or entries may be NULL) receives the updated weights rounded to bf16, numel int64, weight_decay
+ * float32, lr_scale float32. Work is cut into chunks of chunk_elems (multiple of 4) elements: chunk i updates
+ * tensor chunk_tensor[i] from element chunk_offset[i] (host-built once per parameter set). step is the 1-based
+ * step count; grad_scale multiplies every gradient first (1/accum or 1/world). dev_hyper (optional, device float32
+ * [4] = {1-beta1^step, sqrt(1-beta2^step), grad_scale, lr multiplier}) overrides the host scalars so that a
+ * captured HIP graph can be replayed with per-step values refreshed by a tiny H2D copy. */
+int evp_adamw_multi(float *const *params, const float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                    uint16_t *const *lp_shadow, const int64_t *numel, const float *weight_decay, const float *lr_scale,
+                    const int32_t *chunk_tensor, const int64_t *chunk_offset, int n_chunks, int chunk_elems, float lr,
+                    float beta1, float beta2, float eps, int step, float grad_scale, const float *dev_hyper,
+                    void *stream);
+/* utils/misc.py:303-315: total 2-norm over a tensor list -> out float32 [1]. workspace float32 [n_chunks]. */
+int evp_grad_norm_multi(const float *const *grads, const int64_t *numel, const int32_t *chunk_tensor,
+                        const int64_t *chunk_offset, int n_chunks, int chunk_elems, float *workspace, float *out,
+                        void *stream);
+
+/* ------------------------------------------------------------------------------------------------ K13 BatchNorm on tokens
+ * mlp_head.py:13,18 applied as pr_hub_model.py:223-237 does: per-channel batch statistics over the B*L rows of
+ * x (dtype [R,C]). Training mode only (the pre-training loop never evaluates). gamma/beta may be NULL
+ * (affine=False). y dtype [R,C] (relu != 0 fuses the following ReLU); saves mean/invstd float32 [C]; updates
+ * running_mean/var (momentum 0.1, unbiased var) in place. workspace float32 [(2*evp_batchnorm_nblk(R)+2)*C]. */
+int evp_batchnorm_fwd(const void *x, int dtype, int64_t R, int C, const float *gamma, const float *beta, float eps,
+                      float momentum, int relu, void *y, float *mean, float *invstd, float *running_mean,
+                      float *running_var, float *workspace, void *stream);
+int evp_batchnorm_bwd(const void *dy, const void *x, const void *y, int dtype, int64_t R, int C, const float *gamma,
+                      const float *mean, const float *invstd, int relu, void *dx, float *dgamma, float *dbeta,
+                      float *workspace, void *stream);
+int evp_batchnorm_nblk(int64_t R);
+
+/* ------------------------------------------------------------------------------------------------ K15/K16 InfoNCE
+ * F.normalize(x, dim=-1) rows (pr_hub_model.py:145-146,172-173): y = x / max(||x||, 1e-12); saves norm. */
+int evp_l2norm_rows_fwd(const float *x, int64_t R, int C, float *y, float *norm, void *stream);
+int evp_l2norm_rows_bwd(const float *dy, const float *y, const float *norm, int64_t R, int C, float *dx, void *stream);
+/* Cross entropy over rows of logits float32 [R,ld] (n_cls valid columns), integer label per row (int64 [R]):
+ * loss[0] = mean_r(-log softmax(logits[r])[label[r]]) and, if dlogits != NULL, dlogits = (softmax - onehot)/R.
+ * workspace float32 [R]. */
+int evp_cross_entropy(const float *logits, const int64_t *labels, int64_t R, int n_cls, int64_t ld, float *loss,
+                      float *dlogits, float *workspace, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVTPRETRAIN_H */

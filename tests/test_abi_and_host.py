@@ -1,0 +1,115 @@
+"""CPU-side checks: the C-ABI library builds for gfx950, loads, and exports every symbol include/evtpretrain.h
+declares (no compute calls without a GPU); host-side logic (schedules, param groups, pos-embed, reshape helpers,
+checkpoint key remap) against the reference-made fixtures."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from helpers import jl
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "evtpretrain.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(evp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from eventpretrain_amd import _lib
+    _lib.build_library()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/evtpretrain.h but not exported"
+    assert set(_lib.exported_symbols()) == set(names), set(_lib.exported_symbols()) ^ set(names)
+    lib.evp_target_arch.restype = ctypes.c_char_p
+    assert lib.evp_target_arch() == b"gfx950"
+    assert lib.evp_abi_version() == 1
+
+
+def test_code_object_is_gfx950():
+    from eventpretrain_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"gfx90a" not in blob and b"sm_" not in blob
+
+
+def test_argument_validation_without_gpu():
+    """Shape/pointer validation happens on the host before any launch, so it can be exercised here."""
+    from eventpretrain_amd import _lib
+    lib = _lib.load()
+    d = _lib.GemmDesc()
+    assert lib.evp_gemm(ctypes.byref(d), None) == -1          # EVP_EINVAL: null operands
+    assert b"null" in lib.evp_last_error()
+    assert lib.evp_mask_from_noise(1, 2, 5000, 10, 1, 1, 1, None) == -2   # EVP_ESHAPE: L > 4096
+
+
+def test_ops_refuse_cpu_tensors():
+    from eventpretrain_amd import ops
+    from eventpretrain_amd._lib import EvpError
+    with pytest.raises(EvpError):
+        ops.mask_from_noise(torch.rand(2, 16), 0.5)
+    with pytest.raises(EvpError):
+        ops.cast(torch.zeros(4), torch.bfloat16)
+
+
+def test_pos_embed_matches_reference():
+    from eventpretrain_amd.utils.pos_embed import get_2d_sincos_pos_embed
+    from helpers import checksums
+    d = load_golden("pos_embed")
+    for dim, g in [(64, 4), (192, 4), (384, 14), (512, 14), (768, 14), (256, 7)]:
+        t = get_2d_sincos_pos_embed(dim, g)
+        assert str(t.dtype) == str(d[f"d{dim}_g{g}_dtype"])
+        assert np.array_equal(checksums(torch.from_numpy(t).float()), d[f"d{dim}_g{g}_checksums"])
+    assert get_2d_sincos_pos_embed(64, 4, cls_token=True).shape == (17, 64)
+
+
+def test_lr_schedule_and_param_groups():
+    import types
+    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
+    from eventpretrain_amd.testing import make_args
+    from eventpretrain_amd.utils import lr_decay as lrd
+    from eventpretrain_amd.utils.lr_sched import adjust_learning_rate
+    d = load_golden("train_tiny")
+    opt = types.SimpleNamespace(param_groups=[{"lr": 0.0}, {"lr": 0.0, "lr_scale": 0.5}])
+    a = make_args(lr=2e-3, min_lr=1e-5, warmup_epochs=5, epochs=40)
+    for e, lr, g0, g1 in d["sched"]:
+        assert adjust_learning_rate(opt, e, a) == pytest.approx(lr, rel=1e-12, abs=1e-18)
+        assert opt.param_groups[0]["lr"] == pytest.approx(g0, rel=1e-12, abs=1e-18)
+        assert opt.param_groups[1]["lr"] == pytest.approx(g1, rel=1e-12, abs=1e-18)
+    a = make_args(model_size="tiny")
+    m = hub.pretrain_hub_model_tiny_patch16_64(a, emb_frames_dim=512, queue_length=8, T=0.07)
+    groups = lrd.param_groups_lrd(a, m, 0.05, layer_decay=1)
+    cnt = {"decay": sum(len(g["params"]) for g in groups if g["weight_decay"] > 0),
+           "no_decay": sum(len(g["params"]) for g in groups if g["weight_decay"] == 0)}
+    assert cnt == jl(d["group_decay"]) and len(groups) == int(d["n_groups"])
+    assert all(g["lr_scale"] == 1 for g in groups)
+    g75 = lrd.param_groups_lrd(a, m, 0.05, layer_decay=0.75)
+    scales = sorted({g["lr_scale"] for g in g75})
+    assert scales[0] == pytest.approx(0.75 ** 12) and scales[-1] == 1.0
+
+
+def test_reshape_helpers_round_trip():
+    from eventpretrain_amd.utils import reshape as rs
+    from oracle.model_oracle import patchify
+    x = torch.randn(2, 3, 32, 48)
+    assert torch.equal(rs.frame2emb(16, x), patchify(x, 16))
+    sq = torch.randn(2, 1, 64, 64)
+    import types
+    assert torch.equal(rs.emb2frame(types.SimpleNamespace(patch_size=16), rs.frame2emb(16, sq), 1), sq)
+    e = torch.randn(2, 16, 7)
+    assert torch.equal(rs.patch_frame2emb(rs.emb2patch_frame(e)), e)
+
+
+def test_checkpoint_key_remap():
+    from eventpretrain_amd.utils.misc import remap_stage_checkpoint
+    sd = {"backbone.norm_l_h.weight": 1, "backbone.norm_l_h.bias": 2, "backbone.vit_block.0.norm1.weight": 3}
+    out = remap_stage_checkpoint(sd, "adj")
+    assert set(out) == {"backbone.norm_layer.weight", "backbone.norm_layer.bias", "backbone.vit_block.0.norm1.weight"}
+    out = remap_stage_checkpoint({"backbone.norm_h.weight": 1}, "con")
+    assert set(out) == {"backbone.norm_layer.weight"}

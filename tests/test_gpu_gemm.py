@@ -1,0 +1,156 @@
+"""evp_gemm on the GPU: every layout / dtype / tile / epilogue against float64 matmul on the host.
+Tolerances: f32 path 2e-5 relative to sum|a||b| (exact-f32 MFMA = fmaf chain); bf16 path exact on small-integer data
+(products and sums representable) and 1e-2 relative on random data (bf16 inputs, f32 accumulate, bf16 output)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LAYOUTS = [(False, False), (False, True), (True, True)]
+
+
+def _mk(M, N, K, ta, tb, dtype, gen, ints=False, lda_pad=0, ldb_pad=0):
+    def rnd(*s):
+        if ints:
+            return torch.randint(-3, 4, s, generator=gen).float()
+        return torch.randn(*s, generator=gen)
+    a_log, b_log = rnd(M, K), rnd(N, K)
+    a = (a_log.t() if ta else a_log).contiguous()
+    b = (b_log.t() if tb else b_log).contiguous()
+    if lda_pad:
+        a = torch.nn.functional.pad(a, (0, lda_pad))
+    if ldb_pad:
+        b = torch.nn.functional.pad(b, (0, ldb_pad))
+    a, b = a.to(dtype), b.to(dtype)
+    a_log = (a[:, :a.shape[1] - lda_pad] if lda_pad else a).float()
+    b_log = (b[:, :b.shape[1] - ldb_pad] if ldb_pad else b).float()
+    a_log = a_log.t() if ta else a_log
+    b_log = b_log.t() if tb else b_log
+    return a, b, a_log.double(), b_log.double()
+
+
+@pytest.mark.parametrize("ta,tb", LAYOUTS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tile", [1, 2])
+def test_layouts_exact_on_integers(ta, tb, dtype, tile):
+    """Asymmetric small-integer operands: any row/col or k-order mix-up in a fragment map shows as a wrong integer."""
+    from eventpretrain_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    for (M, N, K) in [(128, 128, 64), (200, 136, 96), (64, 64, 32), (16, 8, 8), (130, 72, 200), (257, 264, 72)]:
+        a, b, al, bl = _mk(M, N, K, ta, tb, dtype, gen, ints=True)
+        out = torch.empty(M, N, dtype=torch.float32).cuda()
+        ops.gemm(a.cuda(), b.cuda(), out, M=M, N=N, K=K, trans_a=ta, trans_b=tb, lda=a.shape[1], ldb=b.shape[1], tile=tile)
+        ref = (al @ bl.t()).float()
+        assert torch.equal(out.cpu(), ref), (M, N, K, (out.cpu() - ref).abs().max())
+
+
+@pytest.mark.parametrize("ta,tb", LAYOUTS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_random_and_ragged_shapes(ta, tb, dtype):
+    from eventpretrain_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    shapes = [(6272 // 8, 768, 768), (98, 98, 64), (196, 32, 196), (1, 8, 8), (333, 24, 40), (100, 1000, 16), (392, 4096, 384)]
+    for (M, N, K) in shapes:
+        # contiguous dims must be multiples of 8 (bf16) / 4 (f32): pad the operand whose ragged dim is contiguous
+        lda_pad = (-K) % 8 if not ta else (-M) % 8
+        ldb_pad = (-K) % 8 if not tb else (-N) % 8
+        a, b, al, bl = _mk(M, N, K, ta, tb, dtype, gen, lda_pad=lda_pad, ldb_pad=ldb_pad)
+        ldc = (N + 7) // 8 * 8
+        for out_dtype in (torch.float32, dtype):
+            out = torch.full((M, ldc), 7.0, dtype=out_dtype).cuda()
+            ops.gemm(a.cuda(), b.cuda(), out, M=M, N=N, K=K, trans_a=ta, trans_b=tb, lda=a.shape[1], ldb=b.shape[1], ldc=ldc)
+            ref = al @ bl.t()
+            scale = (al.abs() @ bl.abs().t()).clamp_min(1e-6)
+            err = ((out.cpu().double()[:, :N] - ref).abs() / scale).max().item()
+            tol = 2e-5 if (dtype == torch.float32 and out_dtype == torch.float32) else 1e-2
+            assert err <= tol, (M, N, K, out_dtype, err)
+            if ldc > N:
+                assert (out.cpu()[:, N:] == 7.0).all(), "wrote outside N"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_epilogues(dtype):
+    from eventpretrain_amd import ops
+    from eventpretrain_amd._lib import ACT_DGELU, ACT_DRELU, ACT_GELU, ACT_RELU
+    gen = torch.Generator().manual_seed(5)
+    M, N, K = 200, 136, 96
+    a, b, al, bl = _mk(M, N, K, False, False, dtype, gen)
+    bias = torch.randn(N, generator=gen)
+    res = torch.randn(M, N, generator=gen)
+    base = 0.5 * (al @ bl.t()) + bias.double()
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+
+    def close(x, y, t=tol):
+        return ((x.cpu().double() - y).abs() / (y.abs() + 1.0)).max().item() <= t
+
+    # bias + GELU with pre-activation aux + residual
+    out = torch.empty(M, N, dtype=torch.float32).cuda()
+    aux = torch.empty(M, N, dtype=torch.float32).cuda()
+    ops.gemm(a.cuda(), b.cuda(), out, M=M, N=N, K=K, alpha=0.5, bias=bias.cuda(), act=ACT_GELU, aux=aux, residual=res.cuda())
+    assert close(aux, base)
+    assert close(out, torch.nn.functional.gelu(base) + res.double())
+    # ReLU
+    ops.gemm(a.cuda(), b.cuda(), out, M=M, N=N, K=K, alpha=0.5, bias=bias.cuda(), act=ACT_RELU)
+    assert close(out, torch.relu(base))
+    # dGELU / dReLU read aux
+    h = torch.randn(M, N, generator=gen)
+    hd = h.double().requires_grad_(True)
+    torch.nn.functional.gelu(hd).sum().backward()
+    ops.gemm(a.cuda(), b.cuda(), out, M=M, N=N, K=K, act=ACT_DGELU, aux=h.cuda())
+    assert close(out, (al @ bl.t()) * hd.grad)
+    ops.gemm(a.cuda(), b.cuda(), out, M=M, N=N, K=K, act=ACT_DRELU, aux=h.cuda())
+    assert close(out, (al @ bl.t()) * (h > 0).double())
+    # accumulate
+    acc0 = torch.randn(M, N, generator=gen)
+    out = acc0.clone().cuda()
+    ops.gemm(a.cuda(), b.cuda(), out, M=M, N=N, K=K, accumulate=True)
+    assert close(out, acc0.double() + al @ bl.t())
+    # low-precision output with aux
+    if dtype == torch.bfloat16:
+        out = torch.empty(M, N, dtype=dtype).cuda()
+        aux = torch.empty(M, N, dtype=dtype).cuda()
+        ops.gemm(a.cuda(), b.cuda(), out, M=M, N=N, K=K, alpha=0.5, bias=bias.cuda(), act=ACT_GELU, aux=aux)
+        assert close(aux.float(), base, 2e-2) and close(out.float(), torch.nn.functional.gelu(base), 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_strided(dtype):
+    """The attention-core shapes: operands are slices of a packed [B,N,3,h,dh] tensor."""
+    from eventpretrain_amd import ops
+    gen = torch.Generator().manual_seed(6)
+    B, Nn, h, dh = 3, 50, 4, 32
+    Cc = h * dh
+    qkv = torch.randn(B, Nn, 3, h, dh, generator=gen).to(dtype)
+    q, k, v = [qkv[:, :, i].float().double().permute(0, 2, 1, 3) for i in range(3)]       # (B,h,N,dh)
+    ldp = (Nn + 7) // 8 * 8
+    s = torch.zeros(B, h, Nn, ldp, dtype=torch.float32).cuda()
+    qd = qkv.cuda()
+    ops.gemm(qd, qd, s, M=Nn, N=Nn, K=dh, lda=3 * Cc, ldb=3 * Cc, ldc=ldp, b_off=Cc, alpha=0.25, batch=(B, h),
+             stride_a=(Nn * 3 * Cc, dh), stride_b=(Nn * 3 * Cc, dh), stride_c=(h * Nn * ldp, Nn * ldp))
+    ref = 0.25 * q @ k.transpose(-1, -2)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert ((s.cpu().double()[..., :Nn] - ref).abs() / (q.abs() @ k.abs().transpose(-1, -2) + 1e-3)).max() <= tol
+    # out = p v with v k-strided (transB) and the output scattered back to [B,N,h*dh]
+    p = torch.rand(B, h, Nn, ldp, generator=gen)
+    p[..., Nn:] = 0
+    p = p.to(dtype)
+    o = torch.zeros(B, Nn, Cc, dtype=torch.float32).cuda()
+    ops.gemm(p.cuda(), qd, o, M=Nn, N=dh, K=Nn, lda=ldp, ldb=3 * Cc, ldc=Cc, b_off=2 * Cc, trans_b=True, batch=(B, h),
+             stride_a=(h * Nn * ldp, Nn * ldp), stride_b=(Nn * 3 * Cc, dh), stride_c=(Nn * Cc, dh))
+    refo = (p.float().double()[..., :Nn] @ v).permute(0, 2, 1, 3).reshape(B, Nn, Cc)
+    assert ((o.cpu().double() - refo).abs() / (refo.abs() + 1.0)).max() <= tol
+
+
+def test_argument_errors_raise():
+    from eventpretrain_amd import ops
+    from eventpretrain_amd._lib import EvpError
+    a = torch.zeros(8, 12).cuda()
+    with pytest.raises(EvpError):
+        ops.gemm(a, a, torch.zeros(8, 8).cuda(), M=8, N=8, K=12, lda=10)          # lda not a multiple of 4
+    with pytest.raises(EvpError):
+        ops.gemm(a, a, torch.zeros(8, 8).cuda(), M=8, N=8, K=12, trans_a=True)     # (1,0) layout not built
+    with pytest.raises(EvpError):
+        ops.gemm(a.cpu(), a.cpu(), torch.zeros(8, 8), M=8, N=8, K=12)              # no CPU path
