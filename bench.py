@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pretrain samples/s of the masked-ViT optimiser step (BASELINE.json configs[1]:
+ViT-Base masked modeling with the difference-map decoder, 224x224 5-bin voxels, bf16, batch 64 per MI355X).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = mask-noise draw -> forward -> backward -> (N>1: bucketed RCCL gradient all-reduce, overlapped with
+backward) -> fused AdamW -> zero_grad, on a synthetic batch that is already resident in HBM (voxel grids made by the
+K1 kernel from synthetic event clips before the timed region). Prints ONE JSON line on rank 0.
+
+Extra objects on the same line:
+  roofline      dominant kernel = the 128x128-tile bf16 MFMA GEMM family; achieved = algorithmic FLOPs of its launches in
+                one step / their HIP-event-measured duration (instrumented steps after the timed region), peak = 2.5
+                PFLOP/s dense bf16 (MI355X_MICROARCH.md).
+  voxel         K1 event->voxel scatter: achieved GB/s on 64 clips x 100k events (4.2 MB algorithmic bytes per clip)
+                against the 8 TB/s HBM peak, HIP-event timed.
+  cpu_baseline  the CPU oracle (oracle/model_oracle.py: torch fp32 restatement, kind "port") timed on this box's host
+                cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md "Chip-level parameters"
+HBM_PEAK_GBS = 8000.0            # HBM3E spec, same table
+
+
+def step_flops_per_sample(cfg):
+    """Algorithmic FLOPs of one optimiser step per sample (SURVEY.md 8d conventions: multiply-add = 2, backward = 2x
+    forward, softmax/LN/GELU/optimizer excluded). Patch-embed is counted on the kept tokens only, because this
+    implementation gathers before the conv GEMM (identical result; the reference computes all 196)."""
+    L, keep = cfg["L"], cfg["keep"]
+    D, Dd = cfg["dim"], cfg["dec_dim"]
+    blk = lambda n, d: 24 * n * d * d + 4 * n * n * d
+    fwd = 2 * keep * cfg["patch_k"] * D + cfg["depth"] * blk(keep, D) + 2 * keep * D * Dd + cfg["dec_depth"] * blk(L, Dd) \
+        + 2 * L * Dd * cfg["pred"]
+    return 3 * fwd
+
+
+def build(args, device):
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
+    from eventpretrain_amd.optim import FusedAdamW
+    from eventpretrain_amd.testing import make_args
+    from eventpretrain_amd.utils import lr_decay as lrd
+    a = make_args(model_size=args.model, pr_phase="rec", device="cuda", batch_size=args.batch)
+    torch.manual_seed(1234)       # identical initial weights on every rank (DDP broadcasts them in the reference)
+    fac = {"base": hub.pretrain_hub_model_base_patch16, "small": hub.pretrain_hub_model_small_patch16,
+           "tiny": hub.pretrain_hub_model_tiny_patch16_64}[args.model]
+    model = fac(a, emb_frames_dim=512, queue_length=1024, T=0.07).to(device).train()
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    a.lr = a.blr * args.batch * world / 256
+    groups = lrd.param_groups_lrd(a, model, a.weight_decay, layer_decay=1)
+    opt = FusedAdamW(groups, lr=a.lr, betas=(0.9, 0.95), grad_scale=1.0 / world)
+    ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    return a, model, opt
+
+
+def make_batch(args, device, rank):
+    """Synthetic clips -> voxel grids through the K1 kernel; difference-map targets ~ N(0,1)."""
+    from eventpretrain_amd.dataset.dataset_utils.events_to_voxel_grid import voxel_grid_batch
+    from eventpretrain_amd.testing import synthetic_events
+    S = 64 if args.model == "tiny" else 224
+    n_ev = 10_000 if args.model == "tiny" else 100_000
+    B = args.batch
+    base = synthetic_events(1000 * rank, n_ev, width=S, height=S)
+    rng = np.random.default_rng(77 + rank)
+    evs = []
+    for i in range(B):             # cheap per-clip variation of one generated clip (generation is host-side numpy)
+        e = base.copy()
+        e[:, 0] = (e[:, 0] + rng.integers(0, S)) % S
+        e[:, 1] = (e[:, 1] + rng.integers(0, S)) % S
+        if i % 2:
+            e[:, 3] = 1.0 - e[:, 3]
+        evs.append(e)
+    ev = torch.from_numpy(np.concatenate(evs, 0)).to(device)
+    off = torch.arange(0, (B + 1) * n_ev, n_ev, dtype=torch.int64, device=device)
+    vox = voxel_grid_batch(ev, off, 5, (S, S))
+    g = torch.Generator(device="cpu").manual_seed(1 + rank)
+    tgt = torch.randn(B, 1, S, S, generator=g).to(device)
+    return ev, off, vox, tgt, S, n_ev
+
+
+class GemmTimer:
+    """HIP-event instrumentation of ops.gemm (events are recorded on the stream the kernel is launched on: torch's
+    current stream). Keyed by kernel instantiation (layout + tile)."""
+
+    def __init__(self):
+        self.rec = []
+
+    def install(self):
+        from eventpretrain_amd import ops
+        self._orig = ops.gemm
+        timer = self
+
+        def timed(a, b, out, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = timer._orig(a, b, out, **kw)
+            e1.record()
+            M, N, K = kw["M"], kw["N"], kw["K"]
+            nb = kw.get("batch", (1, 1))
+            big = ((M + 127) // 128) * ((N + 127) // 128) * nb[0] * nb[1]
+            tile = kw.get("tile", 0) or (1 if (M >= 128 and N >= 128 and big >= 192) else 2)
+            key = ("bf16" if a.dtype == torch.bfloat16 else "f32", int(bool(kw.get("trans_a"))), int(bool(kw.get("trans_b"))), tile)
+            timer.rec.append((key, 2.0 * M * N * K * nb[0] * nb[1], e0, e1))
+            return r
+
+        ops.gemm = timed
+
+    def remove(self):
+        from eventpretrain_amd import ops
+        ops.gemm = self._orig
+
+    def summary(self, n_steps):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, fl, e0, e1 in self.rec:
+            a = agg.setdefault(key, [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        out = []
+        for key, (fl, sec, n) in agg.items():
+            out.append(dict(kernel="gemm_kernel<%s,transA=%d,transB=%d,tile=%s>" % (key[0], key[1], key[2], "128x128" if key[3] == 1 else "64x64"),
+                            launches_per_step=n / n_steps, avg_us=sec / n * 1e6, tflops=fl / sec / 1e12,
+                            ms_per_step=sec / n_steps * 1e3, flops_per_step=fl / n_steps))
+        out.sort(key=lambda d: -d["ms_per_step"])
+        return out
+
+
+def cpu_baseline(cfgs, n_threads):
+    """Oracle (torch-CPU fp32 restatement + its own AdamW) on a bounded sample: ViT-Base, B=4, one optimiser step."""
+    from oracle import model_oracle as mo
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import rec_state_dict
+    torch.set_num_threads(n_threads)
+    cfg = dict(input=224, patch=16, dim=768, depth=12, heads=12, dec_dim=512, dec_depth=8, dec_heads=16, mask_ratio=0.5, B=4)
+    sd = rec_state_dict(cfg)
+    train = [k for k in sd if "pos_embed" not in k]
+    for k in train:
+        sd[k].requires_grad_(True)
+    g = torch.Generator().manual_seed(0)
+    x, y, noise = torch.randn(4, 5, 224, 224, generator=g), torch.randn(4, 1, 224, 224, generator=g), torch.rand(4, 196, generator=g)
+    decay, _ = mo.decay_split([(k, tuple(sd[k].shape)) for k in train])
+    t0 = time.time()
+    loss = mo.rec_step(sd, x, y, noise, cfg)[0]
+    loss.backward()
+    with torch.no_grad():
+        for k in train:
+            mo.adamw_step(sd[k], sd[k].grad, torch.zeros_like(sd[k]), torch.zeros_like(sd[k]), 1, 1e-4, 0.05 if k in decay else 0.0)
+    dt_ = time.time() - t0
+    return dict(value=4 / dt_, unit="samples/s", cores=n_threads, kind="port",
+                sample="oracle/model_oracle.py (torch fp32 CPU restatement), ViT-Base+dec-Base masked step fwd+bwd+AdamW, B=4, 1 step, %.1f s" % dt_)
+
+
+def cpu_voxel_baseline():
+    from eventpretrain_amd.testing import synthetic_events
+    from oracle.voxel_oracle import voxel_grid_batch
+    evs = [synthetic_events(i) for i in range(8)]
+    ev = np.concatenate(evs, 0)
+    off = np.arange(0, 9 * 100_000, 100_000, dtype=np.int64)
+    voxel_grid_batch(ev[:100_000], off[:2], 5, (224, 224))
+    t0 = time.time()
+    voxel_grid_batch(ev, off, 5, (224, 224))
+    dt_ = time.time() - t0
+    return dict(value=8 / dt_, unit="clips/s", cores=1, kind="port", sample="oracle/voxel_oracle.c, 8 clips x 100k events, %.2f s" % dt_)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--model", default="base", choices=["base", "small", "tiny"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--bucket-mb", type=float, default=64.0)
+    args = ap.parse_args()
+
+    from eventpretrain_amd import _lib
+    _lib.require_device()
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
+        raise SystemExit("--gpus does not match WORLD_SIZE")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)     # "nccl" is RCCL over xGMI on ROCm
+
+    a, model, opt = build(args, device)
+    ev, off, vox, tgt, S, n_ev = make_batch(args, device, rank)
+    reducer = None
+    if world > 1:
+        from eventpretrain_amd.parallel import BucketedGradReducer
+        reducer = BucketedGradReducer([p for p in model.parameters() if p.requires_grad], bucket_mb=args.bucket_mb)
+    gen = torch.Generator(device=device).manual_seed(100 + rank)     # seed + rank, as main_pretrain.py:174
+    L = model.backbone.num_patches
+
+    def step():
+        noise = torch.rand(args.batch, L, device=device, generator=gen)
+        out = model(vox, tgt, is_rec=True, noise=noise)
+        out[0].backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return out[0]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    ms = elapsed / args.steps * 1e3
+    value = args.batch * world * args.steps / elapsed
+    dims = dict(base=(768, 12, 512, 8), small=(384, 12, 256, 8), tiny=(192, 12, 128, 4))[args.model]
+    fcfg = dict(L=L, keep=int(L * 0.5), dim=dims[0], depth=dims[1], dec_dim=dims[2], dec_depth=dims[3], patch_k=5 * 256, pred=256)
+    fl_sample = step_flops_per_sample(fcfg)
+    result = {
+        "metric": "pretrain samples/sec (masked-ViT step, B=64 224^2)", "value": value, "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "ViT-%s masked modeling (diff-map decoder), %dx%d 5-bin voxels, batch=%d per GPU, AdamW step included"
+                               % (args.model.capitalize(), S, S, args.batch),
+                   "global_batch": args.batch * world, "parallelism": "dp%d" % world, "mask_ratio": 0.5,
+                   "params_M": sum(p.numel() for p in model.parameters()) / 1e6},
+        "final_loss": final_loss,
+        "step_tflops_per_gpu": fl_sample * args.batch / (ms * 1e-3) / 1e12,
+        "step_mfma_frac": fl_sample * args.batch / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+    }
+
+    if rank == 0 and not args.no_kernel_timing:
+        # ---- dominant kernel, HIP events around every GEMM launch of real steps (instrumented, after the timed region)
+        timer = GemmTimer()
+        timer.install()
+        n_inst = 3
+        for _ in range(n_inst):
+            step()
+        ks = timer.summary(n_inst)
+        timer.remove()
+        if ks:
+            top = ks[0]
+            peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
+            result["roofline"] = {"bound": "mfma", "achieved": top["tflops"], "peak": peak, "unit": "TFLOP/s",
+                                  "frac": top["tflops"] / peak, "traffic": None, "kernel": top["kernel"],
+                                  "avg_launch_us": top["avg_us"], "launches_per_step": top["launches_per_step"],
+                                  "ms_per_step_in_kernel": top["ms_per_step"]}
+            result["gemm_kernels"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items() if k != "flops_per_step"} for d in ks]
+        # ---- K1 voxel scatter (HBM-bound)
+        from eventpretrain_amd.dataset.dataset_utils.events_to_voxel_grid import voxel_grid_batch
+        out = torch.empty_like(vox)
+        for _ in range(3):
+            voxel_grid_batch(ev, off, 5, (S, S), out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            voxel_grid_batch(ev, off, 5, (S, S), out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) * 1e-3 / reps
+        bytes_ = args.batch * (n_ev * 32 + 5 * S * S * 4)
+        result["voxel"] = {"bound": "hbm", "achieved": bytes_ / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": bytes_ / sec / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "voxel_cuts_kernel+voxel_bin_kernel",
+                           "us_per_batch": sec * 1e6, "clips_per_s": args.batch / sec, "events_per_s": args.batch * n_ev / sec,
+                           "algorithmic_bytes_per_clip": n_ev * 32 + 5 * S * S * 4}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        n_thr = min(os.cpu_count() or 1, 16)
+        try:
+            result["cpu_baseline"] = cpu_baseline(fcfg, n_thr)
+            result["cpu_baseline_voxel"] = cpu_voxel_baseline()
+        except Exception as e:  # the baseline is a reported figure; never lose the GPU line over it
+            result["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": n_thr, "kind": "port", "sample": "failed: %r" % (e,)}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

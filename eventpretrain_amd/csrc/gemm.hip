@@ -15,6 +15,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short i16x4;
 typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 namespace {
 
@@ -31,6 +32,7 @@ struct GemmParams {
   const float *residual; int64_t ldres;
   int accumulate;
   int tiles_m;
+  int splitk, k_per_split;   // blockIdx.y = K slice
 };
 
 template <typename T> struct Cfg;
@@ -84,23 +86,20 @@ template <typename T, bool TR, int ROWS, int NT> struct Stage {
   static constexpr int NCHUNK = (NROW * CPR + NT - 1) / NT;         // per thread
   uint4 r[NCHUNK];
 
-  // base: operand pointer for this batch; row0: first m/n of the tile; k0: first k; nrows: M or N; K: depth
-  __device__ __forceinline__ void load(const T *base, int64_t ld, int row0, int k0, int nrows, int K, int tid) {
+  // rs: buffer descriptor of this batch's operand (2 GiB window); row0: first m/n of the tile; k0: first k;
+  // nrows: M or N; K: depth bound. Out-of-range chunks get an offset beyond the window: the hardware range check
+  // returns zeros, so there is no branch, no select and nothing that forces a wait before the MFMAs.
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int ld, int row0, int k0, int nrows, int K, int tid) {
 #pragma unroll
     for (int i = 0; i < NCHUNK; ++i) {
       const int cid = tid + i * NT;
       const int lr = cid / CPR, c = cid % CPR;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (NROW * CPR % NT == 0 || cid < NROW * CPR) {
-        if (!TR) {
-          const int gr = row0 + lr, gk = k0 + c * EPC;
-          if (gr < nrows && gk < K) v = *reinterpret_cast<const uint4 *>(base + (int64_t)gr * ld + gk);
-        } else {
-          const int gk = k0 + lr, gr = row0 + c * EPC;
-          if (gk < K && gr < nrows) v = *reinterpret_cast<const uint4 *>(base + (int64_t)gk * ld + gr);
-        }
-      }
-      r[i] = v;
+      const int gr = TR ? row0 + c * EPC : row0 + lr;   // m / n index
+      const int gk = TR ? k0 + lr : k0 + c * EPC;       // k index
+      const bool ok = (NROW * CPR % NT == 0 || cid < NROW * CPR) && gr < nrows && gk < K;
+      const int off = ok ? (TR ? gk * ld + gr : gr * ld + gk) * (int)sizeof(T) : (int)0x80000000;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+      r[i] = make_uint4(v[0], v[1], v[2], v[3]);
     }
   }
   __device__ __forceinline__ void store(char *img, int tid) const {
@@ -157,8 +156,132 @@ __device__ __forceinline__ float frag_f32(const char *img, int rb, int ks, int l
   else return f[(ks * 4 + g) * Img<float, true, ROWS>::LD + rb + i];
 }
 
+// ---- epilogue helpers ----------------------------------------------------------------------------------------
+// erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): one v_exp + one v_rcp + 5 fma. Used in bf16 mode only.
+__device__ __forceinline__ void erf_pdf_fast(float x, float &erfv, float &pdf) {
+  const float z = x * 0.70710678118654752440f, az = fabsf(z);
+  const float t = __frcp_rn(1.0f + 0.3275911f * az);
+  const float u = __expf(-0.5f * x * x);          // e^{-x^2/2};  e^{-z^2} = u
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = 1.0f - poly * u;
+  erfv = z < 0.f ? -e : e;
+  pdf = 0.39894228040143267794f * u;
+}
+__device__ __forceinline__ float gelu_sel(float x, bool fast) {
+  if (!fast) return gelu_f(x);
+  float e, pdf;
+  erf_pdf_fast(x, e, pdf);
+  return 0.5f * x * (1.0f + e);
+}
+__device__ __forceinline__ float dgelu_sel(float x, bool fast) {
+  if (!fast) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+  }
+  float e, pdf;
+  erf_pdf_fast(x, e, pdf);
+  return 0.5f * (1.0f + e) + x * pdf;
+}
+
+template <typename TC> __device__ __forceinline__ float4 ld4(const TC *p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+template <> __device__ __forceinline__ float4 ld4<bf16_t>(const bf16_t *p) {
+  const uint2 u = *reinterpret_cast<const uint2 *>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xFFFF0000u));
+}
+template <typename TC> __device__ __forceinline__ void st4(TC *p, float4 v);
+template <> __device__ __forceinline__ void st4<float>(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t *p, float4 v) {
+  uint2 u;
+  u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+  u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+  *reinterpret_cast<uint2 *>(p) = u;
+}
+
+// ragged right edge (N not a multiple of 4, e.g. attention scores with N = 98): element-wise and out of line. All
+// arguments by value: taking the address of the kernel-argument struct would push it (and every pointer derived from
+// it) into scratch memory.
+template <typename TC>
+__device__ __noinline__ void epilogue_edge(TC *C, TC *aux, const float *bias, const float *residual, float alpha, int act,
+                                           int accumulate, int splitk, int64_t o, int64_t ao, int64_t ro, int n, int nv,
+                                           float a0, float a1, float a2, bool fast) {
+  for (int e = 0; e < nv; ++e) {
+    float x = (e == 0 ? a0 : e == 1 ? a1 : a2) * alpha;
+    if (bias) x += bias[n + e];
+    if (act == EVP_ACT_GELU || act == EVP_ACT_RELU) {
+      if (aux) ElemIO<TC>::st(aux + ao + e, x);
+      x = act == EVP_ACT_GELU ? gelu_sel(x, fast) : fmaxf(x, 0.f);
+    } else if (act == EVP_ACT_DGELU || act == EVP_ACT_DRELU) {
+      const float h = ElemIO<TC>::ld(aux + ao + e);
+      x *= act == EVP_ACT_DGELU ? dgelu_sel(h, fast) : (h > 0.f ? 1.f : 0.f);
+    }
+    if (residual) x += residual[ro + e];
+    if (splitk > 1) { atomicAdd(reinterpret_cast<float *>(C) + o + e, x); continue; }
+    if (accumulate) x += ElemIO<TC>::ld(C + o + e);
+    ElemIO<TC>::st(C + o + e, x);
+  }
+}
+
+// EPI: 0 = linear (bias / residual / accumulate), 1 = activation forward (GELU / ReLU, optional pre-activation store),
+//      2 = activation backward (multiply by act'(aux))
+template <typename TC, int EPI, int MI, int NI>
+__device__ __forceinline__ void epilogue(const f32x4 (&acc)[MI][NI], const GemmParams &p, int64_t coff, int mbase, int nbase, bool fast) {
+  TC *C = reinterpret_cast<TC *>(p.C);
+  float4 bias4[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = nbase + j * 16;
+    bias4[j] = (p.bias && n + 3 < p.N) ? *reinterpret_cast<const float4 *>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = mbase + i * 16;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = nbase + j * 16;
+      if (n >= p.N) continue;
+      const float4 a = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if (n + 3 >= p.N) {
+        epilogue_edge<TC>(C, reinterpret_cast<TC *>(p.aux), p.bias, p.residual, p.alpha, p.act, p.accumulate, p.splitk,
+                          coff + (int64_t)m * p.ldc + n, coff + (int64_t)m * p.ldaux + n, coff + (int64_t)m * p.ldres + n, n,
+                          p.N - n, a.x, a.y, a.z, fast);
+        continue;
+      }
+      float4 v = make_float4(a.x * p.alpha + bias4[j].x, a.y * p.alpha + bias4[j].y, a.z * p.alpha + bias4[j].z, a.w * p.alpha + bias4[j].w);
+      const int64_t ao = coff + (int64_t)m * p.ldaux + n;
+      if constexpr (EPI == 1) {
+        if (p.aux) st4<TC>(reinterpret_cast<TC *>(p.aux) + ao, v);
+        if (p.act == EVP_ACT_GELU) v = make_float4(gelu_sel(v.x, fast), gelu_sel(v.y, fast), gelu_sel(v.z, fast), gelu_sel(v.w, fast));
+        else v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      } else if constexpr (EPI == 2) {
+        const float4 h = ld4<TC>(reinterpret_cast<const TC *>(p.aux) + ao);
+        if (p.act == EVP_ACT_DGELU)
+          v = make_float4(v.x * dgelu_sel(h.x, fast), v.y * dgelu_sel(h.y, fast), v.z * dgelu_sel(h.z, fast), v.w * dgelu_sel(h.w, fast));
+        else v = make_float4(h.x > 0.f ? v.x : 0.f, h.y > 0.f ? v.y : 0.f, h.z > 0.f ? v.z : 0.f, h.w > 0.f ? v.w : 0.f);
+      }
+      if (p.residual) {
+        const float4 r = *reinterpret_cast<const float4 *>(p.residual + coff + (int64_t)m * p.ldres + n);
+        v = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
+      }
+      const int64_t o = coff + (int64_t)m * p.ldc + n;
+      if (p.splitk > 1) {          // split-K partial sums meet in HBM (f32 C, zeroed by the launcher)
+        float *c = reinterpret_cast<float *>(p.C) + o;
+        atomicAdd(c + 0, v.x); atomicAdd(c + 1, v.y); atomicAdd(c + 2, v.z); atomicAdd(c + 3, v.w);
+        continue;
+      }
+      if (p.accumulate) {
+        const float4 c = ld4<TC>(C + o);
+        v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
+      }
+      st4<TC>(C + o, v);
+    }
+  }
+}
+
 // ---- the kernel --------------------------------------------------------------------------------------------
-template <typename T, bool TA, bool TB, int BM, int BN, int WM, int WN>
+template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmParams p) {
   constexpr int NT = WM * WN * 64;
   constexpr int BK = Cfg<T>::BK, KSTEP = Cfg<T>::KSTEP;
@@ -168,11 +291,31 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int tile_m = blockIdx.x % p.tiles_m, tile_n = blockIdx.x / p.tiles_m;
+  // Block -> tile map (speed only, never correctness): (1) blocks b and b+8 share an XCD, so renumber to give every
+  // XCD a contiguous run of tiles (bijective for any grid size); (2) inside the run walk GROUP_M x tiles_n panels,
+  // M fastest, so the ~64 blocks an XCD runs at once share 8 A panels and 8 B panels that fit its 4 MiB L2.
+  int tile_m, tile_n;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    constexpr int GROUP_M = 8;
+    const int tiles_n = nblk / p.tiles_m;
+    const int per_group = GROUP_M * tiles_n;
+    const int gid = t / per_group, first_m = gid * GROUP_M;
+    const int gsz = (p.tiles_m - first_m) < GROUP_M ? (p.tiles_m - first_m) : GROUP_M;
+    const int in_g = t - gid * per_group;
+    tile_m = first_m + in_g % gsz;
+    tile_n = in_g / gsz;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int b0 = blockIdx.z / p.batch1, b1 = blockIdx.z % p.batch1;
   const T *A = reinterpret_cast<const T *>(p.A) + b0 * p.sA0 + b1 * p.sA1;
   const T *B = reinterpret_cast<const T *>(p.B) + b0 * p.sB0 + b1 * p.sB1;
+  // wave-uniform buffer descriptors (kernel arguments and blockIdx only): hardware bounds check, 32-bit offsets
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(A), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(B), 0, 0x7FFFFFFF, 0x00020000);
+  const int lda = (int)p.lda, ldb = (int)p.ldb;
 
   f32x4 acc[MI][NI];
 #pragma unroll
@@ -182,10 +325,12 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmParams p) {
 
   Stage<T, TA, BM, NT> sa;
   Stage<T, TB, BN, NT> sb;
-  const int ntiles = (p.K + BK - 1) / BK;
+  const int kbeg = blockIdx.y * p.k_per_split;
+  const int kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
+  const int ntiles = (kend - kbeg + BK - 1) / BK;
 
-  sa.load(A, p.lda, m0, 0, p.M, p.K, tid);
-  sb.load(B, p.ldb, n0, 0, p.N, p.K, tid);
+  sa.load(rsA, lda, m0, kbeg, p.M, kend, tid);
+  sb.load(rsB, ldb, n0, kbeg, p.N, kend, tid);
   sa.store(smem, tid);
   sb.store(smem + A_BYTES, tid);
   __syncthreads();
@@ -195,8 +340,8 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmParams p) {
     char *nxt = smem + ((t + 1) & 1) * (A_BYTES + B_BYTES);
     const bool more = (t + 1) < ntiles;
     if (more) {
-      sa.load(A, p.lda, m0, (t + 1) * BK, p.M, p.K, tid);
-      sb.load(B, p.ldb, n0, (t + 1) * BK, p.N, p.K, tid);
+      sa.load(rsA, lda, m0, kbeg + (t + 1) * BK, p.M, kend, tid);
+      sb.load(rsB, ldb, n0, kbeg + (t + 1) * BK, p.N, kend, tid);
     }
     const char *ia = cur, *ib = cur + A_BYTES;
 #pragma unroll
@@ -235,68 +380,33 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmParams p) {
   // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4
   const int64_t coff = b0 * p.sC0 + b1 * p.sC1;
   const int li = lane & 15, lg = lane >> 4;
+  if constexpr (2 * (A_BYTES + B_BYTES) >= BM * BN * 4 && EPI == 0 && sizeof(TC) == 4) {
+    if (p.splitk > 1) {
+      // split-K: stage the f32 tile through LDS so that every atomic wave-instruction adds 256 contiguous bytes of
+      // one output row (the full-rate shape for global_atomic_add_f32, MI355X_MICROARCH.md "Global float atomics")
+      float *tile = reinterpret_cast<float *>(smem);
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int m = m0 + wm * WTM + i * 16 + li;
-    if (m >= p.M) continue;
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = n0 + wn * WTN + j * 16 + lg * 4;
-      if (n >= p.N) continue;
-      float v[4] = {acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha};
-      const int nv = (p.N - n) < 4 ? (p.N - n) : 4;
-      if (p.bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (e < nv) v[e] += p.bias[n + e];
-      }
-      if (p.act == EVP_ACT_GELU || p.act == EVP_ACT_RELU) {
-        if (p.aux) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (e < nv) st_any(p.aux, p.c_dtype, coff + (int64_t)m * p.ldaux + n + e, v[e]);
+        for (int j = 0; j < NI; ++j) {
+          const int r = wm * WTM + i * 16 + li, c = wn * WTN + j * 16 + lg * 4;
+          *reinterpret_cast<float4 *>(tile + r * BN + c) =
+              make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = p.act == EVP_ACT_GELU ? gelu_f(v[e]) : fmaxf(v[e], 0.f);
-      } else if (p.act == EVP_ACT_DGELU || p.act == EVP_ACT_DRELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (e < nv) {
-            const float h = ld_any(p.aux, p.c_dtype, coff + (int64_t)m * p.ldaux + n + e);
-            v[e] *= p.act == EVP_ACT_DGELU ? dgelu_f(h) : (h > 0.f ? 1.f : 0.f);
-          }
+      __syncthreads();
+      float *C = reinterpret_cast<float *>(p.C) + coff;
+      for (int e = tid; e < BM * BN; e += NT) {
+        const int r = e / BN, c = e % BN;
+        if (m0 + r < p.M && n0 + c < p.N) atomicAdd(C + (int64_t)(m0 + r) * p.ldc + n0 + c, tile[e]);
       }
-      if (p.residual) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (e < nv) v[e] += p.residual[coff + (int64_t)m * p.ldres + n + e];
-      }
-      const int64_t o = coff + (int64_t)m * p.ldc + n;
-      if (p.c_dtype == EVP_F32) {
-        float *c = reinterpret_cast<float *>(p.C) + o;
-        if (p.accumulate) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (e < nv) v[e] += c[e];
-        }
-        if (nv == 4 && (o & 3) == 0) *reinterpret_cast<float4 *>(c) = make_float4(v[0], v[1], v[2], v[3]);
-        else
-          for (int e = 0; e < nv; ++e) c[e] = v[e];
-      } else {
-        bf16_t *c = reinterpret_cast<bf16_t *>(p.C) + o;
-        if (nv == 4 && (o & 3) == 0) {
-          uint2 pk;
-          pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-          pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-          *reinterpret_cast<uint2 *>(c) = pk;
-        } else
-          for (int e = 0; e < nv; ++e) c[e] = f32_to_bf16(v[e]);
-      }
+      return;
     }
   }
+  const bool fast = sizeof(T) == 2;   // bf16 mode may use the fast erf; f32 parity mode uses erff
+  epilogue<TC, EPI, MI, NI>(acc, p, coff, m0 + wm * WTM + li, n0 + wn * WTN + lg * 4, fast);
 }
 
-template <typename T, bool TA, bool TB, int BM, int BN, int WM, int WN>
+template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN>
 int launch(const evp_gemm_desc *d, hipStream_t s) {
   GemmParams p;
   p.M = d->M; p.N = d->N; p.K = d->K;
@@ -309,8 +419,34 @@ int launch(const evp_gemm_desc *d, hipStream_t s) {
   p.tiles_m = (d->M + BM - 1) / BM;
   const int tiles_n = (d->N + BN - 1) / BN;
   const int nb = (d->batch0 > 0 ? d->batch0 : 1) * p.batch1;
+  // split-K: only for plain f32 outputs without epilogue extras (the weight-gradient GEMMs: few output tiles, long K)
+  constexpr int BKc = Cfg<T>::BK;
+  int splitk = d->splitk;
+  const bool can_split = d->c_dtype == EVP_F32 && !d->bias && d->act == EVP_ACT_NONE && !d->residual && !d->aux && nb == 1;
+  if (splitk == 0) {
+    splitk = 1;
+    const int tiles = p.tiles_m * tiles_n;
+    const int ktiles = (d->K + BKc - 1) / BKc;
+    if (can_split && tiles < 384 && ktiles >= 16) {
+      splitk = (512 + tiles - 1) / tiles;
+      if (splitk > ktiles / 8) splitk = ktiles / 8;
+      if (splitk < 1) splitk = 1;
+    }
+  }
+  if (!can_split) splitk = 1;
+  {
+    const int ktiles = (d->K + BKc - 1) / BKc;
+    const int per = (ktiles + splitk - 1) / splitk;
+    p.k_per_split = per * BKc;
+    splitk = (ktiles + per - 1) / per;
+    p.splitk = splitk;
+  }
+  if (splitk > 1 && !d->accumulate) {
+    hipError_t e = hipMemset2DAsync(d->C, (size_t)d->ldc * 4, 0, (size_t)d->N * 4, (size_t)d->M, s);
+    if (e != hipSuccess) { evp_set_error("evp_gemm: memset for split-K failed: %s", hipGetErrorString(e)); return EVP_ELAUNCH; }
+  }
   constexpr int smem = 2 * (Img<T, TA, BM>::BYTES + Img<T, TB, BN>::BYTES);
-  auto k = gemm_kernel<T, TA, TB, BM, BN, WM, WN>;
+  auto k = gemm_kernel<T, TC, EPI, TA, TB, BM, BN, WM, WN>;
   static bool attr_done = false;  // one flag per instantiation
   if (!attr_done) {
     if (smem > 48 * 1024) {
@@ -322,28 +458,46 @@ int launch(const evp_gemm_desc *d, hipStream_t s) {
     }
     attr_done = true;
   }
-  dim3 grid((unsigned)(p.tiles_m * tiles_n), 1, (unsigned)nb);
+  dim3 grid((unsigned)(p.tiles_m * tiles_n), (unsigned)splitk, (unsigned)nb);
   hipLaunchKernelGGL(k, grid, dim3(WM * WN * 64), smem, s, p);
   EVP_CHECK_LAUNCH("evp_gemm");
   return EVP_OK;
 }
 
-template <typename T, bool TA, bool TB> int pick_tile(const evp_gemm_desc *d, hipStream_t s) {
+template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(const evp_gemm_desc *d, hipStream_t s) {
   int tile = d->tile;
   if (tile == 0) {
     const int64_t big = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * (d->batch0 > 0 ? d->batch0 : 1) *
                         (d->batch1 > 0 ? d->batch1 : 1);
-    tile = (d->M >= 128 && d->N >= 128 && big >= 192) ? 1 : 2;
+    const bool splittable = d->c_dtype == EVP_F32 && !d->bias && d->act == EVP_ACT_NONE && !d->residual && !d->aux &&
+                            d->batch0 <= 1 && d->batch1 <= 1 && d->K >= 2048;
+    tile = (d->M >= 128 && d->N >= 128 && (big >= 192 || splittable)) ? 1 : 2;
   }
-  if (tile == 1) return launch<T, TA, TB, 128, 128, 2, 2>(d, s);
-  return launch<T, TA, TB, 64, 64, 2, 2>(d, s);
+  if (tile == 1) return launch<T, TC, EPI, TA, TB, 128, 128, 2, 2>(d, s);
+  return launch<T, TC, EPI, TA, TB, 64, 64, 2, 2>(d, s);
 }
 
-template <typename T> int pick_layout(const evp_gemm_desc *d, hipStream_t s) {
-  if (!d->transA && !d->transB) return pick_tile<T, false, false>(d, s);
-  if (!d->transA && d->transB) return pick_tile<T, false, true>(d, s);
-  if (d->transA && d->transB) return pick_tile<T, true, true>(d, s);
-  evp_set_error("evp_gemm: layout transA=1,transB=0 is not used on this path and not built");
+// Layout x epilogue combinations that exist on this path (everything else is refused, not silently emulated):
+//   linear epilogue: NT (forward), NN (dgrad), TN (wgrad);  activation forward: NT only;  activation backward: NN only.
+template <typename T, typename TC> int pick_layout(const evp_gemm_desc *d, hipStream_t s) {
+  const int epi = (d->act == EVP_ACT_GELU || d->act == EVP_ACT_RELU) ? 1 : (d->act == EVP_ACT_DGELU || d->act == EVP_ACT_DRELU) ? 2 : 0;
+  if (epi == 0) {
+    if (!d->transA && !d->transB) return pick_tile<T, TC, 0, false, false>(d, s);
+    if (!d->transA && d->transB) return pick_tile<T, TC, 0, false, true>(d, s);
+    if (d->transA && d->transB) return pick_tile<T, TC, 0, true, true>(d, s);
+    evp_set_error("evp_gemm: layout transA=1,transB=0 is not used on this path and not built");
+    return EVP_EUNSUPPORTED;
+  }
+  if (epi == 1 && !d->transA && !d->transB) return pick_tile<T, TC, 1, false, false>(d, s);
+  if (epi == 2 && !d->transA && d->transB) return pick_tile<T, TC, 2, false, true>(d, s);
+  evp_set_error("evp_gemm: activation epilogue %d is only built for its own layout (forward: NT, backward: transB)", d->act);
+  return EVP_EUNSUPPORTED;
+}
+
+template <typename T> int pick_ctype(const evp_gemm_desc *d, hipStream_t s) {
+  if (d->c_dtype == EVP_F32) return pick_layout<T, float>(d, s);
+  if constexpr (sizeof(T) == 2) return pick_layout<T, bf16_t>(d, s);
+  evp_set_error("evp_gemm: bf16 output needs bf16 operands");
   return EVP_EUNSUPPORTED;
 }
 
@@ -362,7 +516,13 @@ extern "C" int evp_gemm(const evp_gemm_desc *d, void *stream) {
   EVP_CHECK_ARG(d->strideA0 % epc == 0 && d->strideA1 % epc == 0 && d->strideB0 % epc == 0 && d->strideB1 % epc == 0,
                 EVP_ESHAPE, "evp_gemm: batch strides of A/B must be multiples of %d elements", epc);
   EVP_CHECK_ARG(!d->accumulate || d->c_dtype == EVP_F32, EVP_EINVAL, "evp_gemm: accumulate needs an f32 C");
+  {
+    const int64_t es = d->dtype == EVP_BF16 ? 2 : 4;
+    const int64_t spanA = (int64_t)(d->transA ? d->K : d->M) * d->lda * es, spanB = (int64_t)(d->transB ? d->K : d->N) * d->ldb * es;
+    EVP_CHECK_ARG(spanA < 0x7FFFFFFFLL && spanB < 0x7FFFFFFFLL, EVP_ESHAPE,
+                  "evp_gemm: one batch's operand must span < 2 GiB (32-bit buffer offsets)");
+  }
   EVP_CHECK_ARG((d->act != EVP_ACT_DGELU && d->act != EVP_ACT_DRELU) || d->aux, EVP_EINVAL, "evp_gemm: dgelu/drelu need aux");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  return d->dtype == EVP_BF16 ? pick_layout<bf16_t>(d, s) : pick_layout<float>(d, s);
+  return d->dtype == EVP_BF16 ? pick_ctype<bf16_t>(d, s) : pick_ctype<float>(d, s);
 }

@@ -6,7 +6,7 @@
 namespace {
 
 constexpr int ROWS_PER_BLOCK = 4;  // 4 waves / 256 threads
-constexpr int LN_MAX_BLOCKS = 1024;
+constexpr int LN_MAX_BLOCKS = 512;
 
 // Number of float4 chunks a lane holds for a row of D floats
 static inline int vpl_for(int D) {
@@ -193,14 +193,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void *dy, int dy_dtyp
   }
 }
 
-// out0[d] = sum_blk part[blk][0][d], out1[d] = sum_blk part[blk][1][d]
-__global__ void ln_bwd_finalize(const float *part, int nblk, int D, float *out0, float *out1) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= 2 * D) return;
+// out0[d] = sum_blk part[blk][0][d], out1[d] = sum_blk part[blk][1][d].
+// 1024 threads = 64 columns x 16 partial-row groups: coalesced 256-byte reads, 16-way parallel over the partials.
+__global__ __launch_bounds__(1024) void ln_bwd_finalize(const float *part, int nblk, int D, float *out0, float *out1) {
+  __shared__ float sh[16][65];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * 2 * D + e];
-  if (e < D) { if (out0) out0[e] = s; }
-  else { if (out1) out1[e - D] = s; }
+  if (e < 2 * D)
+    for (int b = g; b < nblk; b += 16) s += part[(int64_t)b * 2 * D + e];
+  sh[g][c] = s;
+  __syncthreads();
+  if (g == 0 && e < 2 * D) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sh[i][c];
+    if (e < D) { if (out0) out0[e] = t; }
+    else { if (out1) out1[e - D] = t; }
+  }
 }
 
 static inline int ln_grid(int64_t M) {
@@ -211,22 +221,49 @@ static inline int ln_grid(int64_t M) {
 }
 
 // ------------------------------------------------------------------------------------------------ column sums
-constexpr int CS_ROWS = 64;  // rows per partial block
-__global__ __launch_bounds__(256) void colsum_partial(const void *x, int dtype, int64_t M, int N, int64_t ld, float *part) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
-  const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
-  const int64_t r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
-  float s = 0.f;
-  for (int64_t r = r0; r < r1; ++r) s += ld_any(x, dtype, r * ld + n);
-  part[(int64_t)blockIdx.y * N + n] = s;
-}
-__global__ void colsum_finalize(const float *part, int nblk, int N, float *out) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * N + n];
-  out[n] = s;
+// out[n] += sum_m x[m,n]. Block = 16 column chunks (8 columns each, one 16/32-byte load per thread) x 16 row lanes
+// over a slab of CS_ROWS rows; the 16 row lanes meet in LDS, then ONE f32 atomic per column and block.
+constexpr int CS_ROWS = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T *x, int64_t M, int N, int64_t ld, float *out) {
+  __shared__ float sh[16][129];
+  const int cc = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int n = blockIdx.x * 128 + cc * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS, r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (n < N) {
+    const bool full = n + 7 < N;
+    for (int64_t r = r0 + rl; r < r1; r += 16) {
+      const T *p = x + r * ld + n;
+      if (full) {
+        if constexpr (sizeof(T) == 2) {
+          const uint4 u = *reinterpret_cast<const uint4 *>(p);
+          const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[2 * e] += __uint_as_float(w[e] << 16);
+            acc[2 * e + 1] += __uint_as_float(w[e] & 0xFFFF0000u);
+          }
+        } else {
+          const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+          acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+          acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+        }
+      } else {
+        for (int e = 0; e < 8 && n + e < N; ++e) acc[e] += ElemIO<T>::ld(p + e);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sh[rl][cc * 8 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sh[i][c];
+    if (blockIdx.x * 128 + c < N) atomicAdd(out + blockIdx.x * 128 + c, t);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ patch-embed post-op
@@ -466,7 +503,7 @@ extern "C" int evp_layernorm_bwd(const void *dy, int dy_dtype, const float *x, c
     hipLaunchKernelGGL(ln_bwd_kernel<V>, dim3(g), dim3(256), sh, s, dy, dy_dtype, x, x2, x3, gamma, mean, rstd, gres, M, D, dx, dx_lp, workspace);
   });
   EVP_CHECK_LAUNCH("evp_layernorm_bwd");
-  hipLaunchKernelGGL(ln_bwd_finalize, dim3((2 * D + 255) / 256), dim3(256), 0, s, workspace, g, D, dgamma, dbeta);
+  hipLaunchKernelGGL(ln_bwd_finalize, dim3((2 * D + 63) / 64), dim3(1024), 0, s, workspace, g, D, dgamma, dbeta);
   EVP_CHECK_LAUNCH("evp_layernorm_bwd(finalize)");
   return EVP_OK;
 }
@@ -474,14 +511,16 @@ extern "C" int evp_layernorm_bwd(const void *dy, int dy_dtype, const float *x, c
 extern "C" int evp_colsum_nblk(int64_t M) { return (int)((M + CS_ROWS - 1) / CS_ROWS); }
 
 extern "C" int evp_colsum(const void *x, int x_dtype, int64_t M, int N, int64_t ld, float *out, float *workspace, void *stream) {
-  EVP_CHECK_ARG(x && out && workspace, EVP_EINVAL, "evp_colsum: null pointer");
-  EVP_CHECK_ARG(M > 0 && N > 0 && ld >= N, EVP_ESHAPE, "evp_colsum: bad shape");
+  (void)workspace;  // kept in the signature for ABI stability; the reduction now meets in LDS + one atomic per column
+  EVP_CHECK_ARG(x && out, EVP_EINVAL, "evp_colsum: null pointer");
+  EVP_CHECK_ARG(M > 0 && N > 0 && ld >= N && ld % 8 == 0, EVP_ESHAPE, "evp_colsum: bad shape (ld must be a multiple of 8)");
   hipStream_t s = (hipStream_t)stream;
-  const int nb = evp_colsum_nblk(M);
-  hipLaunchKernelGGL(colsum_partial, dim3((N + 255) / 256, nb), dim3(256), 0, s, x, x_dtype, M, N, ld, workspace);
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * N, s);
+  EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_colsum: memset failed: %s", hipGetErrorString(e));
+  dim3 grid((N + 127) / 128, evp_colsum_nblk(M));
+  if (x_dtype == EVP_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)x, M, N, ld, out);
+  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float *)x, M, N, ld, out);
   EVP_CHECK_LAUNCH("evp_colsum");
-  hipLaunchKernelGGL(colsum_finalize, dim3((N + 255) / 256), dim3(256), 0, s, workspace, nb, N, out);
-  EVP_CHECK_LAUNCH("evp_colsum(finalize)");
   return EVP_OK;
 }
 
@@ -510,7 +549,7 @@ extern "C" int evp_embed_post_bwd(const float *g, const float *y, const float *g
     hipLaunchKernelGGL(embed_post_bwd_kernel<V>, dim3(gsz), dim3(256), sh, s, g, y, gamma, beta, mean, rstd, M, D, dy, dy_dtype, workspace);
   });
   EVP_CHECK_LAUNCH("evp_embed_post_bwd");
-  hipLaunchKernelGGL(ln_bwd_finalize, dim3((2 * D + 255) / 256), dim3(256), 0, s, workspace, gsz, D, dgamma, dbeta);
+  hipLaunchKernelGGL(ln_bwd_finalize, dim3((2 * D + 63) / 64), dim3(1024), 0, s, workspace, gsz, D, dgamma, dbeta);
   EVP_CHECK_LAUNCH("evp_embed_post_bwd(finalize)");
   return EVP_OK;
 }

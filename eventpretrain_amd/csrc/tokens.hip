@@ -206,7 +206,7 @@ static inline int ew_grid(int64_t n_items) {
 
 extern "C" int evp_mask_from_noise(const float *noise, int B, int L, int len_keep, int64_t *ids_keep, float *mask,
                                    int64_t *ids_restore, void *stream) {
-  EVP_CHECK_ARG(noise && ids_keep && mask && ids_restore, EVP_EINVAL, "evp_mask_from_noise: null pointer");
+  EVP_CHECK_ARG(noise && (ids_keep || len_keep == 0) && mask && ids_restore, EVP_EINVAL, "evp_mask_from_noise: null pointer");
   EVP_CHECK_ARG(B > 0 && L > 0 && L <= 4096 && len_keep >= 0 && len_keep <= L, EVP_ESHAPE,
                 "evp_mask_from_noise: need 0<L<=4096, 0<=len_keep<=L (B=%d L=%d keep=%d)", B, L, len_keep);
   hipLaunchKernelGGL(mask_kernel, dim3(B), dim3(256), (size_t)L * sizeof(float), (hipStream_t)stream, noise, L, len_keep,

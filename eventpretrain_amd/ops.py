@@ -50,7 +50,7 @@ def _chk(t, dtype=None):
 # ----------------------------------------------------------------------------------------------------- raw calls
 def gemm(a, b, out, *, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, bias=None, act=ACT_NONE,
          aux=None, residual=None, alpha=1.0, accumulate=False, batch=(1, 1), stride_a=(0, 0), stride_b=(0, 0),
-         stride_c=(0, 0), a_off=0, b_off=0, c_off=0, tile=0):
+         stride_c=(0, 0), a_off=0, b_off=0, c_off=0, tile=0, splitk=0):
     """out = epilogue(alpha * A . B^T); offsets/strides in ELEMENTS. See include/evtpretrain.h (evp_gemm)."""
     if not (a.is_cuda and b.is_cuda and out.is_cuda):
         raise _lib.EvpError("gemm operands must be in device memory; eventpretrain_amd has no CPU path")
@@ -81,6 +81,7 @@ def gemm(a, b, out, *, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None
     d.ldres = d.ldc
     d.accumulate = int(accumulate)
     d.tile = int(tile)
+    d.splitk = int(splitk)
     call("evp_gemm", C.byref(d), stream_ptr())
     return out
 

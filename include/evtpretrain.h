@@ -87,6 +87,7 @@ typedef struct {
   const float *residual; int64_t ldres; /* batch strides = C's */
   int accumulate;
   int tile;                             /* 0 auto, 1 = 128x128, 2 = 64x64 */
+  int splitk;                           /* 0 auto, n = cut K into n slices summed with f32 atomics (plain f32 C only) */
 } evp_gemm_desc;
 int evp_gemm(const evp_gemm_desc *d, void *stream);
 

@@ -40,7 +40,9 @@ def test_layouts_exact_on_integers(ta, tb, dtype, tile):
     from eventpretrain_amd import ops
     gen = torch.Generator().manual_seed(3)
     for (M, N, K) in [(128, 128, 64), (200, 136, 96), (64, 64, 32), (16, 8, 8), (130, 72, 200), (257, 264, 72)]:
-        a, b, al, bl = _mk(M, N, K, ta, tb, dtype, gen, ints=True)
+        lda_pad = (-K) % 8 if not ta else (-M) % 8
+        ldb_pad = (-K) % 8 if not tb else (-N) % 8
+        a, b, al, bl = _mk(M, N, K, ta, tb, dtype, gen, ints=True, lda_pad=lda_pad, ldb_pad=ldb_pad)
         out = torch.empty(M, N, dtype=torch.float32).cuda()
         ops.gemm(a.cuda(), b.cuda(), out, M=M, N=N, K=K, trans_a=ta, trans_b=tb, lda=a.shape[1], ldb=b.shape[1], tile=tile)
         ref = (al @ bl.t()).float()
@@ -99,10 +101,17 @@ def test_epilogues(dtype):
     h = torch.randn(M, N, generator=gen)
     hd = h.double().requires_grad_(True)
     torch.nn.functional.gelu(hd).sum().backward()
-    ops.gemm(a.cuda(), b.cuda(), out, M=M, N=N, K=K, act=ACT_DGELU, aux=h.cuda())
+    bt = b.t().contiguous()          # activation backward is built for the dgrad layout (transB)
+    ops.gemm(a.cuda(), bt.cuda(), out, M=M, N=N, K=K, trans_b=True, act=ACT_DGELU, aux=h.cuda())
     assert close(out, (al @ bl.t()) * hd.grad)
-    ops.gemm(a.cuda(), b.cuda(), out, M=M, N=N, K=K, act=ACT_DRELU, aux=h.cuda())
+    ops.gemm(a.cuda(), bt.cuda(), out, M=M, N=N, K=K, trans_b=True, act=ACT_DRELU, aux=h.cuda())
     assert close(out, (al @ bl.t()) * (h > 0).double())
+    if dtype == torch.bfloat16:
+        hb, ob = h.to(dtype), torch.empty(M, N, dtype=dtype).cuda()
+        ops.gemm(a.cuda(), bt.cuda(), ob, M=M, N=N, K=K, trans_b=True, act=ACT_DGELU, aux=hb.cuda())
+        hd2 = hb.float().double().requires_grad_(True)
+        torch.nn.functional.gelu(hd2).sum().backward()
+        assert close(ob.float(), (al @ bl.t()) * hd2.grad, 2e-2)
     # accumulate
     acc0 = torch.randn(M, N, generator=gen)
     out = acc0.clone().cuda()
@@ -142,6 +151,25 @@ def test_batched_strided(dtype):
              stride_a=(h * Nn * ldp, Nn * ldp), stride_b=(Nn * 3 * Cc, dh), stride_c=(Nn * Cc, dh))
     refo = (p.float().double()[..., :Nn] @ v).permute(0, 2, 1, 3).reshape(B, Nn, Cc)
     assert ((o.cpu().double() - refo).abs() / (refo.abs() + 1.0)).max() <= tol
+
+
+def test_split_k_matches_single_pass():
+    """Weight-gradient shape (few output tiles, long K): split-K with LDS-staged f32 atomics vs one pass."""
+    from eventpretrain_amd import ops
+    gen = torch.Generator().manual_seed(8)
+    for dtype in (torch.bfloat16, torch.float32):
+        M, N, K = 384, 256, 4096 + 40
+        a, b, al, bl = _mk(M, N, K, True, True, dtype, gen)
+        ref = al @ bl.t()
+        for sk in (0, 1, 3, 7):
+            out = torch.full((M, N), 5.0).cuda()
+            ops.gemm(a.cuda(), b.cuda(), out, M=M, N=N, K=K, trans_a=True, trans_b=True, lda=M, ldb=N, splitk=sk, tile=1)
+            scale = (al.abs() @ bl.abs().t())
+            assert ((out.cpu().double() - ref).abs() / scale).max() <= (2e-5 if dtype == torch.float32 else 1e-2), sk
+        acc0 = torch.randn(M, N, generator=gen)
+        out = acc0.clone().cuda()
+        ops.gemm(a.cuda(), b.cuda(), out, M=M, N=N, K=K, trans_a=True, trans_b=True, lda=M, ldb=N, splitk=4, accumulate=True, tile=1)
+        assert ((out.cpu().double() - ref - acc0.double()).abs() / (al.abs() @ bl.abs().t())).max() <= 1e-2
 
 
 def test_argument_errors_raise():

@@ -140,7 +140,9 @@ def test_training_trajectory_matches_reference_trainer():
                     sub_frame=det_normalish(f"train.sub_frame.{s}", (2, 1, 64, 64)), image_name=[f"s{s}"] * 2) for s in range(n)]
     stats = pr_rec_one_epoch(a, m, batches, opt, 0, NativeScalerWithGradNormCount())
     assert np.allclose(losses, d["losses"], rtol=2e-4), (losses, d["losses"])
-    assert stats["lr"] == pytest.approx(d["lrs"][-1], rel=1e-9)
+    ref_stats = jl(d["stats"])            # the dict the reference trainer returned: global averages of the meters
+    assert stats["lr"] == pytest.approx(ref_stats["lr"], rel=1e-9)
+    assert stats["reconstruct_loss"] == pytest.approx(ref_stats["reconstruct_loss"], rel=2e-4)
     params = dict(m.named_parameters())
     for name, ws in zip(jl(d["param_names"]), d["param_wsums"]):
         tol = 5e-4 if name.endswith("attn.qkv.bias") else 2e-5
