@@ -43,6 +43,9 @@ SIGNATURES = {
     "evp_colsum": [_vp, _i, _i64, _i, _i64, _vp, _vp, _vp],
     "evp_attention_fwd": [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i64, _vp, _vp],
     "evp_attention_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i64, _vp, _vp, _vp, _vp],
+    "evp_attention_fused_supported": [_i, _i, _i],
+    "evp_attention_fused_fwd": [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i64, _vp],
+    "evp_attention_fused_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
     "evp_softmax_rows": [_vp, _vp, _i, _i64, _i, _i64, _vp],
     "evp_softmax_rows_bwd": [_vp, _vp, _vp, _i, _i64, _i, _i64, _vp],
     "evp_patchify": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
@@ -66,7 +69,7 @@ SIGNATURES = {
     "evp_abi_version": [],
 }
 _OTHER_RESTYPE = {"evp_last_error": C.c_char_p, "evp_target_arch": C.c_char_p}
-_NO_STATUS = {"evp_layernorm_bwd_nblk", "evp_colsum_nblk", "evp_batchnorm_nblk", "evp_abi_version"}
+_NO_STATUS = {"evp_attention_fused_supported", "evp_layernorm_bwd_nblk", "evp_colsum_nblk", "evp_batchnorm_nblk", "evp_abi_version"}
 
 _lib = None
 

@@ -141,6 +141,38 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, gres=None, x2=None, x3=None, want_lp
     return dx, dx_lp, dgamma, dbeta
 
 
+_use_fused_attention = True
+
+
+def set_fused_attention(flag):
+    """A/B switch: the fused per-head kernels (default) or the batched-GEMM + softmax formulation."""
+    global _use_fused_attention
+    _use_fused_attention = bool(flag)
+
+
+def fused_attention_ok(dtype, N, dh):
+    return _use_fused_attention and bool(call("evp_attention_fused_supported", _code(dtype), int(N), int(dh)))
+
+
+def attention_fused_fwd(qkv, B, N, heads, dh, want_probs=False):
+    """-> (out [B*N, h*dh] bf16, lse [B,h,N] f32, probs [B,h,N,ldp] bf16 | None)."""
+    dev = qkv.device
+    out = torch.empty(B * N, heads * dh, dtype=qkv.dtype, device=dev)
+    lse = torch.empty(B, heads, N, dtype=torch.float32, device=dev)
+    ldp = (N + 7) // 8 * 8
+    probs = torch.empty(B, heads, N, ldp, dtype=qkv.dtype, device=dev) if want_probs else None
+    call("evp_attention_fused_fwd", ptr(_chk(qkv)), B, N, heads, dh, float(dh) ** -0.5, ptr(out), ptr(lse), ptr(probs), ldp,
+         stream_ptr())
+    return out, lse, probs
+
+
+def attention_fused_bwd(qkv, out, dout, lse, B, N, heads, dh):
+    dqkv = torch.empty_like(qkv)
+    call("evp_attention_fused_bwd", ptr(qkv), ptr(out), ptr(_chk(dout)), ptr(lse), B, N, heads, dh, float(dh) ** -0.5, ptr(dqkv),
+         stream_ptr())
+    return dqkv
+
+
 def attention_fwd(qkv, B, N, heads, dh):
     """qkv [B*N, 3*h*dh] (compute dtype) -> (probs [B,h,N,ldp], out [B*N, h*dh])."""
     ldp = (N + 7) // 8 * 8
@@ -212,7 +244,12 @@ class ViTBlockFn(torch.autograd.Function):
         ln1, mean1, rstd1 = layernorm_fwd(x2d, n1w, n1b, eps, T)
         qkv = torch.empty(M, 3 * D, dtype=T, device=dev)
         gemm(ln1, wq, qkv, M=M, N=3 * D, K=D, bias=qkvb)
-        probs, att = attention_fwd(qkv, B, N, heads, dh)
+        fused = fused_attention_ok(T, N, dh)
+        if fused:
+            att, stat, probs = attention_fused_fwd(qkv, B, N, heads, dh, want_probs=want_attn)   # stat = log-sum-exp
+        else:
+            probs, att = attention_fwd(qkv, B, N, heads, dh)
+            stat = probs
         x1 = torch.empty(M, D, dtype=torch.float32, device=dev)
         gemm(att, wp, x1, M=M, N=D, K=D, bias=pb, residual=x2d)
         ln2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, eps, T)
@@ -222,9 +259,10 @@ class ViTBlockFn(torch.autograd.Function):
         gemm(ln2, w1, h_act, M=M, N=Hd, K=D, bias=f1b, act=ACT_GELU, aux=h_pre)
         x2 = torch.empty(M, D, dtype=torch.float32, device=dev)
         gemm(h_act, w2, x2, M=M, N=D, K=Hd, bias=f2b, residual=x1)
-        ctx.save_for_backward(x2d, n1w, n2w, mean1, rstd1, ln1, qkv, probs, att, x1, mean2, rstd2, ln2, h_pre, h_act,
+        ctx.save_for_backward(x2d, n1w, n2w, mean1, rstd1, ln1, qkv, stat, att, x1, mean2, rstd2, ln2, h_pre, h_act,
                               wq, wp, w1, w2)
         ctx.dims = (B, N, D, heads, dh, Hd)
+        ctx.fused = fused
         out = x2.view(B, N, D)
         if want_attn:
             attn = probs[..., :N]
@@ -234,7 +272,7 @@ class ViTBlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g2, *_):
-        (x2d, n1w, n2w, mean1, rstd1, ln1, qkv, probs, att, x1, mean2, rstd2, ln2, h_pre, h_act, wq, wp, w1, w2) = \
+        (x2d, n1w, n2w, mean1, rstd1, ln1, qkv, stat, att, x1, mean2, rstd2, ln2, h_pre, h_act, wq, wp, w1, w2) = \
             ctx.saved_tensors
         B, N, D, heads, dh, Hd = ctx.dims
         M = B * N
@@ -260,7 +298,10 @@ class ViTBlockFn(torch.autograd.Function):
         dwp = _wgrad(g1_lp, att, D, D, M)
         datt = torch.empty(M, D, dtype=T, device=dev)
         gemm(g1_lp, wp, datt, M=M, N=D, K=D, trans_b=True, ldb=D)
-        dqkv = attention_bwd(qkv, probs, datt, B, N, heads, dh)
+        if ctx.fused:
+            dqkv = attention_fused_bwd(qkv, att, datt, stat, B, N, heads, dh)
+        else:
+            dqkv = attention_bwd(qkv, stat, datt, B, N, heads, dh)
         dbq = colsum(dqkv)
         dwq = _wgrad(dqkv, ln1, 3 * D, D, M)
         dln1 = torch.empty(M, D, dtype=T, device=dev)

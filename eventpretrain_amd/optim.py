@@ -83,7 +83,9 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def refresh(self, advance=True):
         """Host side of a step: (re)build tables if the set of parameters with gradients changed, bump the step
-        counter, stage gradient pointers / lr / weight decay / bias corrections into device tables (async H2D)."""
+        counter, stage gradient pointers / lr / weight decay / bias corrections into pinned host tables and enqueue
+        their (tiny) H2D copies. Called inside a HIP-graph capture, the copies become graph nodes that re-read the
+        pinned tables at every replay; `stage_scalars()` then updates lr / bias corrections before each replay."""
         act = self._active()
         if not act:
             return False
@@ -91,27 +93,35 @@ class FusedAdamW(torch.optim.Optimizer):
         if sig != self._sig:
             self._tabs, self._sig = self._build(act), sig
         T = self._tabs
-        if advance:
-            self._step += 1
-        b1, b2 = self.param_groups[0]["betas"]
+        self._act = act
         for i, (gi, p) in enumerate(act):
-            g = self.param_groups[gi]
             if p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
                 raise _lib.EvpError("FusedAdamW: gradients must be contiguous float32")
             T["h_grads"][i] = p.grad.data_ptr()
             sh = getattr(p, "_evp_lp", None)
             T["h_lp"][i] = sh.data_ptr() if (sh is not None and getattr(p, "_evp_lp_version", -1) == p._version) else 0
+        self.stage_scalars(advance)
+        for k in ("grads", "lp", "wd", "lr", "hyper"):
+            T[k].copy_(T["h_" + k], non_blocking=True)
+        return True
+
+    def stage_scalars(self, advance=True):
+        """Write this step's lr / weight decay / bias corrections into the pinned host tables (no device work)."""
+        T = self._tabs
+        if advance:
+            self._step += 1
+        b1, b2 = self.param_groups[0]["betas"]
+        for i, (gi, p) in enumerate(self._act):
+            g = self.param_groups[gi]
             T["h_wd"][i] = g["weight_decay"]
             T["h_lr"][i] = g["lr"]
-            self.state[p]["step"] += 1 if advance else 0
+            if advance:
+                self.state[p]["step"] += 1
         step = max(self._step, 1)
         T["h_hyper"][0] = 1.0 - b1 ** step
         T["h_hyper"][1] = math.sqrt(1.0 - b2 ** step)
         T["h_hyper"][2] = self.grad_scale
         T["h_hyper"][3] = 1.0
-        for k in ("grads", "lp", "wd", "lr", "hyper"):
-            T[k].copy_(T["h_" + k], non_blocking=True)
-        return True
 
     def launch(self):
         """Device side of a step (graph-capturable): one evp_adamw_multi over all chunks."""

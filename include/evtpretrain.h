@@ -120,6 +120,16 @@ int evp_attention_fwd(const void *qkv, int dtype, int B, int N, int heads, int d
  * logits are kept in f32 between the GEMM and the softmax in both precisions); ds_ws dtype [B,h,N,ldp]. */
 int evp_attention_bwd(const void *qkv, const void *probs, const void *dout, int dtype, int B, int N, int heads, int dh,
                       float scale, int64_t ldp, float *dp_ws, void *ds_ws, void *dqkv, void *stream);
+/* Fused form of the same core for the shapes of this path (bf16, N <= 224 tokens, dh in {32,64}): one workgroup per
+ * (batch, head), scores stay in registers, softmax statistics are saved as the per-row log-sum-exp
+ * (lse float32 [B,h,N]) instead of the N x N probabilities; probs (bf16 [B,h,N,ldp], may be NULL) is written only
+ * when the caller needs the attention map (dense branch, vit.py:144). The backward recomputes the probabilities from
+ * qkv and lse; out is the forward output (needed for rowsum(dout*out)). */
+int evp_attention_fused_supported(int dtype, int N, int dh);
+int evp_attention_fused_fwd(const void *qkv, int B, int N, int heads, int dh, float scale, void *out, float *lse,
+                            void *probs, int64_t ldp, void *stream);
+int evp_attention_fused_bwd(const void *qkv, const void *out, const void *dout, const float *lse, int B, int N,
+                            int heads, int dh, float scale, void *dqkv, void *stream);
 /* p[r,:] = softmax(s[r,:n_valid]) with s float32 [rows,ld], p dtype [rows,ld]; pad columns [n_valid,ld) = 0. */
 int evp_softmax_rows(const float *s, void *p, int dtype, int64_t rows, int n_valid, int64_t ld, void *stream);
 /* ds = p * (dp - rowsum(p*dp)); dp float32, p/ds dtype; pad columns = 0. */

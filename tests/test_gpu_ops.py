@@ -95,6 +95,41 @@ def test_attention_core_fwd_bwd(dtype, B, N, h, dh):
     assert err <= (1e-4 if dtype == torch.float32 else 3e-2), err
 
 
+@pytest.mark.parametrize("B,N,h,dh", [(2, 16, 3, 64), (3, 98, 4, 64), (2, 196, 4, 32), (1, 49, 2, 32), (2, 224, 2, 64), (2, 1, 1, 32),
+                                      (64, 98, 12, 64)])
+def test_fused_attention_fwd_bwd(B, N, h, dh):
+    """Fused per-head kernels (bf16) against float64 attention on the bf16-rounded inputs, and against the unfused
+    HIP formulation."""
+    from eventpretrain_amd import ops
+    g = _g(1000 + N)
+    Cc = h * dh
+    qkv = (torch.randn(B * N, 3 * Cc, generator=g) * 0.8).bfloat16()
+    dout = torch.randn(B * N, Cc, generator=g).bfloat16()
+    qd = qkv.float().double().requires_grad_(True)
+    q, k, v = qd.view(B, N, 3, h, dh).permute(2, 0, 3, 1, 4)
+    sc = q @ k.transpose(-1, -2) * dh ** -0.5
+    p = torch.softmax(sc, -1)
+    o = (p @ v).transpose(1, 2).reshape(B * N, Cc)
+    o.backward(dout.float().double())
+    assert ops.fused_attention_ok(torch.bfloat16, N, dh)
+    out, lse, probs = ops.attention_fused_fwd(qkv.cuda(), B, N, h, dh, want_probs=True)
+    assert torch.allclose(lse.cpu().double(), torch.logsumexp(sc, -1).detach(), atol=1e-3, rtol=1e-4)
+    assert torch.allclose(probs[..., :N].float().cpu().double(), p.detach(), atol=1e-2, rtol=2e-2)
+    assert (probs[..., N:] == 0).all()
+    assert torch.allclose(out.float().cpu().double(), o.detach(), atol=3e-2, rtol=3e-2)
+    # the backward takes the forward's own (bf16) output, as the training step does
+    dqkv = ops.attention_fused_bwd(qkv.cuda(), out, dout.cuda(), lse, B, N, h, dh)
+    ref = qd.grad
+    err = (dqkv.float().cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 3e-2, err
+    # the three slices separately (a swapped dK/dV or a transposed tile would pass a max-norm check of the whole)
+    got = dqkv.float().cpu().double().view(B, N, 3, h, dh)
+    want = ref.view(B, N, 3, h, dh)
+    for i in range(3):
+        e = (got[:, :, i] - want[:, :, i]).abs().max().item() / max(want[:, :, i].abs().max().item(), 1e-6)
+        assert e <= 4e-2 or N == 1, (i, e)
+
+
 def test_patchify_embed_post_unshuffle_loss():
     from eventpretrain_amd import ops
     from oracle import model_oracle as mo
