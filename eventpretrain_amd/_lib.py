@@ -36,10 +36,13 @@ SIGNATURES = {
     "evp_mask_from_noise": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "evp_density_noise": [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "evp_gemm": [C.POINTER(GemmDesc), _vp],
+    "evp_gemm_grouped_tn_bf16": [_vp, _vp, _i, _vp],
+    "evp_gemm_set_variant": [_i],
     "evp_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp, _i, _vp, _vp, _vp],
     "evp_layernorm_bwd_nblk": [_i64],
     "evp_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "evp_colsum_nblk": [_i64],
+    "evp_colsum_grouped": [_vp, _vp, _i, _vp],
     "evp_colsum": [_vp, _i, _i64, _i, _i64, _vp, _vp, _vp],
     "evp_attention_fwd": [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i64, _vp, _vp],
     "evp_attention_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i64, _vp, _vp, _vp, _vp],
@@ -69,7 +72,7 @@ SIGNATURES = {
     "evp_abi_version": [],
 }
 _OTHER_RESTYPE = {"evp_last_error": C.c_char_p, "evp_target_arch": C.c_char_p}
-_NO_STATUS = {"evp_attention_fused_supported", "evp_layernorm_bwd_nblk", "evp_colsum_nblk", "evp_batchnorm_nblk", "evp_abi_version"}
+_NO_STATUS = {"evp_gemm_set_variant", "evp_attention_fused_supported", "evp_layernorm_bwd_nblk", "evp_colsum_nblk", "evp_batchnorm_nblk", "evp_abi_version"}
 
 _lib = None
 

@@ -17,6 +17,8 @@ typedef __attribute__((ext_vector_type(4))) short i16x4;
 typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+static int g_gemm_variant = 1;
+
 namespace {
 
 struct GemmParams {
@@ -120,6 +122,40 @@ template <typename T, bool TR, int ROWS, int NT> struct Stage {
           }
         }
       }
+    }
+  }
+};
+
+// ---- global -> LDS direct (LDS-DMA) staging of one bf16 operand tile -------------------------------------------
+// One wave-instruction (buffer_load_dwordx4 ... lds) lands 64 x 16 B = 1 KiB contiguously in LDS, so the LDS image is
+// written linearly and the XOR swizzle is applied to the per-lane SOURCE address instead (the same involution the
+// fragment reads use). A 16 KiB tile image = 16 such pieces, 4 per wave (256 threads).
+typedef __attribute__((address_space(3))) void lds_void;
+template <bool TR, int ROWS, int NT> struct GStage {
+  static constexpr int PIECES = Img<bf16_t, TR, ROWS>::BYTES / 1024;   // wave-instructions per tile
+  static constexpr int PER_WAVE = PIECES / (NT / 64);
+  __device__ __forceinline__ static void issue(__amdgpu_buffer_rsrc_t rs, int ld, int row0, int k0, int nrows, int K, char *img,
+                                               int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int piece = wave * PER_WAVE + i;
+      int gr, gk;
+      if (!TR) {                       // 128-byte rows: 8 rows per piece, 8 chunks per row
+        const int row = piece * 8 + (lane >> 3), pos = lane & 7;
+        gr = row0 + row;
+        gk = k0 + ((pos ^ (row & 7)) << 3);
+      } else if (ROWS == 128) {        // 256-byte k-rows: 4 per piece, 16 chunks per row
+        const int k = piece * 4 + (lane >> 4), pos = lane & 15;
+        gk = k0 + k;
+        gr = row0 + ((pos ^ (((k & 3) << 2) | ((k >> 2) & 3))) << 3);
+      } else {                         // 128-byte k-rows (64-wide tile): 8 per piece, 8 chunks per row
+        const int k = piece * 8 + (lane >> 3), pos = lane & 7;
+        gk = k0 + k;
+        gr = row0 + ((pos ^ ((((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1)) << 3);
+      }
+      const bool ok = gr < nrows && gk < K;
+      const int off = ok ? (TR ? gk * ld + gr : gr * ld + gk) * 2 : (int)0x80000000;   // out of range -> zeros
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)(img + piece * 1024), 16, off, 0, 0, 0);
     }
   }
 };
@@ -280,9 +316,9 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[MI][NI], const GemmP
   }
 }
 
-// ---- the kernel --------------------------------------------------------------------------------------------
-template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmParams p) {
+// ---- the tile body (shared by the plain and the grouped kernel) ------------------------------------------------
+template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN, bool GLDS, int STAGES>
+__device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m, const int tile_n, const int bz, const int kslice) {
   constexpr int NT = WM * WN * 64;
   constexpr int BK = Cfg<T>::BK, KSTEP = Cfg<T>::KSTEP;
   constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
@@ -291,25 +327,8 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  // Block -> tile map (speed only, never correctness): (1) blocks b and b+8 share an XCD, so renumber to give every
-  // XCD a contiguous run of tiles (bijective for any grid size); (2) inside the run walk GROUP_M x tiles_n panels,
-  // M fastest, so the ~64 blocks an XCD runs at once share 8 A panels and 8 B panels that fit its 4 MiB L2.
-  int tile_m, tile_n;
-  {
-    const int nblk = gridDim.x, bid = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    constexpr int GROUP_M = 8;
-    const int tiles_n = nblk / p.tiles_m;
-    const int per_group = GROUP_M * tiles_n;
-    const int gid = t / per_group, first_m = gid * GROUP_M;
-    const int gsz = (p.tiles_m - first_m) < GROUP_M ? (p.tiles_m - first_m) : GROUP_M;
-    const int in_g = t - gid * per_group;
-    tile_m = first_m + in_g % gsz;
-    tile_n = in_g / gsz;
-  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int b0 = blockIdx.z / p.batch1, b1 = blockIdx.z % p.batch1;
+  const int b0 = bz / p.batch1, b1 = bz % p.batch1;
   const T *A = reinterpret_cast<const T *>(p.A) + b0 * p.sA0 + b1 * p.sA1;
   const T *B = reinterpret_cast<const T *>(p.B) + b0 * p.sB0 + b1 * p.sB1;
   // wave-uniform buffer descriptors (kernel arguments and blockIdx only): hardware bounds check, 32-bit offsets
@@ -323,27 +342,11 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  Stage<T, TA, BM, NT> sa;
-  Stage<T, TB, BN, NT> sb;
-  const int kbeg = blockIdx.y * p.k_per_split;
+  const int kbeg = kslice * p.k_per_split;
   const int kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
   const int ntiles = (kend - kbeg + BK - 1) / BK;
 
-  sa.load(rsA, lda, m0, kbeg, p.M, kend, tid);
-  sb.load(rsB, ldb, n0, kbeg, p.N, kend, tid);
-  sa.store(smem, tid);
-  sb.store(smem + A_BYTES, tid);
-  __syncthreads();
-
-  for (int t = 0; t < ntiles; ++t) {
-    char *cur = smem + (t & 1) * (A_BYTES + B_BYTES);
-    char *nxt = smem + ((t + 1) & 1) * (A_BYTES + B_BYTES);
-    const bool more = (t + 1) < ntiles;
-    if (more) {
-      sa.load(rsA, lda, m0, kbeg + (t + 1) * BK, p.M, kend, tid);
-      sb.load(rsB, ldb, n0, kbeg + (t + 1) * BK, p.N, kend, tid);
-    }
-    const char *ia = cur, *ib = cur + A_BYTES;
+  auto compute_tile = [&](const char *ia, const char *ib) {
 #pragma unroll
     for (int ks = 0; ks < BK / KSTEP; ++ks) {
       if constexpr (sizeof(T) == 2) {
@@ -370,17 +373,95 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmParams p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);
       }
     }
-    if (more) {
-      sa.store(nxt, tid);
-      sb.store(nxt + A_BYTES, tid);
+  };
+
+  if constexpr (GLDS) {
+    // LDS-DMA pipeline: tile t+1 streams into the other stage while tile t is multiplied; a counted vmcnt leaves
+    // the newest tile's pieces in flight across the raw barrier (a __syncthreads() would drain them).
+    using GA = GStage<TA, BM, NT>;
+    using GB = GStage<TB, BN, NT>;
+    constexpr int INFLIGHT = GA::PER_WAVE + GB::PER_WAVE;   // LDS-DMA pieces per wave and tile
+    static_assert(INFLIGHT == 8 || INFLIGHT == 6 || INFLIGHT == 4, "add the vmcnt literal for this tile shape");
+    auto wait_all_but_newest_tile = [] {
+      if constexpr (INFLIGHT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (INFLIGHT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    };
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    if constexpr (STAGES == 2) {
+      GA::issue(rsA, lda, m0, kbeg, p.M, kend, smem, wave, lane);
+      GB::issue(rsB, ldb, n0, kbeg, p.N, kend, smem + A_BYTES, wave, lane);
+      for (int t = 0; t < ntiles; ++t) {
+        char *cur = smem + (t & 1) * STAGE_BYTES;
+        char *nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
+        if (t + 1 < ntiles) {
+          GA::issue(rsA, lda, m0, kbeg + (t + 1) * BK, p.M, kend, nxt, wave, lane);
+          GB::issue(rsB, ldb, n0, kbeg + (t + 1) * BK, p.N, kend, nxt + A_BYTES, wave, lane);
+          wait_all_but_newest_tile();
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        compute_tile(cur, cur + A_BYTES);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    } else {
+      // 3-stage ring, ONE barrier per K tile, two tiles of LDS-DMA in flight: at iteration t every wave first waits
+      // for its own pieces of tile t (leaving tile t+1 in flight), the barrier then proves (a) tile t is complete and
+      // (b) every wave has finished reading tile t-1, whose stage is the one tile t+2 is issued into right after.
+      GA::issue(rsA, lda, m0, kbeg, p.M, kend, smem, wave, lane);
+      GB::issue(rsB, ldb, n0, kbeg, p.N, kend, smem + A_BYTES, wave, lane);
+      if (ntiles > 1) {
+        GA::issue(rsA, lda, m0, kbeg + BK, p.M, kend, smem + STAGE_BYTES, wave, lane);
+        GB::issue(rsB, ldb, n0, kbeg + BK, p.N, kend, smem + STAGE_BYTES + A_BYTES, wave, lane);
+      }
+      int st = 0;                     // stage of tile t
+      for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) wait_all_but_newest_tile();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < ntiles) {
+          const int s2 = st == 0 ? 2 : st - 1;        // (t + 2) % 3
+          GA::issue(rsA, lda, m0, kbeg + (t + 2) * BK, p.M, kend, smem + s2 * STAGE_BYTES, wave, lane);
+          GB::issue(rsB, ldb, n0, kbeg + (t + 2) * BK, p.N, kend, smem + s2 * STAGE_BYTES + A_BYTES, wave, lane);
+        }
+        const char *cur = smem + st * STAGE_BYTES;
+        compute_tile(cur, cur + A_BYTES);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        st = st == 2 ? 0 : st + 1;
+      }
+      __builtin_amdgcn_s_barrier();   // the split-K epilogue reuses the ring as scratch
     }
+  } else {
+    Stage<T, TA, BM, NT> sa;
+    Stage<T, TB, BN, NT> sb;
+    sa.load(rsA, lda, m0, kbeg, p.M, kend, tid);
+    sb.load(rsB, ldb, n0, kbeg, p.N, kend, tid);
+    sa.store(smem, tid);
+    sb.store(smem + A_BYTES, tid);
     __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+      char *cur = smem + (t & 1) * (A_BYTES + B_BYTES);
+      char *nxt = smem + ((t + 1) & 1) * (A_BYTES + B_BYTES);
+      const bool more = (t + 1) < ntiles;
+      if (more) {
+        sa.load(rsA, lda, m0, kbeg + (t + 1) * BK, p.M, kend, tid);
+        sb.load(rsB, ldb, n0, kbeg + (t + 1) * BK, p.N, kend, tid);
+      }
+      compute_tile(cur, cur + A_BYTES);
+      if (more) {
+        sa.store(nxt, tid);
+        sb.store(nxt + A_BYTES, tid);
+      }
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4
   const int64_t coff = b0 * p.sC0 + b1 * p.sC1;
   const int li = lane & 15, lg = lane >> 4;
-  if constexpr (2 * (A_BYTES + B_BYTES) >= BM * BN * 4 && EPI == 0 && sizeof(TC) == 4) {
+  if constexpr (STAGES * (A_BYTES + B_BYTES) >= BM * BN * 4 && EPI == 0 && sizeof(TC) == 4) {
     if (p.splitk > 1) {
       // split-K: stage the f32 tile through LDS so that every atomic wave-instruction adds 256 contiguous bytes of
       // one output row (the full-rate shape for global_atomic_add_f32, MI355X_MICROARCH.md "Global float atomics")
@@ -406,7 +487,57 @@ __global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmParams p) {
   epilogue<TC, EPI, MI, NI>(acc, p, coff, m0 + wm * WTM + li, n0 + wn * WTN + lg * 4, fast);
 }
 
-template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN>
+// Block -> tile map (speed only, never correctness): (1) blocks b and b+8 share an XCD, so renumber to give every XCD
+// a contiguous run of tiles (bijective for any grid size); (2) inside the run walk GROUP_M x tiles_n panels, M
+// fastest, so the ~64 blocks an XCD runs at once share 8 A panels and 8 B panels that fit its 4 MiB L2.
+__device__ __forceinline__ void map_tile(int nblk, int bid, int tiles_m, int &tile_m, int &tile_n) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  constexpr int GROUP_M = 8;
+  const int tiles_n = nblk / tiles_m;
+  const int per_group = GROUP_M * tiles_n;
+  const int gid = t / per_group, first_m = gid * GROUP_M;
+  const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+  const int in_g = t - gid * per_group;
+  tile_m = first_m + in_g % gsz;
+  tile_n = in_g / gsz;
+}
+
+template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN, bool GLDS, int STAGES>
+__global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmParams p) {
+  int tile_m, tile_n;
+  map_tile(gridDim.x, blockIdx.x, p.tiles_m, tile_m, tile_n);
+  gemm_body<T, TC, EPI, TA, TB, BM, BN, WM, WN, GLDS, STAGES>(p, tile_m, tile_n, blockIdx.z, blockIdx.y);
+}
+
+// ---- grouped weight-gradient GEMM: many independent (dY^T . X) problems in ONE launch ------------------------------
+// problem g: C_g[M_g, N_g] (f32) = A_g^T . B_g with A_g stored [K_g][M_g], B_g stored [K_g][N_g] (bf16). Work item =
+// one 128x128 output tile of one problem; items are listed largest-K first so the long tiles start early.
+struct GroupedProblem {
+  const void *A, *B;
+  void *C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  int accumulate, pad;
+};
+struct GroupedItem { int prob, tile_m, tile_n, pad; };
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_grouped_tn_kernel(const GroupedProblem *__restrict__ probs, const GroupedItem *__restrict__ items) {
+  const GroupedItem it = items[blockIdx.x];
+  const GroupedProblem g = probs[it.prob];
+  GemmParams p;
+  p.M = g.M; p.N = g.N; p.K = g.K;
+  p.A = g.A; p.lda = g.lda; p.sA0 = 0; p.sA1 = 0;
+  p.B = g.B; p.ldb = g.ldb; p.sB0 = 0; p.sB1 = 0;
+  p.C = g.C; p.c_dtype = EVP_F32; p.ldc = g.ldc; p.sC0 = 0; p.sC1 = 0;
+  p.batch1 = 1; p.alpha = 1.0f; p.bias = nullptr; p.act = EVP_ACT_NONE; p.aux = nullptr; p.ldaux = 0;
+  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1;
+  p.k_per_split = (g.K + 63) / 64 * 64;
+  gemm_body<bf16_t, float, 0, true, true, BM, BN, 2, 2, true, 2>(p, it.tile_m, it.tile_n, 0, 0);
+}
+
+template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN, bool GLDS, int STAGES>
 int launch(const evp_gemm_desc *d, hipStream_t s) {
   GemmParams p;
   p.M = d->M; p.N = d->N; p.K = d->K;
@@ -445,8 +576,8 @@ int launch(const evp_gemm_desc *d, hipStream_t s) {
     hipError_t e = hipMemset2DAsync(d->C, (size_t)d->ldc * 4, 0, (size_t)d->N * 4, (size_t)d->M, s);
     if (e != hipSuccess) { evp_set_error("evp_gemm: memset for split-K failed: %s", hipGetErrorString(e)); return EVP_ELAUNCH; }
   }
-  constexpr int smem = 2 * (Img<T, TA, BM>::BYTES + Img<T, TB, BN>::BYTES);
-  auto k = gemm_kernel<T, TC, EPI, TA, TB, BM, BN, WM, WN>;
+  constexpr int smem = STAGES * (Img<T, TA, BM>::BYTES + Img<T, TB, BN>::BYTES);
+  auto k = gemm_kernel<T, TC, EPI, TA, TB, BM, BN, WM, WN, GLDS, STAGES>;
   static bool attr_done = false;  // one flag per instantiation
   if (!attr_done) {
     if (smem > 48 * 1024) {
@@ -466,15 +597,27 @@ int launch(const evp_gemm_desc *d, hipStream_t s) {
 
 template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(const evp_gemm_desc *d, hipStream_t s) {
   int tile = d->tile;
+  const int64_t nb = (int64_t)(d->batch0 > 0 ? d->batch0 : 1) * (d->batch1 > 0 ? d->batch1 : 1);
   if (tile == 0) {
-    const int64_t big = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * (d->batch0 > 0 ? d->batch0 : 1) *
-                        (d->batch1 > 0 ? d->batch1 : 1);
+    const int64_t t128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * nb;
+    const int64_t t256 = (int64_t)((d->M + 255) / 256) * ((d->N + 127) / 128) * nb;
     const bool splittable = d->c_dtype == EVP_F32 && !d->bias && d->act == EVP_ACT_NONE && !d->residual && !d->aux &&
-                            d->batch0 <= 1 && d->batch1 <= 1 && d->K >= 2048;
-    tile = (d->M >= 128 && d->N >= 128 && (big >= 192 || splittable)) ? 1 : 2;
+                            nb == 1 && d->K >= 2048;
+    // the 256x128 / 3-stage ring variant (tile 3) measured slower than 128x128 at this path's shapes (1 block per CU);
+    // it stays selectable explicitly for A/B runs
+    (void)t256;
+    tile = (d->M >= 128 && d->N >= 128 && (t128 >= 192 || splittable)) ? 1 : 2;
   }
-  if (tile == 1) return launch<T, TC, EPI, TA, TB, 128, 128, 2, 2>(d, s);
-  return launch<T, TC, EPI, TA, TB, 64, 64, 2, 2>(d, s);
+  // bf16: LDS-DMA staging (variant 1, default) or register staging (variant 2, kept for A/B runs); f32: registers
+  if constexpr (sizeof(T) == 2) {
+    if (g_gemm_variant != 2) {
+      if (tile == 3) return launch<T, TC, EPI, TA, TB, 256, 128, 4, 2, true, 3>(d, s);   // 8 waves, 144 KiB ring
+      if (tile == 1) return launch<T, TC, EPI, TA, TB, 128, 128, 2, 2, true, 2>(d, s);
+      return launch<T, TC, EPI, TA, TB, 64, 64, 2, 2, true, 2>(d, s);
+    }
+  }
+  if (tile == 1 || tile == 3) return launch<T, TC, EPI, TA, TB, 128, 128, 2, 2, false, 2>(d, s);
+  return launch<T, TC, EPI, TA, TB, 64, 64, 2, 2, false, 2>(d, s);
 }
 
 // Layout x epilogue combinations that exist on this path (everything else is refused, not silently emulated):
@@ -502,6 +645,28 @@ template <typename T> int pick_ctype(const evp_gemm_desc *d, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int evp_gemm_grouped_tn_bf16(const void *problems, const void *items, int n_items, void *stream) {
+  EVP_CHECK_ARG(problems && items && n_items > 0, EVP_EINVAL, "evp_gemm_grouped_tn_bf16: bad argument");
+  auto k = gemm_grouped_tn_kernel<128, 128>;
+  constexpr int smem = 2 * (Img<bf16_t, true, 128>::BYTES + Img<bf16_t, true, 128>::BYTES);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_gemm_grouped_tn_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)n_items), dim3(256), smem, (hipStream_t)stream,
+                     reinterpret_cast<const GroupedProblem *>(problems), reinterpret_cast<const GroupedItem *>(items));
+  EVP_CHECK_LAUNCH("evp_gemm_grouped_tn_bf16");
+  return EVP_OK;
+}
+
+extern "C" int evp_gemm_set_variant(int v) {
+  const int old = g_gemm_variant;
+  if (v == 1 || v == 2) g_gemm_variant = v;
+  return old;
+}
 
 extern "C" int evp_gemm(const evp_gemm_desc *d, void *stream) {
   EVP_CHECK_ARG(d != nullptr, EVP_EINVAL, "evp_gemm: null descriptor");

@@ -266,6 +266,55 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T *x, int64_t M, int 
   }
 }
 
+// grouped form: many independent column sums in one launch (the deferred bias gradients of a whole step).
+struct ColsumProblem { const void *x; float *out; long long M; int N, ld, dtype, pad; };
+struct ColsumItem { int prob, col_block, row_slab, pad; };
+__global__ __launch_bounds__(256) void colsum_grouped_kernel(const ColsumProblem *__restrict__ probs, const ColsumItem *__restrict__ items) {
+  __shared__ float sh[16][129];
+  const ColsumItem it = items[blockIdx.x];
+  const ColsumProblem g = probs[it.prob];
+  const int cc = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int n = it.col_block * 128 + cc * 8;
+  const int64_t r0 = (int64_t)it.row_slab * CS_ROWS, r1 = r0 + CS_ROWS < g.M ? r0 + CS_ROWS : g.M;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (n < g.N) {
+    const bool full = n + 7 < g.N;
+    for (int64_t r = r0 + rl; r < r1; r += 16) {
+      if (g.dtype == EVP_BF16) {
+        const bf16_t *p = (const bf16_t *)g.x + r * g.ld + n;
+        if (full) {
+          const uint4 u = *reinterpret_cast<const uint4 *>(p);
+          const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[2 * e] += __uint_as_float(w[e] << 16);
+            acc[2 * e + 1] += __uint_as_float(w[e] & 0xFFFF0000u);
+          }
+        } else
+          for (int e = 0; e < 8 && n + e < g.N; ++e) acc[e] += bf16_to_f32(p[e]);
+      } else {
+        const float *p = (const float *)g.x + r * g.ld + n;
+        if (full) {
+          const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+          acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+          acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+        } else
+          for (int e = 0; e < 8 && n + e < g.N; ++e) acc[e] += p[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sh[rl][cc * 8 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sh[i][c];
+    if (it.col_block * 128 + c < g.N) atomicAdd(g.out + it.col_block * 128 + c, t);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ patch-embed post-op
 template <int VPL>
 __global__ __launch_bounds__(256) void embed_post_fwd_kernel(const float *y, const float *gamma, const float *beta,
@@ -521,6 +570,14 @@ extern "C" int evp_colsum(const void *x, int x_dtype, int64_t M, int N, int64_t 
   if (x_dtype == EVP_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)x, M, N, ld, out);
   else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float *)x, M, N, ld, out);
   EVP_CHECK_LAUNCH("evp_colsum");
+  return EVP_OK;
+}
+
+extern "C" int evp_colsum_grouped(const void *problems, const void *items, int n_items, void *stream) {
+  EVP_CHECK_ARG(problems && items && n_items > 0, EVP_EINVAL, "evp_colsum_grouped: bad argument");
+  hipLaunchKernelGGL(colsum_grouped_kernel, dim3((unsigned)n_items), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const ColsumProblem *>(problems), reinterpret_cast<const ColsumItem *>(items));
+  EVP_CHECK_LAUNCH("evp_colsum_grouped");
   return EVP_OK;
 }
 

@@ -222,10 +222,147 @@ def add(a, b, c=None):
     return out
 
 
-def _wgrad(dy, x, n_out, k_in, rows):
-    """dW[n_out,k_in] = dy^T x, f32."""
+# ----------------------------------------------------------------------------------------------------- deferred grads
+class _DeferredGrads:
+    """Weight / bias gradients do not feed the backward chain, only the optimizer. In bf16 mode they are therefore
+    queued during backward and computed at its end by ONE grouped GEMM launch (thousands of 128x128 tiles: no split-K,
+    no tail) and ONE grouped column-sum launch (csrc: evp_gemm_grouped_tn_bf16, evp_colsum_grouped). The autograd
+    functions return None for a queued parameter; flush() -- an autograd end-of-backward callback -- writes the
+    result straight into `param.grad` (allocating it, or accumulating into an existing one)."""
+
+    def __init__(self):
+        self.enabled = True
+        self.w, self.b = [], []
+        self.armed = False
+        self._pin = {}
+
+    def arm(self):
+        if not self.armed:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+                self.armed = True
+            except RuntimeError:       # not inside a backward pass: the caller flushes explicitly
+                pass
+
+    def can_defer(self, param):
+        return (self.enabled and _compute_dtype == torch.bfloat16 and isinstance(param, torch.Tensor) and param.is_leaf
+                and param.requires_grad and param.dtype == torch.float32 and param.is_contiguous())
+
+    def wgrad(self, param, dy, x, n_out, k_in, rows):
+        self.w.append((param, dy, x, n_out, k_in, rows))
+        self.arm()
+
+    def colsum(self, param, x2d):
+        self.b.append((param, x2d))
+        self.arm()
+
+    def _stage(self, key, arr, dev):
+        """numpy bytes -> persistent pinned staging -> fresh device tensor (async H2D; capturable in a HIP graph
+        once the pinned buffer exists, i.e. after one eager step)."""
+        raw = torch.from_numpy(arr)
+        n = raw.numel()
+        pin = self._pin.get(key)
+        if pin is None or pin.numel() < n:
+            pin = torch.empty(max(n, 1 << 16), dtype=torch.uint8).pin_memory()
+            self._pin[key] = pin
+        pin[:n].copy_(raw)
+        d = torch.empty(n, dtype=torch.uint8, device=dev)
+        d.copy_(pin[:n], non_blocking=True)
+        return d
+
+    @staticmethod
+    def _target(param):
+        """(grad tensor to write, accumulate flag)"""
+        if param.grad is None:
+            param.grad = torch.empty_like(param, memory_format=torch.contiguous_format)
+            return param.grad, 0
+        if param.grad.dtype != torch.float32 or not param.grad.is_contiguous():
+            raise _lib.EvpError("deferred gradients need contiguous float32 .grad tensors")
+        return param.grad, 1
+
+    def flush(self):
+        import numpy as np
+        self.armed = False
+        w, b, self.w, self.b = self.w, self.b, [], []
+        if w:
+            dev = w[0][1].device
+            probs = np.zeros(len(w), dtype=np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i4"), ("N", "<i4"),
+                                                      ("K", "<i4"), ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4"),
+                                                      ("acc", "<i4"), ("pad", "<i4")]))
+            items = []
+            for i, (param, dy, x, n_out, k_in, rows) in enumerate(w):
+                gt, acc = self._target(param)
+                probs[i] = (dy.data_ptr(), x.data_ptr(), gt.data_ptr(), n_out, k_in, rows, n_out, k_in, k_in, acc, 0)
+                tm, tn = (n_out + 127) // 128, (k_in + 127) // 128
+                t = np.zeros((tn, tm, 4), dtype=np.int32)
+                t[..., 0] = i
+                t[..., 1] = np.arange(tm, dtype=np.int32)[None, :]
+                t[..., 2] = np.arange(tn, dtype=np.int32)[:, None]
+                items.append(t.reshape(-1, 4))
+            items = np.concatenate(items, 0)
+            pt = self._stage("wp", probs.view(np.uint8), dev)
+            it = self._stage("wi", items.view(np.uint8).reshape(-1), dev)
+            call("evp_gemm_grouped_tn_bf16", pt.data_ptr(), it.data_ptr(), int(items.shape[0]), stream_ptr())
+        if b:
+            dev = b[0][1].device
+            probs = np.zeros(len(b), dtype=np.dtype([("x", "<u8"), ("out", "<u8"), ("M", "<i8"), ("N", "<i4"), ("ld", "<i4"),
+                                                      ("dtype", "<i4"), ("pad", "<i4")]))
+            items = []
+            # fresh bias gradients are slices of ONE flat buffer zeroed by one memset (they accumulate with atomics)
+            fresh = [p_ for p_, _ in b if p_.grad is None]
+            if fresh:
+                sizes = [(p_.numel() + 63) // 64 * 64 for p_ in fresh]
+                flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+                o = 0
+                for p_, n_ in zip(fresh, sizes):
+                    p_.grad = flat[o:o + p_.numel()].view_as(p_)
+                    o += n_
+            for i, (param, x2d) in enumerate(b):
+                M, N = x2d.shape
+                gt, acc = self._target(param)
+                probs[i] = (x2d.data_ptr(), gt.data_ptr(), M, N, N, dt(x2d), 0)
+                cb, rs = (N + 127) // 128, (M + 255) // 256
+                t = np.zeros((rs, cb, 4), dtype=np.int32)
+                t[..., 0] = i
+                t[..., 1] = np.arange(cb, dtype=np.int32)[None, :]
+                t[..., 2] = np.arange(rs, dtype=np.int32)[:, None]
+                items.append(t.reshape(-1, 4))
+            items = np.concatenate(items, 0)
+            pt = self._stage("bp", probs.view(np.uint8), dev)
+            it = self._stage("bi", items.view(np.uint8).reshape(-1), dev)
+            call("evp_colsum_grouped", pt.data_ptr(), it.data_ptr(), int(items.shape[0]), stream_ptr())
+
+
+_deferred = _DeferredGrads()
+
+
+def set_deferred_grads(flag):
+    """A/B switch: grouped end-of-backward weight/bias gradients (default) or one GEMM / column sum per layer."""
+    _deferred.enabled = bool(flag)
+
+
+def flush_deferred_grads():
+    if _deferred.w or _deferred.b:
+        _deferred.flush()
+
+
+def _wgrad(dy, x, n_out, k_in, rows, param=None, shape=None):
+    """dW[n_out,k_in] = dy^T x (f32). Returns the gradient, or None when it was queued for the grouped launch
+    (then flush() delivers it into param.grad)."""
+    if param is not None and dy.dtype == torch.bfloat16 and n_out % 8 == 0 and k_in % 8 == 0 and _deferred.can_defer(param):
+        _deferred.wgrad(param, dy, x, n_out, k_in, rows)
+        return None
     dw = torch.empty(n_out, k_in, dtype=torch.float32, device=dy.device)
-    return gemm(dy, x, dw, M=n_out, N=k_in, K=rows, trans_a=True, trans_b=True, lda=n_out, ldb=k_in)
+    gemm(dy, x, dw, M=n_out, N=k_in, K=rows, trans_a=True, trans_b=True, lda=n_out, ldb=k_in)
+    return dw if shape is None else dw.view(shape)
+
+
+def _bgrad(x2d, param=None):
+    """db[n] = sum_m x2d[m,n] (f32); None when queued (see _wgrad)."""
+    if param is not None and x2d.shape[1] % 8 == 0 and _deferred.can_defer(param):
+        _deferred.colsum(param, x2d)
+        return None
+    return colsum(x2d)
 
 
 # ----------------------------------------------------------------------------------------------------- autograd
@@ -263,6 +400,7 @@ class ViTBlockFn(torch.autograd.Function):
                               wq, wp, w1, w2)
         ctx.dims = (B, N, D, heads, dh, Hd)
         ctx.fused = fused
+        ctx.prm = (qkvw, qkvb, pw, pb, f1w, f1b, f2w, f2b)     # leaf parameters: targets of the deferred gradients
         out = x2.view(B, N, D)
         if want_attn:
             attn = probs[..., :N]
@@ -281,29 +419,31 @@ class ViTBlockFn(torch.autograd.Function):
         bf = T == torch.bfloat16
         g2 = _chk(g2.contiguous(), torch.float32).view(M, D)
         g2_lp = cast(g2, T)
+        qkvw_, qkvb_, pw_, pb_, f1w_, f1b_, f2w_, f2b_ = ctx.prm
+        need = ctx.needs_input_grad
         # MLP
-        db2 = colsum(g2)
-        dw2 = _wgrad(g2_lp, h_act, D, Hd, M)
+        db2 = _bgrad(g2, f2b_) if need[12] else None
+        dw2 = _wgrad(g2_lp, h_act, D, Hd, M, f2w_) if need[11] else None
         dh_pre = torch.empty(M, Hd, dtype=T, device=dev)
         gemm(g2_lp, w2, dh_pre, M=M, N=Hd, K=D, trans_b=True, ldb=Hd, act=ACT_DGELU, aux=h_pre)
-        db1 = colsum(dh_pre)
-        dw1 = _wgrad(dh_pre, ln2, Hd, D, M)
+        db1 = _bgrad(dh_pre, f1b_) if need[10] else None
+        dw1 = _wgrad(dh_pre, ln2, Hd, D, M, f1w_) if need[9] else None
         dln2 = torch.empty(M, D, dtype=T, device=dev)
         gemm(dh_pre, w1, dln2, M=M, N=D, K=Hd, trans_b=True, ldb=D)
         g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf)
         if not bf:
             g1_lp = g1
         # attention
-        dbp = colsum(g1)
-        dwp = _wgrad(g1_lp, att, D, D, M)
+        dbp = _bgrad(g1, pb_) if need[6] else None
+        dwp = _wgrad(g1_lp, att, D, D, M, pw_) if need[5] else None
         datt = torch.empty(M, D, dtype=T, device=dev)
         gemm(g1_lp, wp, datt, M=M, N=D, K=D, trans_b=True, ldb=D)
         if ctx.fused:
             dqkv = attention_fused_bwd(qkv, att, datt, stat, B, N, heads, dh)
         else:
             dqkv = attention_bwd(qkv, stat, datt, B, N, heads, dh)
-        dbq = colsum(dqkv)
-        dwq = _wgrad(dqkv, ln1, 3 * D, D, M)
+        dbq = _bgrad(dqkv, qkvb_) if need[4] else None
+        dwq = _wgrad(dqkv, ln1, 3 * D, D, M, qkvw_) if need[3] else None
         dln1 = torch.empty(M, D, dtype=T, device=dev)
         gemm(dqkv, wq, dln1, M=M, N=D, K=3 * D, trans_b=True, ldb=D)
         g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1)
@@ -338,6 +478,7 @@ class PatchEmbedFn(torch.autograd.Function):
              ptr(out), ptr(mean), ptr(rstd), stream_ptr())
         ctx.save_for_backward(cols, y, gamma, beta, mean, rstd)
         ctx.wshape = tuple(w.shape)
+        ctx.prm = (w, b)
         return out.view(B, n_keep, D)
 
     @staticmethod
@@ -354,8 +495,8 @@ class PatchEmbedFn(torch.autograd.Function):
         ws = torch.empty(2 * nb * D, dtype=torch.float32, device=dev)
         call("evp_embed_post_bwd", ptr(g), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), M, D, ptr(dy), dt(dy),
              ptr(dgamma), ptr(dbeta), ptr(ws), stream_ptr())
-        dw = _wgrad(dy, cols, D, Kc, M).view(ctx.wshape)
-        db = colsum(dy)
+        dw = _wgrad(dy, cols, D, Kc, M, ctx.prm[0], ctx.wshape) if ctx.needs_input_grad[2] else None
+        db = _bgrad(dy, ctx.prm[1]) if ctx.needs_input_grad[3] else None
         return None, None, dw, db, dgamma, dbeta, None, None
 
 
@@ -404,6 +545,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(xl, wl)
         ctx.has_bias = b is not None
         ctx.needs_dx = x.requires_grad
+        ctx.prm = (w, b)
         return y.view(*shp[:-1], N)
 
     @staticmethod
@@ -413,8 +555,8 @@ class LinearFn(torch.autograd.Function):
         N = wl.shape[0]
         g2d = _chk(g.contiguous(), torch.float32).view(M, N)
         gl = cast(g2d, xl.dtype)
-        dw = _wgrad(gl, xl, N, K, M)
-        db = colsum(g2d) if ctx.has_bias else None
+        dw = _wgrad(gl, xl, N, K, M, ctx.prm[0]) if ctx.needs_input_grad[1] else None
+        db = _bgrad(g2d, ctx.prm[1]) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         dx = None
         if ctx.needs_dx:
             dx = torch.empty(M, K, dtype=torch.float32, device=g.device)

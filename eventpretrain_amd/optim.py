@@ -86,6 +86,8 @@ class FusedAdamW(torch.optim.Optimizer):
         counter, stage gradient pointers / lr / weight decay / bias corrections into pinned host tables and enqueue
         their (tiny) H2D copies. Called inside a HIP-graph capture, the copies become graph nodes that re-read the
         pinned tables at every replay; `stage_scalars()` then updates lr / bias corrections before each replay."""
+        from . import ops
+        ops.flush_deferred_grads()      # normally already done by the end-of-backward callback
         act = self._active()
         if not act:
             return False

@@ -90,6 +90,16 @@ typedef struct {
   int splitk;                           /* 0 auto, n = cut K into n slices summed with f32 atomics (plain f32 C only) */
 } evp_gemm_desc;
 int evp_gemm(const evp_gemm_desc *d, void *stream);
+/* Grouped weight-gradient GEMM: n problems C_g[M_g,N_g] (f32) = A_g^T . B_g, A_g stored [K_g][M_g] and B_g stored
+ * [K_g][N_g] (bf16), in ONE launch -- the deferred dW = dY^T . X of every Linear of the step (autograd backward of
+ * vit_block.py:133,141,226,230 etc.). `problems` is a device array of
+ *   struct { const void *A, *B; void *C; int M, N, K; int lda, ldb, ldc; int accumulate, pad; }   (56 bytes each;
+ *   accumulate != 0: C_g += ...)
+ * and `items` a device array of  struct { int prob, tile_m, tile_n, pad; }  listing every 128x128 output tile. */
+int evp_gemm_grouped_tn_bf16(const void *problems, const void *items, int n_items, void *stream);
+/* Tuning switch for A/B measurements: 1 = LDS-DMA (buffer_load ... lds) staging for bf16 (default), 2 = register
+ * staging. Returns the previous value; any other argument only queries. Results are identical. */
+int evp_gemm_set_variant(int v);
 
 /* ------------------------------------------------------------------------------------------------ K4/K9 LayerNorm
  * Replaces nn.LayerNorm over the last dim (vit_block.py:247,249; vit.py:126-128 with the 3-tap sum fused:
@@ -108,6 +118,12 @@ int evp_layernorm_bwd(const void *dy, int dy_dtype, const float *x, const float 
  * nblk = evp_colsum_nblk(M). */
 int evp_colsum_nblk(int64_t M);
 int evp_colsum(const void *x, int x_dtype, int64_t M, int N, int64_t ld, float *out, float *workspace, void *stream);
+
+/* Grouped column sums: out_g[n] += sum_m x_g[m,n] for many tensors in one launch (the deferred bias gradients of a
+ * step). problems: device array of struct { const void *x; float *out; int64 M; int N, ld, dtype, pad; } (40 bytes);
+ * items: device array of struct { int prob, col_block (128 columns), row_slab (evp_colsum rows per slab = 256),
+ * pad; }. The outputs must be zeroed by the caller (they accumulate with f32 atomics). */
+int evp_colsum_grouped(const void *problems, const void *items, int n_items, void *stream);
 
 /* ------------------------------------------------------------------------------------------------ K6 attention core
  * Replaces vit_block.py:134-140 on the packed qkv tensor ([B,N,3,h,dh], element type dtype) of the fused qkv Linear:

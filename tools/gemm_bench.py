@@ -29,8 +29,12 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--splitk", type=int, default=0)
     ap.add_argument("--only", default="")
+    ap.add_argument("--variant", type=int, default=0)
     args = ap.parse_args()
     dev = "cuda"
+    if args.variant:
+        from eventpretrain_amd._lib import call
+        call("evp_gemm_set_variant", args.variant)
     T = torch.bfloat16
     Me, Md = 64 * 98, 64 * 196
     shapes = [  # (name, M, N, K) of the forward Linear; dgrad = (M, K, N), wgrad = (N, K, M)
