@@ -69,6 +69,10 @@ SIGNATURES = {
     "evp_l2norm_rows_fwd": [_vp, _i64, _i, _vp, _vp, _vp],
     "evp_l2norm_rows_bwd": [_vp, _vp, _vp, _i64, _i, _vp, _vp],
     "evp_cross_entropy": [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp],
+    "evp_rowdot_f32": [_vp, _vp, _i64, _i, _vp, _vp],
+    "evp_scale_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp, _vp],
+    "evp_infonce_queue": [_vp, _vp, _i64, _i, _i64, _f, _vp, _vp, _vp, _vp, _vp],
+    "evp_enqueue_keys": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "evp_abi_version": [],
 }
 _OTHER_RESTYPE = {"evp_last_error": C.c_char_p, "evp_target_arch": C.c_char_p}

@@ -62,6 +62,60 @@ __global__ __launch_bounds__(1024) void mean_kernel(const float *v, int64_t n, f
   if (threadIdx.x == 0) out[0] = s / (float)n;
 }
 
+// out[r] = sum_c a[r,c] * b[r,c]
+__global__ __launch_bounds__(256) void rowdot_kernel(const float *a, const float *b, int64_t R, int C, float *out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < R; r += (int64_t)gridDim.x * 4) {
+    float s = 0.f;
+    for (int j = lane; j < C; j += 64) s += a[r * C + j] * b[r * C + j];
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s;
+  }
+}
+// out[r,c] = s[r] * x[r,c] (+ add[r,c])
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float *x, const float *s, const float *add, int64_t R, int C, float *out) {
+  const int64_t total = R * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float v = s[i / C] * x[i];
+    out[i] = add ? v + add[i] : v;
+  }
+}
+// InfoNCE against a queue: logits_r = [pos_r, neg_r[0..K)] / T, label 0 (pr_hub_model.py:150-163)
+__global__ __launch_bounds__(256) void infonce_queue_kernel(const float *pos, const float *neg, int64_t R, int K, int64_t ldn, float invT,
+                                                            float *row_loss, float *dpos, float *dneg) {
+  __shared__ float red[16];
+  const int64_t r = blockIdx.x;
+  const float *nr = neg + r * ldn;
+  const float p0 = pos[r] * invT;
+  float mx = p0;
+  for (int j = threadIdx.x; j < K; j += 256) mx = fmaxf(mx, nr[j] * invT);
+  mx = wave_max(mx);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+  for (int j = threadIdx.x; j < K; j += 256) s += expf(nr[j] * invT - mx);
+  s = block_sum(s, red) + expf(p0 - mx);
+  if (threadIdx.x == 0) row_loss[r] = (logf(s) + mx) - p0;
+  if (dneg) {
+    const float inv = 1.0f / s, sc = invT / (float)R;
+    if (threadIdx.x == 0) dpos[r] = (expf(p0 - mx) * inv - 1.0f) * sc;
+    float *dr = dneg + r * ldn;
+    for (int j = threadIdx.x; j < ldn; j += 256) dr[j] = j < K ? expf(nr[j] * invT - mx) * inv * sc : 0.f;
+  }
+}
+// queue[c, l, ptr + b] = keys[b, l, c]   (pr_hub_model.py:119: keys.T on a 3-D tensor reverses all dims)
+__global__ __launch_bounds__(256) void enqueue_kernel(float *queue, const float *keys, int ptr, int B, int L, int C, int K) {
+  const int64_t total = (int64_t)B * L * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)(i % B);
+    const int64_t t = i / B;
+    const int l = (int)(t % L), c = (int)(t / L);
+    queue[((int64_t)c * L + l) * K + ptr + b] = keys[((int64_t)b * L + l) * C + c];
+  }
+}
+
 static inline int rows_grid(int64_t rows) {
   int64_t g = (rows + 3) / 4;
   if (g > 4096) g = 4096;
@@ -91,5 +145,38 @@ extern "C" int evp_cross_entropy(const float *logits, const int64_t *labels, int
   EVP_CHECK_LAUNCH("evp_cross_entropy");
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, workspace, R, loss);
   EVP_CHECK_LAUNCH("evp_cross_entropy(mean)");
+  return EVP_OK;
+}
+
+extern "C" int evp_rowdot_f32(const float *a, const float *b, int64_t R, int C, float *out, void *stream) {
+  EVP_CHECK_ARG(a && b && out && R > 0 && C > 0, EVP_EINVAL, "evp_rowdot_f32: bad argument");
+  hipLaunchKernelGGL(rowdot_kernel, dim3(rows_grid(R)), dim3(256), 0, (hipStream_t)stream, a, b, R, C, out);
+  EVP_CHECK_LAUNCH("evp_rowdot_f32");
+  return EVP_OK;
+}
+extern "C" int evp_scale_rows_f32(const float *x, const float *s, const float *add, int64_t R, int C, float *out, void *stream) {
+  EVP_CHECK_ARG(x && s && out && R > 0 && C > 0, EVP_EINVAL, "evp_scale_rows_f32: bad argument");
+  int64_t g = (R * C + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, x, s, add, R, C, out);
+  EVP_CHECK_LAUNCH("evp_scale_rows_f32");
+  return EVP_OK;
+}
+extern "C" int evp_infonce_queue(const float *pos, const float *neg, int64_t R, int K, int64_t ldn, float inv_T, float *loss,
+                                 float *dpos, float *dneg, float *workspace, void *stream) {
+  EVP_CHECK_ARG(pos && neg && loss && workspace, EVP_EINVAL, "evp_infonce_queue: null pointer");
+  EVP_CHECK_ARG(R > 0 && K > 0 && ldn >= K && R < 2147483647LL && ((dpos == nullptr) == (dneg == nullptr)), EVP_ESHAPE, "evp_infonce_queue: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(infonce_queue_kernel, dim3((unsigned)R), dim3(256), 0, s, pos, neg, R, K, ldn, inv_T, workspace, dpos, dneg);
+  EVP_CHECK_LAUNCH("evp_infonce_queue");
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, workspace, R, loss);
+  EVP_CHECK_LAUNCH("evp_infonce_queue(mean)");
+  return EVP_OK;
+}
+extern "C" int evp_enqueue_keys(float *queue, const float *keys, int ptr, int B, int L, int C, int K, void *stream) {
+  EVP_CHECK_ARG(queue && keys, EVP_EINVAL, "evp_enqueue_keys: null pointer");
+  EVP_CHECK_ARG(B > 0 && L > 0 && C > 0 && ptr >= 0 && ptr + B <= K, EVP_ESHAPE, "evp_enqueue_keys: ptr+B exceeds the queue length");
+  int64_t g = ((int64_t)B * L * C + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(enqueue_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, queue, keys, ptr, B, L, C, K);
+  EVP_CHECK_LAUNCH("evp_enqueue_keys");
   return EVP_OK;
 }

@@ -623,3 +623,219 @@ def vit_block(x, blk, heads, eps, want_attn=False):
                             blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias,
                             blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias,
                             heads, eps, want_attn)
+
+
+# ----------------------------------------------------------------------------------------------------- contrastive stage
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+class LinearBNFn(torch.autograd.Function):
+    """Linear(no bias) -> BatchNorm over the B*L token rows (training statistics) -> optional ReLU: one stage of the
+    MoCo-v3 heads (mlp_head.py:4-24 applied as pr_hub_model.py:223-237). Hidden stages keep the compute dtype, the
+    last stage (affine=False, no ReLU) returns f32 tokens. Running statistics are updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, running_mean, running_var, eps, momentum, relu, last):
+        B, L, K = x.shape
+        R, N = B * L, w.shape[0]
+        T = _compute_dtype
+        dev = x.device
+        xl = cast(_chk(x.detach().contiguous()).view(R, K), T)
+        wl = lp_weight(w)
+        ydt = torch.float32 if last else T
+        y_pre = torch.empty(R, N, dtype=ydt, device=dev)
+        gemm(xl, wl, y_pre, M=R, N=N, K=K)
+        y = torch.empty(R, N, dtype=ydt, device=dev)
+        mean = torch.empty(N, dtype=torch.float32, device=dev)
+        invstd = torch.empty(N, dtype=torch.float32, device=dev)
+        nb = call("evp_batchnorm_nblk", R)
+        ws = torch.empty((2 * nb + 2) * N, dtype=torch.float32, device=dev)
+        call("evp_batchnorm_fwd", ptr(y_pre), dt(y_pre), R, N, ptr(gamma), ptr(beta), float(eps), float(momentum), int(relu),
+             ptr(y), ptr(mean), ptr(invstd), ptr(running_mean), ptr(running_var), ptr(ws), stream_ptr())
+        ctx.save_for_backward(xl, wl, y_pre, y, mean, invstd, gamma)
+        ctx.cfg = (B, L, K, N, bool(relu), x.dtype, x.requires_grad)
+        ctx.prm = (w,)
+        return y.view(B, L, N)
+
+    @staticmethod
+    def backward(ctx, g):
+        xl, wl, y_pre, y, mean, invstd, gamma = ctx.saved_tensors
+        B, L, K, N, relu, xdt, need_dx = ctx.cfg
+        R = B * L
+        dev = g.device
+        g2d = cast(_chk(g.contiguous()).view(R, N), y.dtype)
+        dpre = torch.empty(R, N, dtype=y.dtype, device=dev)
+        nb = call("evp_batchnorm_nblk", R)
+        ws = torch.empty((2 * nb + 2) * N, dtype=torch.float32, device=dev)
+        affine = gamma is not None
+        dgamma = torch.empty(N, dtype=torch.float32, device=dev) if affine else None
+        dbeta = torch.empty(N, dtype=torch.float32, device=dev) if affine else None
+        call("evp_batchnorm_bwd", ptr(g2d), ptr(y_pre), ptr(y), dt(y), R, N, ptr(gamma), ptr(mean), ptr(invstd), int(relu),
+             ptr(dpre), ptr(dgamma), ptr(dbeta), ptr(ws), stream_ptr())
+        dl = cast(dpre, xl.dtype)
+        dw = _wgrad(dl, xl, N, K, R, ctx.prm[0]) if ctx.needs_input_grad[1] else None
+        dx = None
+        if need_dx:
+            dx = torch.empty(R, K, dtype=xdt if xdt == torch.float32 else xl.dtype, device=dev)
+            gemm(dl, wl, dx, M=R, N=K, K=N, trans_b=True, ldb=K)
+            dx = dx.view(B, L, K)
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None
+
+
+def linear_bn_tokens(x, lin, bn, relu):
+    """One [Linear, BatchNorm2d(, ReLU)] stage of an nn.Sequential head on (B, L, C) tokens."""
+    if bn is None:
+        return LinearFn.apply(x, lin.weight, None)
+    if not bn.training:
+        raise NotImplementedError("the pre-training heads only run in training mode (batch statistics)")
+    last = not relu
+    out = LinearBNFn.apply(x, lin.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                           0.1 if bn.momentum is None else bn.momentum, relu, last)
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return out
+
+
+class L2NormFn(torch.autograd.Function):
+    """F.normalize(x, dim=-1) on f32 tokens."""
+
+    @staticmethod
+    def forward(ctx, x):
+        C_ = x.shape[-1]
+        x2 = _chk(x.detach().contiguous(), torch.float32).view(-1, C_)
+        y = torch.empty_like(x2)
+        nrm = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
+        call("evp_l2norm_rows_fwd", ptr(x2), x2.shape[0], C_, ptr(y), ptr(nrm), stream_ptr())
+        ctx.save_for_backward(y, nrm)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        y, nrm = ctx.saved_tensors
+        g2 = _chk(g.contiguous(), torch.float32).view(y.shape)
+        dx = torch.empty_like(y)
+        call("evp_l2norm_rows_bwd", ptr(g2), ptr(y), ptr(nrm), y.shape[0], y.shape[1], ptr(dx), stream_ptr())
+        return dx.view(g.shape)
+
+
+class InfoNCEQueueFn(torch.autograd.Function):
+    """Per-position InfoNCE of normalised q against the positive key and the (C,L,K) queue
+    (pr_hub_model.py:150-160). q, k: normalised f32 (B,L,C)."""
+
+    @staticmethod
+    def forward(ctx, q, k, queue, T_):
+        B, L, C_ = q.shape
+        K = queue.shape[2]
+        Kp = _pad8(K)
+        R = B * L
+        dev = q.device
+        Tc = _compute_dtype
+        q2, k2 = _chk(q.detach().contiguous(), torch.float32).view(R, C_), _chk(k.detach().contiguous(), torch.float32).view(R, C_)
+        pos = torch.empty(R, dtype=torch.float32, device=dev)
+        call("evp_rowdot_f32", ptr(q2), ptr(k2), R, C_, ptr(pos), stream_ptr())
+        qw = queue.detach() if Kp == K else torch.nn.functional.pad(queue.detach(), (0, Kp - K))   # tiny test queues only
+        ql, qul = cast(q2, Tc), cast(qw.contiguous(), Tc)
+        neg = torch.empty(B, L, Kp, dtype=torch.float32, device=dev)
+        # neg[b,l,:] = q[b,l,:] . queue[:,l,:]   ('blc,clk->blk'), batched over l
+        gemm(ql, qul, neg, M=B, N=K, K=C_, trans_b=True, lda=L * C_, ldb=L * Kp, ldc=L * Kp, batch=(L, 1),
+             stride_a=(C_, 0), stride_b=(Kp, 0), stride_c=(Kp, 0))
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dpos = torch.empty(R, dtype=torch.float32, device=dev)
+        dneg = torch.empty(B, L, Kp, dtype=torch.float32, device=dev)
+        ws = torch.empty(R, dtype=torch.float32, device=dev)
+        call("evp_infonce_queue", ptr(pos), ptr(neg), R, K, Kp, 1.0 / T_, ptr(loss), ptr(dpos), ptr(dneg), ptr(ws), stream_ptr())
+        ctx.save_for_backward(q2, k2, qul, dpos, dneg)
+        ctx.cfg = (B, L, C_, K, Kp)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        q2, k2, qul, dpos, dneg = ctx.saved_tensors
+        B, L, C_, K, Kp = ctx.cfg
+        R = B * L
+        dev = g.device
+        dq_pos = torch.empty(R, C_, dtype=torch.float32, device=dev)
+        call("evp_scale_rows_f32", ptr(k2), ptr(dpos), None, R, C_, ptr(dq_pos), stream_ptr())
+        dk = torch.empty(R, C_, dtype=torch.float32, device=dev)
+        call("evp_scale_rows_f32", ptr(q2), ptr(dpos), None, R, C_, ptr(dk), stream_ptr())
+        dq = torch.empty(R, C_, dtype=torch.float32, device=dev)
+        dnl = cast(dneg, qul.dtype)
+        # dq[b,l,:] = dpos*k + dneg[b,l,:] . queue[:,l,:]^T    ('blk,clk->blc')
+        gemm(dnl, qul, dq, M=B, N=C_, K=K, lda=L * Kp, ldb=L * Kp, ldc=L * C_, batch=(L, 1), stride_a=(Kp, 0),
+             stride_b=(Kp, 0), stride_c=(C_, 0), residual=dq_pos)
+        gs = _chk(g.contiguous().view(1), torch.float32)
+        call("evp_scale_f32", ptr(dq), ptr(gs), dq.numel(), stream_ptr())
+        call("evp_scale_f32", ptr(dk), ptr(gs), dk.numel(), stream_ptr())
+        return dq.view(B, L, C_), dk.view(B, L, C_), None, None
+
+
+class InfoNCEInBatchFn(torch.autograd.Function):
+    """MoCo-v3 in-batch InfoNCE (pr_hub_model.py:170-188): logits[n,l,m] = q[n,l,:].k_all[m,l,:] / T, label of row
+    (n,l) = n + N*rank. k_all carries no gradient when it was all-gathered (as in the reference)."""
+
+    @staticmethod
+    def forward(ctx, q, k_all, T_, rank, k_has_grad):
+        N, L, C_ = q.shape
+        Mk = k_all.shape[0]
+        Mp = _pad8(Mk)
+        dev = q.device
+        Tc = _compute_dtype
+        q2 = _chk(q.detach().contiguous(), torch.float32)
+        ka = _chk(k_all.detach().contiguous(), torch.float32)
+        ql, kl = cast(q2, Tc), cast(ka, Tc)
+        logits = torch.zeros(N, L, Mp, dtype=torch.float32, device=dev)
+        gemm(ql, kl, logits, M=N, N=Mk, K=C_, lda=L * C_, ldb=L * C_, ldc=L * Mp, batch=(L, 1), stride_a=(C_, 0),
+             stride_b=(C_, 0), stride_c=(Mp, 0), alpha=1.0 / T_)
+        labels = (torch.arange(N, device=dev, dtype=torch.int64) + N * rank).unsqueeze(1).expand(N, L).contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dlog = torch.empty(N, L, Mp, dtype=torch.float32, device=dev)
+        ws = torch.empty(N * L, dtype=torch.float32, device=dev)
+        call("evp_cross_entropy", ptr(logits), ptr(labels), N * L, Mk, Mp, ptr(loss), ptr(dlog), ptr(ws), stream_ptr())
+        ctx.save_for_backward(ql, kl, dlog)
+        ctx.cfg = (N, L, C_, Mk, Mp, T_, bool(k_has_grad))
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ql, kl, dlog = ctx.saved_tensors
+        N, L, C_, Mk, Mp, T_, k_has_grad = ctx.cfg
+        dev = g.device
+        dl = cast(dlog, ql.dtype)
+        gs = _chk(g.contiguous().view(1), torch.float32)
+        dq = torch.empty(N, L, C_, dtype=torch.float32, device=dev)
+        gemm(dl, kl, dq, M=N, N=C_, K=Mk, trans_b=True, lda=L * Mp, ldb=L * C_, ldc=L * C_, batch=(L, 1), stride_a=(Mp, 0),
+             stride_b=(C_, 0), stride_c=(C_, 0), alpha=1.0 / T_)
+        call("evp_scale_f32", ptr(dq), ptr(gs), dq.numel(), stream_ptr())
+        dk = None
+        if k_has_grad:
+            dk = torch.empty(Mk, L, C_, dtype=torch.float32, device=dev)
+            gemm(dl, ql, dk, M=Mk, N=C_, K=N, trans_a=True, trans_b=True, lda=L * Mp, ldb=L * C_, ldc=L * C_, batch=(L, 1),
+                 stride_a=(Mp, 0), stride_b=(C_, 0), stride_c=(C_, 0), alpha=1.0 / T_)
+            call("evp_scale_f32", ptr(dk), ptr(gs), dk.numel(), stream_ptr())
+        return dq, dk, None, None, None
+
+
+def info_nce_queue(emb_h, clip_emb, queue, T_):
+    """-> (loss, normalised keys (detached) for the enqueue)."""
+    q = L2NormFn.apply(emb_h)
+    k = L2NormFn.apply(clip_emb)
+    return InfoNCEQueueFn.apply(q, k, queue, T_), k.detach()
+
+
+def info_nce_inbatch(emb_h, clip_emb, T_, distributed=False):
+    q = L2NormFn.apply(emb_h)
+    k = L2NormFn.apply(clip_emb)
+    rank = 0
+    if distributed:
+        import torch.distributed as dist
+        from .model.pretrain.pr_hub_model import concat_all_gather
+        k_all, rank = concat_all_gather(k), dist.get_rank()       # RCCL all-gather over xGMI; no gradient (reference)
+        return InfoNCEInBatchFn.apply(q, k_all, T_, rank, False)
+    return InfoNCEInBatchFn.apply(q, k, T_, rank, True)
+
+
+def enqueue_keys(queue, keys, ptr_):
+    B, L, C_ = keys.shape
+    call("evp_enqueue_keys", ptr(_chk(queue, torch.float32)), ptr(_chk(keys.contiguous(), torch.float32)), int(ptr_), B, L, C_,
+         queue.shape[2], stream_ptr())

@@ -236,6 +236,17 @@ int evp_l2norm_rows_bwd(const float *dy, const float *y, const float *norm, int6
 int evp_cross_entropy(const float *logits, const int64_t *labels, int64_t R, int n_cls, int64_t ld, float *loss,
                       float *dlogits, float *workspace, void *stream);
 
+/* out[r] = <a[r,:], b[r,:]> (the positive logits l_pos of pr_hub_model.py:151) and out[r,c] = s[r]*x[r,c] (+ add). */
+int evp_rowdot_f32(const float *a, const float *b, int64_t R, int C, float *out, void *stream);
+int evp_scale_rows_f32(const float *x, const float *s, const float *add, int64_t R, int C, float *out, void *stream);
+/* InfoNCE against the per-position queue (pr_hub_model.py:150-160): row r has logits [pos[r], neg[r,0..K)] * inv_T,
+ * positive at class 0; loss[0] = mean CE; optional dpos float32 [R], dneg float32 [R,ldn] (pad columns zeroed).
+ * workspace float32 [R]. */
+int evp_infonce_queue(const float *pos, const float *neg, int64_t R, int K, int64_t ldn, float inv_T, float *loss,
+                      float *dpos, float *dneg, float *workspace, void *stream);
+/* _dequeue_and_enqueue (pr_hub_model.py:112-122): queue[c,l,ptr+b] = keys[b,l,c]; queue float32 [C,L,K]. */
+int evp_enqueue_keys(float *queue, const float *keys, int ptr, int B, int L, int C, int K, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,6 +149,66 @@ def test_training_trajectory_matches_reference_trainer():
         assert checksums(params[name])[2] == pytest.approx(ws, rel=2e-4, abs=tol), name
 
 
+@pytest.mark.parametrize("use_queue", [True, False])
+def test_contrastive_stage_f32_matches_reference(use_queue):
+    """PrHubModel.forward(is_rec=False) (dense ViT-Small, MoCo-v3 heads with BatchNorm, CLIP-token branch, InfoNCE with
+    and without the queue) against the fixture made by the reference: loss, returned tensors, gradients, BN running
+    statistics, queue contents and pointer after the enqueue."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
+    from eventpretrain_amd.testing import det_fill_module_, det_normalish, make_args
+    d = load_golden("con_small_queue" if use_queue else "con_small_noqueue")
+    a = make_args(model_size="small", pr_phase="con", use_queue=use_queue, mask_ratio=0.0, device="cuda")
+    m = hub.pretrain_hub_model_small_patch16(a, emb_frames_dim=512, queue_length=4, T=0.07)
+    det_fill_module_(m)
+    m = m.cuda().train()
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == jl(d["state_keys"])
+    x = det_normalish("con.voxels", (2, 5, 224, 224)) * 0.5
+    clip = det_normalish("con.clip_emb", (2, 197, 512))
+    ops.set_compute_dtype(torch.float32)
+    loss, h_org, h_proj, c_org, c_proj, attn = m(x.cuda(), clip.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(d["loss"])) <= F32_LOSS_RTOL * abs(float(d["loss"]))
+    assert_checksums(h_org, d["emb_h_org_checksums"], 1e-4)
+    assert_checksums(h_proj, d["emb_h_proj_checksums"], 2e-4)
+    assert_checksums(c_org, d["clip_org_checksums"], 1e-4)
+    assert_checksums(c_proj, d["clip_proj_checksums"], 1e-4)
+    assert_checksums(attn.float(), d["attn_checksums"], 1e-4)
+    params = dict(m.named_parameters())
+    for n, gn in zip(jl(d["grad_names"]), d["grad_norms"]):
+        assert params[n].grad is not None, n
+        assert params[n].grad.double().norm().item() == pytest.approx(gn, rel=5e-3, abs=2e-6), n
+    sd = m.state_dict()
+    for k, cs in zip(jl(d["bn_keys"]), d["bn_checksums"]):
+        assert_checksums(sd[k], cs, 1e-4, k)
+    if use_queue:
+        assert_checksums(m.queue, d["queue_after_checksums"], 1e-5)
+        assert int(m.queue_ptr) == int(d["queue_ptr_after"][0])
+
+
+def test_contrastive_stage_bf16_runs():
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
+    from eventpretrain_amd.testing import det_fill_module_, det_normalish, make_args
+    d = load_golden("con_small_queue")
+    a = make_args(model_size="small", pr_phase="con", use_queue=True, mask_ratio=0.0, device="cuda")
+    m = hub.pretrain_hub_model_small_patch16(a, emb_frames_dim=512, queue_length=4, T=0.07)
+    det_fill_module_(m)
+    m = m.cuda().train()
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        loss = m((det_normalish("con.voxels", (2, 5, 224, 224)) * 0.5).cuda(), det_normalish("con.clip_emb", (2, 197, 512)).cuda())[0]
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_compute_dtype(torch.float32)
+    rel = abs(loss.item() - float(d["loss"])) / abs(float(d["loss"]))
+    print(f"con bf16 loss rel err {rel:.2e}")
+    assert rel <= 5e-2
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
 def test_no_cpu_fallback():
     from eventpretrain_amd import ops
     from eventpretrain_amd._lib import EvpError
