@@ -189,6 +189,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python each step (no HIP graph)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-GPU code path (process group, reducer, split graphs) even with one rank")
     args = ap.parse_args()
 
     from eventpretrain_amd import _lib
@@ -201,22 +203,24 @@ def main():
         raise SystemExit("--gpus does not match WORLD_SIZE")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)     # "nccl" is RCCL over xGMI on ROCm
 
     a, model, opt = build(args, device)
     ev, off, vox, tgt, S, n_ev = make_batch(args, device, rank)
     reducer = None
-    if world > 1:
+    if multi:
         from eventpretrain_amd.parallel import BucketedGradReducer
         reducer = BucketedGradReducer([p for p in model.parameters() if p.requires_grad], bucket_mb=args.bucket_mb)
     gen = torch.Generator(device=device).manual_seed(100 + rank)     # seed + rank, as main_pretrain.py:174
     L = model.backbone.num_patches
-
     noise_buf = torch.empty(args.batch, L, device=device)
 
     def eager_step():
+        nonlocal gen
         noise_buf.copy_(torch.rand(args.batch, L, device=device, generator=gen))
         out = model(vox, tgt, is_rec=True, noise=noise_buf)
         out[0].backward()
@@ -227,22 +231,23 @@ def main():
         return out[0]
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- HIP graph of the step (single GPU): the ~900 kernel launches of forward + backward + AdamW are captured
-    # once and replayed; per-step scalars (lr, Adam bias corrections) travel through pinned host tables that the
-    # graph's own H2D copy nodes re-read, the mask noise is drawn into a static buffer before each replay.
-    graph, graph_note, static_loss = None, "eager", None
-    use_graph = not args.no_graph and world == 1
+    # ---- HIP graphs of the step: the ~900 kernel launches of forward + backward (+ AdamW) are captured once and
+    # replayed; per-step scalars (lr, Adam bias corrections) travel through pinned host tables that the graph's own
+    # H2D copy nodes re-read, the mask noise is drawn into a static buffer before each replay. With N > 1 the
+    # collectives stay outside the graphs: [forward+backward graph] -> in-place RCCL all-reduce of the flat gradient
+    # buffers -> [AdamW graph].
+    graph, graph2, plan, graph_note, static_loss = None, None, None, "eager", None
+    use_graph = not args.no_graph
     n_warm_eager = min(args.warmup, 3) if use_graph else args.warmup
     loss = None
     if use_graph:
-        # warm up on the capture stream (so every AccumulateGrad node is born there), then capture
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side):     # warm up on the capture stream so every AccumulateGrad node is born there
             for _ in range(max(n_warm_eager, 2)):
                 loss = eager_step()
         torch.cuda.current_stream().wait_stream(side)
@@ -253,14 +258,25 @@ def main():
             with torch.cuda.graph(g_, stream=side):
                 out = model(vox, tgt, is_rec=True, noise=noise_buf)
                 out[0].backward()
-                opt.refresh()
-                opt.launch()
+                if not multi:
+                    opt.refresh()
+                    opt.launch()
                 static_loss = out[0].detach()
                 del out
             graph, graph_note = g_, "hip-graph"
+            if multi:
+                plan = reducer.make_static_plan()       # freezes the (now static) gradient buffers
+                plan.run()
+                g2_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2_, stream=side):
+                    opt.refresh()
+                    opt.launch()
+                graph2, graph_note = g2_, "hip-graph (fwd+bwd) + RCCL all-reduce + hip-graph (AdamW)"
         except Exception as e:      # keep the benchmark alive; say what happened
-            graph, graph_note = None, "eager (graph capture failed: %r)" % (e,)
+            graph, graph2, plan = None, None, None
+            graph_note = "eager (graph capture failed: %r)" % (e,)
             opt.zero_grad(set_to_none=True)
+            gen = torch.Generator(device=device).manual_seed(100 + rank)   # a failed capture can poison the old one
     else:
         for _ in range(n_warm_eager):
             loss = eager_step()
@@ -271,6 +287,9 @@ def main():
         noise_buf.copy_(torch.rand(args.batch, L, device=device, generator=gen))
         opt.stage_scalars()
         graph.replay()
+        if plan is not None:
+            plan.run()
+            graph2.replay()
         return static_loss
 
     for _ in range(args.warmup - n_warm_eager):
@@ -281,7 +300,7 @@ def main():
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -341,7 +360,7 @@ def main():
                            "frac": bytes_ / sec / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "voxel_cuts_kernel+voxel_bin_kernel",
                            "us_per_batch": sec * 1e6, "clips_per_s": args.batch / sec, "events_per_s": args.batch * n_ev / sec,
                            "algorithmic_bytes_per_clip": n_ev * 32 + 5 * S * S * 4}
-    if world > 1:
+    if multi:
         dist.barrier()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -353,7 +372,7 @@ def main():
             result["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": n_thr, "kind": "port", "sample": "failed: %r" % (e,)}
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

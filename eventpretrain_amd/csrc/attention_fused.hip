@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t *qkv, bf16_t
 template <int DH, int NT>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse,
                                                        bf16_t *dqkv, int N, int heads, float scale) {
-  constexpr int NP = 16 * NT, IMG = NP * DH * 2, KS = DH / 32, DT = DH / 16;
+  constexpr int NP = 16 * NT, IMG = NP * DH * 2, KS = DH / 32, DT = DH / 16, CH = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *Qs = smem, *Ks = smem + IMG, *Vs = smem + 2 * IMG, *Gs = smem + 3 * IMG;   // Gs = dO
   float *Ls = reinterpret_cast<float *>(smem + 4 * IMG), *Ds = Ls + NP;          // log-sum-exp, delta = rowsum(dO * O)
@@ -195,29 +195,43 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *qkv, const 
       gf[ks] = frag_rows<DH>(Gs, strip * 16, ks, lane);
     }
     const float lq = Ls[strip * 16 + li] * l2e, dq_ = Ds[strip * 16 + li];
-    f32x4 P[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Ks, t * 16, ks, lane), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Vs, t * 16, ks, lane), gf[ks], dp, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = (16 * t + 4 * g + r < N) ? exp2f(s[r] * c2 - lq) : 0.f;
-        P[t][r] = p * (dp[r] - dq_) * scale;   // dS
-      }
-    }
     const int q = strip * 16 + li;
+    f32x4 accq[DT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DT; ++dt) accq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // key tiles in chunks of CH (even): only CH score tiles are live at a time, dQ accumulates across chunks
+#pragma unroll 1
+    for (int c0 = 0; c0 < NT; c0 += CH) {
+      f32x4 P[CH];
 #pragma unroll
-      for (int s = 0; s < NT / 2; ++s)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<DH>(Ks, dt * 16, s, lane), pack_tiles(P[2 * s], P[2 * s + 1]), acc, 0, 0, 0);
-      if (q < N) *reinterpret_cast<uint2 *>(dqkv + ((int64_t)b * N + q) * tok + h * DH + dt * 16 + 4 * g) = pack4(acc);
+      for (int tt = 0; tt < CH; ++tt) {
+        const int t = c0 + tt;
+        if (t < NT) {
+          f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Ks, t * 16, ks, lane), qf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Vs, t * 16, ks, lane), gf[ks], dp, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = (16 * t + 4 * g + r < N) ? exp2f(s[r] * c2 - lq) : 0.f;
+            P[tt][r] = p * (dp[r] - dq_) * scale;   // dS
+          }
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int ss = 0; ss < CH / 2; ++ss)
+          if (c0 + 2 * ss < NT)
+            accq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<DH>(Ks, dt * 16, (c0 >> 1) + ss, lane),
+                                                               pack_tiles(P[2 * ss], P[2 * ss + 1]), accq[dt], 0, 0, 0);
+    }
+    if (q < N) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        *reinterpret_cast<uint2 *>(dqkv + ((int64_t)b * N + q) * tok + h * DH + dt * 16 + 4 * g) = pack4(accq[dt]);
     }
   }
 
@@ -229,38 +243,51 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *qkv, const 
       kf[ks] = frag_rows<DH>(Ks, strip * 16, ks, lane);
       vf[ks] = frag_rows<DH>(Vs, strip * 16, ks, lane);
     }
-    f32x4 P[NT], dS[NT];
+    f32x4 av[DT], ak[DT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DT; ++dt) av[dt] = ak[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c0 = 0; c0 < NT; c0 += CH) {      // query tiles in chunks: dK / dV accumulate across chunks
+      f32x4 P[CH], dS[CH];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Qs, t * 16, ks, lane), kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Gs, t * 16, ks, lane), vf[ks], dp, 0, 0, 0);
+      for (int tt = 0; tt < CH; ++tt) {
+        const int t = c0 + tt;
+        if (t < NT) {
+          f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Qs, t * 16, ks, lane), kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Gs, t * 16, ks, lane), vf[ks], dp, 0, 0, 0);
+          }
+          const float4 lq = *reinterpret_cast<const float4 *>(Ls + 16 * t + 4 * g);
+          const float4 dl = *reinterpret_cast<const float4 *>(Ds + 16 * t + 4 * g);
+          const float lqa[4] = {lq.x, lq.y, lq.z, lq.w}, dla[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = exp2f(s[r] * c2 - lqa[r] * l2e);   // padded queries carry lse = +inf -> p = 0
+            P[tt][r] = p;
+            dS[tt][r] = p * (dp[r] - dla[r]) * scale;
+          }
+        }
       }
-      const float4 lq = *reinterpret_cast<const float4 *>(Ls + 16 * t + 4 * g);
-      const float4 dl = *reinterpret_cast<const float4 *>(Ds + 16 * t + 4 * g);
-      const float lqa[4] = {lq.x, lq.y, lq.z, lq.w}, dla[4] = {dl.x, dl.y, dl.z, dl.w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = exp2f(s[r] * c2 - lqa[r] * l2e);   // padded queries carry lse = +inf -> p = 0
-        P[t][r] = p;
-        dS[t][r] = p * (dp[r] - dla[r]) * scale;
-      }
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int ss = 0; ss < CH / 2; ++ss)
+          if (c0 + 2 * ss < NT) {
+            av[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<DH>(Gs, dt * 16, (c0 >> 1) + ss, lane),
+                                                             pack_tiles(P[2 * ss], P[2 * ss + 1]), av[dt], 0, 0, 0);
+            ak[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<DH>(Qs, dt * 16, (c0 >> 1) + ss, lane),
+                                                             pack_tiles(dS[2 * ss], dS[2 * ss + 1]), ak[dt], 0, 0, 0);
+          }
     }
     const int key = strip * 16 + li;
+    if (key < N) {
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      f32x4 av = f32x4{0.f, 0.f, 0.f, 0.f}, ak = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < NT / 2; ++s) {
-        av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<DH>(Gs, dt * 16, s, lane), pack_tiles(P[2 * s], P[2 * s + 1]), av, 0, 0, 0);
-        ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<DH>(Qs, dt * 16, s, lane), pack_tiles(dS[2 * s], dS[2 * s + 1]), ak, 0, 0, 0);
-      }
-      if (key < N) {
+      for (int dt = 0; dt < DT; ++dt) {
         bf16_t *o = dqkv + ((int64_t)b * N + key) * tok + h * DH + dt * 16 + 4 * g;
-        *reinterpret_cast<uint2 *>(o + C) = pack4(ak);
-        *reinterpret_cast<uint2 *>(o + 2 * C) = pack4(av);
+        *reinterpret_cast<uint2 *>(o + C) = pack4(ak[dt]);
+        *reinterpret_cast<uint2 *>(o + 2 * C) = pack4(av[dt]);
       }
     }
   }

@@ -56,33 +56,37 @@ template <> struct Cfg<float> {
 // Transposed operand (k strided): image [BK][ROWS].
 //   bf16: ROWS*2-byte rows; chunk XOR per the transposed-read rule ("LDS images")
 //   f32 : rows padded to ROWS+16 floats
-template <typename T, bool TR, int ROWS> struct Img;
+template <typename T, bool TR, int ROWS, int BK> struct Img;
 
-template <int ROWS> struct Img<bf16_t, false, ROWS> {
-  static constexpr int BYTES = ROWS * 64 * 2;
-  static __device__ __forceinline__ int chunk_off(int row, int ch) { return row * 128 + ((ch ^ (row & 7)) << 4); }
+template <int ROWS, int BK> struct Img<bf16_t, false, ROWS, BK> {
+  static constexpr int BYTES = ROWS * BK * 2;
+  static __device__ __forceinline__ int chunk_off(int row, int ch) {
+    if (BK == 64) return row * 128 + ((ch ^ (row & 7)) << 4);
+    return row * 64 + (ch << 4);              // BK = 32: 64-byte rows, a 16-row fragment read is 1 KiB contiguous
+  }
 };
-template <int ROWS> struct Img<bf16_t, true, ROWS> {
-  static constexpr int BYTES = 64 * ROWS * 2;
+template <int ROWS, int BK> struct Img<bf16_t, true, ROWS, BK> {
+  static constexpr int BYTES = BK * ROWS * 2;
   // k = LDS row, ch = 16-byte chunk along the ROWS (m or n) direction
   static __device__ __forceinline__ int chunk_off(int k, int ch) {
+    if (ROWS == 256) return k * 512 + ((ch ^ (((k & 3) << 2) | ((k >> 2) & 3))) << 4);
     if (ROWS == 128) return k * 256 + ((ch ^ (((k & 3) << 2) | ((k >> 2) & 3))) << 4);
     else return k * 128 + ((ch ^ ((((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1)) << 4);
   }
 };
-template <int ROWS> struct Img<float, false, ROWS> {
+template <int ROWS, int BK> struct Img<float, false, ROWS, BK> {
   static constexpr int LD = 16 + 1;
   static constexpr int BYTES = ((ROWS * LD * 4 + 15) / 16) * 16;
 };
-template <int ROWS> struct Img<float, true, ROWS> {
+template <int ROWS, int BK> struct Img<float, true, ROWS, BK> {
   static constexpr int LD = ROWS + 16;
   static constexpr int BYTES = 16 * LD * 4;
 };
 
 // ---- global -> register staging of one operand tile --------------------------------------------------------
 // Non-transposed: tile = ROWS rows x BK elements, chunks along k. Transposed: BK rows (k) x ROWS elements.
-template <typename T, bool TR, int ROWS, int NT> struct Stage {
-  static constexpr int BK = Cfg<T>::BK, EPC = Cfg<T>::EPC;
+template <typename T, bool TR, int ROWS, int NT, int BK> struct Stage {
+  static constexpr int EPC = Cfg<T>::EPC;
   static constexpr int CPR = TR ? ROWS / EPC : BK / EPC;           // chunks per LDS row
   static constexpr int NROW = TR ? BK : ROWS;
   static constexpr int NCHUNK = (NROW * CPR + NT - 1) / NT;         // per thread
@@ -111,9 +115,9 @@ template <typename T, bool TR, int ROWS, int NT> struct Stage {
       const int lr = cid / CPR, c = cid % CPR;
       if (NROW * CPR % NT == 0 || cid < NROW * CPR) {
         if constexpr (sizeof(T) == 2) {
-          *reinterpret_cast<uint4 *>(img + Img<T, TR, ROWS>::chunk_off(lr, c)) = r[i];
+          *reinterpret_cast<uint4 *>(img + Img<T, TR, ROWS, BK>::chunk_off(lr, c)) = r[i];
         } else {
-          float *p = reinterpret_cast<float *>(img) + lr * Img<T, TR, ROWS>::LD + c * 4;
+          float *p = reinterpret_cast<float *>(img) + lr * Img<T, TR, ROWS, BK>::LD + c * 4;
           if (!TR) {  // padded rows are not 16-byte aligned: scalar stores
             p[0] = __uint_as_float(r[i].x); p[1] = __uint_as_float(r[i].y);
             p[2] = __uint_as_float(r[i].z); p[3] = __uint_as_float(r[i].w);
@@ -131,19 +135,23 @@ template <typename T, bool TR, int ROWS, int NT> struct Stage {
 // written linearly and the XOR swizzle is applied to the per-lane SOURCE address instead (the same involution the
 // fragment reads use). A 16 KiB tile image = 16 such pieces, 4 per wave (256 threads).
 typedef __attribute__((address_space(3))) void lds_void;
-template <bool TR, int ROWS, int NT> struct GStage {
-  static constexpr int PIECES = Img<bf16_t, TR, ROWS>::BYTES / 1024;   // wave-instructions per tile
+template <bool TR, int ROWS, int NT, int BK> struct GStage {
+  static constexpr int PIECES = Img<bf16_t, TR, ROWS, BK>::BYTES / 1024;   // wave-instructions per tile
   static constexpr int PER_WAVE = PIECES / (NT / 64);
+  static_assert(PIECES % (NT / 64) == 0, "tile image must split evenly over the waves");
   __device__ __forceinline__ static void issue(__amdgpu_buffer_rsrc_t rs, int ld, int row0, int k0, int nrows, int K, char *img,
                                                int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
       const int piece = wave * PER_WAVE + i;
       int gr, gk;
-      if (!TR) {                       // 128-byte rows: 8 rows per piece, 8 chunks per row
+      if (!TR && BK == 64) {           // 128-byte rows: 8 rows per piece, 8 chunks per row, chunk ^ (row & 7)
         const int row = piece * 8 + (lane >> 3), pos = lane & 7;
         gr = row0 + row;
         gk = k0 + ((pos ^ (row & 7)) << 3);
+      } else if (!TR) {                // BK = 32: 64-byte rows, 16 rows per piece, linear
+        gr = row0 + piece * 16 + (lane >> 2);
+        gk = k0 + ((lane & 3) << 3);
       } else if (ROWS == 128) {        // 256-byte k-rows: 4 per piece, 16 chunks per row
         const int k = piece * 4 + (lane >> 4), pos = lane & 15;
         gk = k0 + k;
@@ -162,19 +170,19 @@ template <bool TR, int ROWS, int NT> struct GStage {
 
 // ---- fragment loads ----------------------------------------------------------------------------------------
 // bf16 fragment of the 16 rows starting at `rb` for k-step `ks` (32 deep): lane holds row rb+(l&15), k 8*(l>>4)..+7
-template <bool TR, int ROWS>
+template <bool TR, int ROWS, int BK>
 __device__ __forceinline__ bf16x8 frag_bf16(const char *img, int rb, int ks, int lane) {
   const int g = lane >> 4, i = lane & 15;
   if constexpr (!TR) {
     const int row = rb + i;
-    const uint4 v = *reinterpret_cast<const uint4 *>(img + Img<bf16_t, false, ROWS>::chunk_off(row, ks * 4 + g));
+    const uint4 v = *reinterpret_cast<const uint4 *>(img + Img<bf16_t, false, ROWS, BK>::chunk_off(row, ks * 4 + g));
     return __builtin_bit_cast(bf16x8, v);
   } else {
     const int q = i >> 2, p = i & 3;
     const int k = ks * 32 + 8 * g + q;
     const int ch = (rb >> 3) + (p >> 1);
-    const char *a0 = img + Img<bf16_t, true, ROWS>::chunk_off(k, ch) + 8 * (p & 1);
-    const char *a1 = img + Img<bf16_t, true, ROWS>::chunk_off(k + 4, ch) + 8 * (p & 1);
+    const char *a0 = img + Img<bf16_t, true, ROWS, BK>::chunk_off(k, ch) + 8 * (p & 1);
+    const char *a1 = img + Img<bf16_t, true, ROWS, BK>::chunk_off(k + 4, ch) + 8 * (p & 1);
     const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4 *)(a0));
     const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4 *)(a1));
     typedef __attribute__((ext_vector_type(8))) short i16x8;
@@ -188,8 +196,8 @@ template <bool TR, int ROWS>
 __device__ __forceinline__ float frag_f32(const char *img, int rb, int ks, int lane) {
   const int g = lane >> 4, i = lane & 15;
   const float *f = reinterpret_cast<const float *>(img);
-  if constexpr (!TR) return f[(rb + i) * Img<float, false, ROWS>::LD + ks * 4 + g];
-  else return f[(ks * 4 + g) * Img<float, true, ROWS>::LD + rb + i];
+  if constexpr (!TR) return f[(rb + i) * Img<float, false, ROWS, 16>::LD + ks * 4 + g];
+  else return f[(ks * 4 + g) * Img<float, true, ROWS, 16>::LD + rb + i];
 }
 
 // ---- epilogue helpers ----------------------------------------------------------------------------------------
@@ -317,12 +325,12 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[MI][NI], const GemmP
 }
 
 // ---- the tile body (shared by the plain and the grouped kernel) ------------------------------------------------
-template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN, bool GLDS, int STAGES>
+template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN, bool GLDS, int STAGES, int BK>
 __device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m, const int tile_n, const int bz, const int kslice) {
   constexpr int NT = WM * WN * 64;
-  constexpr int BK = Cfg<T>::BK, KSTEP = Cfg<T>::KSTEP;
+  constexpr int KSTEP = Cfg<T>::KSTEP;
   constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
-  constexpr int A_BYTES = Img<T, TA, BM>::BYTES, B_BYTES = Img<T, TB, BN>::BYTES;
+  constexpr int A_BYTES = Img<T, TA, BM, BK>::BYTES, B_BYTES = Img<T, TB, BN, BK>::BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -352,9 +360,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m,
       if constexpr (sizeof(T) == 2) {
         bf16x8 af[MI], bf[NI];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = frag_bf16<TA, BM>(ia, wm * WTM + i * 16, ks, lane);
+        for (int i = 0; i < MI; ++i) af[i] = frag_bf16<TA, BM, BK>(ia, wm * WTM + i * 16, ks, lane);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bf[j] = frag_bf16<TB, BN>(ib, wn * WTN + j * 16, ks, lane);
+        for (int j = 0; j < NI; ++j) bf[j] = frag_bf16<TB, BN, BK>(ib, wn * WTN + j * 16, ks, lane);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -378,8 +386,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m,
   if constexpr (GLDS) {
     // LDS-DMA pipeline: tile t+1 streams into the other stage while tile t is multiplied; a counted vmcnt leaves
     // the newest tile's pieces in flight across the raw barrier (a __syncthreads() would drain them).
-    using GA = GStage<TA, BM, NT>;
-    using GB = GStage<TB, BN, NT>;
+    using GA = GStage<TA, BM, NT, BK>;
+    using GB = GStage<TB, BN, NT, BK>;
     constexpr int INFLIGHT = GA::PER_WAVE + GB::PER_WAVE;   // LDS-DMA pieces per wave and tile
     static_assert(INFLIGHT == 8 || INFLIGHT == 6 || INFLIGHT == 4, "add the vmcnt literal for this tile shape");
     auto wait_all_but_newest_tile = [] {
@@ -434,8 +442,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m,
       __builtin_amdgcn_s_barrier();   // the split-K epilogue reuses the ring as scratch
     }
   } else {
-    Stage<T, TA, BM, NT> sa;
-    Stage<T, TB, BN, NT> sb;
+    Stage<T, TA, BM, NT, BK> sa;
+    Stage<T, TB, BN, NT, BK> sb;
     sa.load(rsA, lda, m0, kbeg, p.M, kend, tid);
     sb.load(rsB, ldb, n0, kbeg, p.N, kend, tid);
     sa.store(smem, tid);
@@ -503,11 +511,11 @@ __device__ __forceinline__ void map_tile(int nblk, int bid, int tiles_m, int &ti
   tile_n = in_g / gsz;
 }
 
-template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN, bool GLDS, int STAGES>
-__global__ __launch_bounds__(WM *WN * 64) void gemm_kernel(const GemmParams p) {
+template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN, bool GLDS, int STAGES, int BK, int MINW>
+__global__ __launch_bounds__(WM *WN * 64, MINW) void gemm_kernel(const GemmParams p) {
   int tile_m, tile_n;
   map_tile(gridDim.x, blockIdx.x, p.tiles_m, tile_m, tile_n);
-  gemm_body<T, TC, EPI, TA, TB, BM, BN, WM, WN, GLDS, STAGES>(p, tile_m, tile_n, blockIdx.z, blockIdx.y);
+  gemm_body<T, TC, EPI, TA, TB, BM, BN, WM, WN, GLDS, STAGES, BK>(p, tile_m, tile_n, blockIdx.z, blockIdx.y);
 }
 
 // ---- grouped weight-gradient GEMM: many independent (dY^T . X) problems in ONE launch ------------------------------
@@ -534,10 +542,11 @@ __global__ __launch_bounds__(256) void gemm_grouped_tn_kernel(const GroupedProbl
   p.batch1 = 1; p.alpha = 1.0f; p.bias = nullptr; p.act = EVP_ACT_NONE; p.aux = nullptr; p.ldaux = 0;
   p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1;
   p.k_per_split = (g.K + 63) / 64 * 64;
-  gemm_body<bf16_t, float, 0, true, true, BM, BN, 2, 2, true, 2>(p, it.tile_m, it.tile_n, 0, 0);
+  gemm_body<bf16_t, float, 0, true, true, BM, BN, 2, 2, true, 2, 64>(p, it.tile_m, it.tile_n, 0, 0);
 }
 
-template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN, bool GLDS, int STAGES>
+template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN, bool GLDS, int STAGES, int BK = Cfg<T>::BK,
+          int MINW = 1>
 int launch(const evp_gemm_desc *d, hipStream_t s) {
   GemmParams p;
   p.M = d->M; p.N = d->N; p.K = d->K;
@@ -551,7 +560,7 @@ int launch(const evp_gemm_desc *d, hipStream_t s) {
   const int tiles_n = (d->N + BN - 1) / BN;
   const int nb = (d->batch0 > 0 ? d->batch0 : 1) * p.batch1;
   // split-K: only for plain f32 outputs without epilogue extras (the weight-gradient GEMMs: few output tiles, long K)
-  constexpr int BKc = Cfg<T>::BK;
+  constexpr int BKc = BK;
   int splitk = d->splitk;
   const bool can_split = d->c_dtype == EVP_F32 && !d->bias && d->act == EVP_ACT_NONE && !d->residual && !d->aux && nb == 1;
   if (splitk == 0) {
@@ -576,8 +585,8 @@ int launch(const evp_gemm_desc *d, hipStream_t s) {
     hipError_t e = hipMemset2DAsync(d->C, (size_t)d->ldc * 4, 0, (size_t)d->N * 4, (size_t)d->M, s);
     if (e != hipSuccess) { evp_set_error("evp_gemm: memset for split-K failed: %s", hipGetErrorString(e)); return EVP_ELAUNCH; }
   }
-  constexpr int smem = STAGES * (Img<T, TA, BM>::BYTES + Img<T, TB, BN>::BYTES);
-  auto k = gemm_kernel<T, TC, EPI, TA, TB, BM, BN, WM, WN, GLDS, STAGES>;
+  constexpr int smem = STAGES * (Img<T, TA, BM, BK>::BYTES + Img<T, TB, BN, BK>::BYTES);
+  auto k = gemm_kernel<T, TC, EPI, TA, TB, BM, BN, WM, WN, GLDS, STAGES, BK, MINW>;
   static bool attr_done = false;  // one flag per instantiation
   if (!attr_done) {
     if (smem > 48 * 1024) {
@@ -612,11 +621,13 @@ template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(cons
   if constexpr (sizeof(T) == 2) {
     if (g_gemm_variant != 2) {
       if (tile == 3) return launch<T, TC, EPI, TA, TB, 256, 128, 4, 2, true, 3>(d, s);   // 8 waves, 144 KiB ring
+      if (tile == 4) return launch<T, TC, EPI, TA, TB, 128, 128, 2, 2, true, 2, 32, 3>(d, s);   // BK 32, 32 KiB: 3+ blocks / CU
+      if (tile == 5) return launch<T, TC, EPI, TA, TB, 128, 128, 2, 2, true, 2, 32, 4>(d, s);   // BK 32, <=128 VGPR: 4 blocks / CU
       if (tile == 1) return launch<T, TC, EPI, TA, TB, 128, 128, 2, 2, true, 2>(d, s);
       return launch<T, TC, EPI, TA, TB, 64, 64, 2, 2, true, 2>(d, s);
     }
   }
-  if (tile == 1 || tile == 3) return launch<T, TC, EPI, TA, TB, 128, 128, 2, 2, false, 2>(d, s);
+  if (tile == 1 || tile >= 3) return launch<T, TC, EPI, TA, TB, 128, 128, 2, 2, false, 2>(d, s);
   return launch<T, TC, EPI, TA, TB, 64, 64, 2, 2, false, 2>(d, s);
 }
 
@@ -649,7 +660,7 @@ template <typename T> int pick_ctype(const evp_gemm_desc *d, hipStream_t s) {
 extern "C" int evp_gemm_grouped_tn_bf16(const void *problems, const void *items, int n_items, void *stream) {
   EVP_CHECK_ARG(problems && items && n_items > 0, EVP_EINVAL, "evp_gemm_grouped_tn_bf16: bad argument");
   auto k = gemm_grouped_tn_kernel<128, 128>;
-  constexpr int smem = 2 * (Img<bf16_t, true, 128>::BYTES + Img<bf16_t, true, 128>::BYTES);
+  constexpr int smem = 2 * (Img<bf16_t, true, 128, 64>::BYTES + Img<bf16_t, true, 128, 64>::BYTES);
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);

@@ -235,6 +235,7 @@ class _DeferredGrads:
         self.w, self.b = [], []
         self.armed = False
         self._pin = {}
+        self.flat_buffers = []      # flat f32 buffers holding the gradients written by the last flush(es)
 
     def arm(self):
         if not self.armed:
@@ -286,12 +287,26 @@ class _DeferredGrads:
         w, b, self.w, self.b = self.w, self.b, [], []
         if w:
             dev = w[0][1].device
+            fresh = [p_ for p_ in dict.fromkeys(t_[0] for t_ in w) if p_.grad is None]
+            if fresh:
+                sizes = [(p_.numel() + 63) // 64 * 64 for p_ in fresh]
+                flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+                o = 0
+                for p_, n_ in zip(fresh, sizes):
+                    p_.grad = flat[o:o + p_.numel()].view_as(p_)
+                    o += n_
+                self.flat_buffers.append(flat)
+            seen = set()
             probs = np.zeros(len(w), dtype=np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i4"), ("N", "<i4"),
                                                       ("K", "<i4"), ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4"),
                                                       ("acc", "<i4"), ("pad", "<i4")]))
             items = []
+            fresh_ids = {id(p_) for p_ in fresh}
             for i, (param, dy, x, n_out, k_in, rows) in enumerate(w):
                 gt, acc = self._target(param)
+                if id(param) in fresh_ids and id(param) not in seen:
+                    acc = 0                      # first write into the freshly allocated flat slice
+                seen.add(id(param))
                 probs[i] = (dy.data_ptr(), x.data_ptr(), gt.data_ptr(), n_out, k_in, rows, n_out, k_in, k_in, acc, 0)
                 tm, tn = (n_out + 127) // 128, (k_in + 127) // 128
                 t = np.zeros((tn, tm, 4), dtype=np.int32)
@@ -309,7 +324,7 @@ class _DeferredGrads:
                                                       ("dtype", "<i4"), ("pad", "<i4")]))
             items = []
             # fresh bias gradients are slices of ONE flat buffer zeroed by one memset (they accumulate with atomics)
-            fresh = [p_ for p_, _ in b if p_.grad is None]
+            fresh = [p_ for p_ in dict.fromkeys(t_[0] for t_ in b) if p_.grad is None]
             if fresh:
                 sizes = [(p_.numel() + 63) // 64 * 64 for p_ in fresh]
                 flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
@@ -317,6 +332,7 @@ class _DeferredGrads:
                 for p_, n_ in zip(fresh, sizes):
                     p_.grad = flat[o:o + p_.numel()].view_as(p_)
                     o += n_
+                self.flat_buffers.append(flat)
             for i, (param, x2d) in enumerate(b):
                 M, N = x2d.shape
                 gt, acc = self._target(param)
@@ -344,6 +360,13 @@ def set_deferred_grads(flag):
 def flush_deferred_grads():
     if _deferred.w or _deferred.b:
         _deferred.flush()
+
+
+def take_deferred_flat_buffers():
+    """Flat f32 buffers that hold the deferred gradients written since the last call (their parameters' .grad are
+    views into them): the data-parallel reducer all-reduces these in place."""
+    out, _deferred.flat_buffers = _deferred.flat_buffers, []
+    return out
 
 
 def _wgrad(dy, x, n_out, k_in, rows, param=None, shape=None):

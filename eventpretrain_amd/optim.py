@@ -47,7 +47,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 raise _lib.EvpError("FusedAdamW: parameters must be contiguous float32 tensors in device memory")
             st = self.state[p]
             if "exp_avg" not in st:
-                st["step"] = torch.zeros((), dtype=torch.float32)
+                st["step"] = torch.tensor(float(self._step))      # informational; the kernel uses self._step
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         numel = np.array([p.numel() for _, p in act], dtype=np.int64)
@@ -79,6 +79,9 @@ class FusedAdamW(torch.optim.Optimizer):
         T["h_wd"] = torch.zeros(n, dtype=torch.float32).pin_memory()
         T["h_lr"] = torch.zeros(n, dtype=torch.float32).pin_memory()
         T["h_hyper"] = torch.zeros(4, dtype=torch.float32).pin_memory()
+        for k in ("grads", "lp", "wd", "lr", "hyper"):       # numpy views of the pinned tables: cheap element writes
+            T["n_" + k] = T["h_" + k].numpy()
+        T["group_of"] = np.array([gi for gi, _ in act], dtype=np.int64)
         return T
 
     def refresh(self, advance=True):
@@ -96,12 +99,14 @@ class FusedAdamW(torch.optim.Optimizer):
             self._tabs, self._sig = self._build(act), sig
         T = self._tabs
         self._act = act
+        ng, nl = T["n_grads"], T["n_lp"]
         for i, (gi, p) in enumerate(act):
-            if p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+            g = p.grad
+            if g.dtype != torch.float32 or not g.is_contiguous():
                 raise _lib.EvpError("FusedAdamW: gradients must be contiguous float32")
-            T["h_grads"][i] = p.grad.data_ptr()
+            ng[i] = g.data_ptr()
             sh = getattr(p, "_evp_lp", None)
-            T["h_lp"][i] = sh.data_ptr() if (sh is not None and getattr(p, "_evp_lp_version", -1) == p._version) else 0
+            nl[i] = sh.data_ptr() if (sh is not None and getattr(p, "_evp_lp_version", -1) == p._version) else 0
         self.stage_scalars(advance)
         for k in ("grads", "lp", "wd", "lr", "hyper"):
             T[k].copy_(T["h_" + k], non_blocking=True)
@@ -113,17 +118,11 @@ class FusedAdamW(torch.optim.Optimizer):
         if advance:
             self._step += 1
         b1, b2 = self.param_groups[0]["betas"]
-        for i, (gi, p) in enumerate(self._act):
-            g = self.param_groups[gi]
-            T["h_wd"][i] = g["weight_decay"]
-            T["h_lr"][i] = g["lr"]
-            if advance:
-                self.state[p]["step"] += 1
+        go = T["group_of"]
+        T["n_wd"][:] = np.array([g["weight_decay"] for g in self.param_groups], dtype=np.float32)[go]
+        T["n_lr"][:] = np.array([g["lr"] for g in self.param_groups], dtype=np.float32)[go]
         step = max(self._step, 1)
-        T["h_hyper"][0] = 1.0 - b1 ** step
-        T["h_hyper"][1] = math.sqrt(1.0 - b2 ** step)
-        T["h_hyper"][2] = self.grad_scale
-        T["h_hyper"][3] = 1.0
+        T["n_hyper"][:] = (1.0 - b1 ** step, math.sqrt(1.0 - b2 ** step), self.grad_scale, 1.0)
 
     def launch(self):
         """Device side of a step (graph-capturable): one evp_adamw_multi over all chunks."""

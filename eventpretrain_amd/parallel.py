@@ -1,66 +1,71 @@
 """Data-parallel gradient reduction for one process per GPU: RCCL (torch.distributed backend "nccl" on ROCm) over
 xGMI. Replaces the reference's DistributedDataParallel wrap (main_pretrain.py:319; collective C1 in SURVEY.md 2.2).
 
-Gradients are packed into a few large flat f32 buckets in reverse parameter order (the order backward produces
-them); each bucket's SUM all-reduce is issued asynchronously from a post-accumulate-grad hook as soon as its last
-gradient has landed, so the collective overlaps the rest of backward. Buckets are large (default 64 MB): xGMI is
-point-to-point and a ring step is per-link bound, so few big messages beat many 25 MB ones. The 1/world mean is
-folded into FusedAdamW's grad_scale (no extra pass). Buffers (MoCo queue, BN statistics) are NOT broadcast each
-forward -- the reference's accidental C2 broadcast is deliberately not reproduced.
+Where the gradients live decides the shape of the collective:
+  * weight / bias gradients are written by the deferred grouped launches (ops._DeferredGrads) straight into a few
+    large flat f32 buffers (`param.grad` are views) -> they are SUM-all-reduced IN PLACE, no packing pass;
+  * the remaining small gradients (LayerNorm / BatchNorm affine, mask token) are packed into one small flat bucket
+    with a multi-tensor copy and reduced with a single call.
+Few large messages suit xGMI (point-to-point links, a ring step is per-link bound) better than DDP's 25 MB buckets.
+The 1/world mean is folded into FusedAdamW's grad_scale. Buffers (MoCo queue, BN statistics) are NOT broadcast each
+forward: the reference's accidental per-forward DDP buffer broadcast is deliberately not
+reproduced. `make_static_plan()` freezes the buffer set for HIP-graph replay (gradient addresses are then static).
 """
 import torch
 import torch.distributed as dist
+
+
+class _Plan:
+    def __init__(self, flats, others, bucket, views, group):
+        self.flats, self.others, self.bucket, self.views, self.group = flats, others, bucket, views, group
+        self.srcs = [p.grad for p in others]        # where backward writes the small gradients
+        for p, v in zip(others, views):              # the optimizer reads the reduced bucket views
+            p.grad = v
+
+    def run(self):
+        works = [dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for f in self.flats]
+        if self.others:
+            torch._foreach_copy_(self.views, self.srcs)
+            works.append(dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in works:
+            w.wait()                                  # stream wait, no host sync
 
 
 class BucketedGradReducer:
     def __init__(self, params, bucket_mb=64.0, process_group=None):
         self.group = process_group
         self.params = [p for p in params if p.requires_grad]
-        cap = int(bucket_mb * 1024 * 1024 / 4)
-        self.buckets = []          # dict(buf, params=[(p, off, n)], pending, work)
-        cur, cur_n = [], 0
-        for p in reversed(self.params):
-            n = p.numel()
-            if cur and cur_n + n > cap:
-                self._close(cur, cur_n)
-                cur, cur_n = [], 0
-            cur.append((p, cur_n, n))
-            cur_n += (n + 63) // 64 * 64          # keep every slice 256-byte aligned
-        if cur:
-            self._close(cur, cur_n)
-        self._where = {}
-        for bi, b in enumerate(self.buckets):
-            for (p, off, n) in b["params"]:
-                self._where[p] = (bi, off, n)
-                p.register_post_accumulate_grad_hook(self._hook)
-        self._reset()
+        self.bucket_mb = bucket_mb                    # kept for API compatibility; flat buffers are reduced whole
+        self._bucket, self._sig = None, None
 
-    def _close(self, items, total):
-        dev = items[0][0].device
-        self.buckets.append(dict(buf=torch.zeros(total, dtype=torch.float32, device=dev), params=list(items), work=None))
+    def _collect(self):
+        from . import ops
+        ops.flush_deferred_grads()
+        flats = ops.take_deferred_flat_buffers()
+        spans = [(f.data_ptr(), f.data_ptr() + f.numel() * f.element_size()) for f in flats]
 
-    def _reset(self):
-        for b in self.buckets:
-            b["pending"] = len(b["params"])
-            b["work"] = None
+        def in_flat(t):
+            a = t.data_ptr()
+            return any(lo <= a < hi for lo, hi in spans)
 
-    def _hook(self, p):
-        bi, off, n = self._where[p]
-        b = self.buckets[bi]
-        view = b["buf"][off:off + n].view_as(p)
-        view.copy_(p.grad)                 # D2D copy into the bucket; the optimizer then reads the reduced view
-        p.grad = view
-        b["pending"] -= 1
-        if b["pending"] == 0:
-            b["work"] = dist.all_reduce(b["buf"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        others = [p for p in self.params if p.grad is not None and not in_flat(p.grad)]
+        bucket = views = None
+        if others:
+            sig = tuple((id(p), p.numel()) for p in others)
+            if sig != self._sig:
+                sizes = [(p.numel() + 63) // 64 * 64 for p in others]
+                self._bucket = torch.zeros(sum(sizes), dtype=torch.float32, device=others[0].device)
+                self._offs = [sum(sizes[:i]) for i in range(len(sizes))]
+                self._sig = sig
+            bucket = self._bucket
+            views = [bucket[o:o + p.numel()].view_as(p) for o, p in zip(self._offs, others)]
+        return flats, others, bucket, views
 
     def finish(self):
-        """Call after backward: flush buckets whose parameters got no gradient this step, wait for all collectives
-        (on the current stream, no host sync), re-arm."""
-        for b in self.buckets:
-            if b["work"] is None and b["pending"] < len(b["params"]):
-                b["work"] = dist.all_reduce(b["buf"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        for b in self.buckets:
-            if b["work"] is not None:
-                b["work"].wait()
-        self._reset()
+        """Eager mode: call after every backward. All-reduces (SUM) every gradient, waits on the current stream."""
+        _Plan(*self._collect(), self.group).run()
+
+    def make_static_plan(self):
+        """HIP-graph mode: call once after the captured backward; the returned plan's run() reduces the same buffers
+        after every replay."""
+        return _Plan(*self._collect(), self.group)
