@@ -54,6 +54,12 @@ SIGNATURES = {
     "evp_patchify": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "evp_embed_post_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "evp_embed_post_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp],
+    "evp_add_rows_gather_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "evp_patchify_nhwc": [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp],
+    "evp_unpatchify_nhwc": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "evp_dwconv5x5_fwd": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "evp_dwconv5x5_bwd_nslab": [_i, _i, _i],
+    "evp_dwconv5x5_bwd": [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "evp_unshuffle_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "evp_unshuffle_bwd": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "evp_rec_loss": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -76,7 +82,7 @@ SIGNATURES = {
     "evp_abi_version": [],
 }
 _OTHER_RESTYPE = {"evp_last_error": C.c_char_p, "evp_target_arch": C.c_char_p}
-_NO_STATUS = {"evp_gemm_set_variant", "evp_attention_fused_supported", "evp_layernorm_bwd_nblk", "evp_colsum_nblk", "evp_batchnorm_nblk", "evp_abi_version"}
+_NO_STATUS = {"evp_dwconv5x5_bwd_nslab", "evp_gemm_set_variant", "evp_attention_fused_supported", "evp_layernorm_bwd_nblk", "evp_colsum_nblk", "evp_batchnorm_nblk", "evp_abi_version"}
 
 _lib = None
 

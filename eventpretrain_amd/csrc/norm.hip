@@ -330,14 +330,14 @@ __global__ __launch_bounds__(256) void embed_post_fwd_kernel(const float *y, con
     const float rs = 1.0f / sqrtf(var + eps);
     if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
     const int64_t tok = ids_keep ? ids_keep[r] : (r % L);
-    const float *pr = pos + tok * D;
+    const float *pr = pos ? pos + tok * D : nullptr;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int c = lane + 64 * i;
       if (c * 4 < D) {
         const float4 g = *reinterpret_cast<const float4 *>(gamma + c * 4);
         const float4 b = *reinterpret_cast<const float4 *>(beta + c * 4);
-        const float4 pe = *reinterpret_cast<const float4 *>(pr + c * 4);
+        const float4 pe = pr ? *reinterpret_cast<const float4 *>(pr + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 o;
         o.x = gelu_f((row.v[i].x - mu) * rs * g.x + b.x) + pe.x;
         o.y = gelu_f((row.v[i].y - mu) * rs * g.y + b.y) + pe.y;
@@ -584,7 +584,7 @@ extern "C" int evp_colsum_grouped(const void *problems, const void *items, int n
 extern "C" int evp_embed_post_fwd(const float *y, const float *gamma, const float *beta, const float *pos,
                                   const int64_t *ids_keep, int B, int n_keep, int L, int D, float eps, float *out, float *mean,
                                   float *rstd, void *stream) {
-  EVP_CHECK_ARG(y && gamma && beta && pos && out && mean && rstd, EVP_EINVAL, "evp_embed_post_fwd: null pointer");
+  EVP_CHECK_ARG(y && gamma && beta && out && mean && rstd, EVP_EINVAL, "evp_embed_post_fwd: null pointer");
   EVP_CHECK_ARG(B > 0 && n_keep > 0 && n_keep <= L && D > 0 && D % 4 == 0 && D <= 4096, EVP_ESHAPE, "evp_embed_post_fwd: bad shape");
   hipStream_t s = (hipStream_t)stream;
   const int64_t M = (int64_t)B * n_keep;

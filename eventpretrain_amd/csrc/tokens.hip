@@ -103,6 +103,18 @@ __global__ __launch_bounds__(256) void unshuffle_fwd_kernel(const float *emb, co
     *reinterpret_cast<float4 *>(o + d) = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
   }
 }
+// out[b,j,:] = x[b,j,:] + table[ids[b,j] (or j), :]
+__global__ __launch_bounds__(256) void add_rows_gather_kernel(const float *x, const float *table, const int64_t *ids, int n, int L, int D,
+                                                             float *out) {
+  const int64_t row = blockIdx.x;
+  const int64_t tok = ids ? ids[row] : (row % L);
+  const float *s = x + row * D, *t = table + tok * D;
+  float *o = out + row * D;
+  for (int d = threadIdx.x * 4; d < D; d += blockDim.x * 4) {
+    const float4 a = *reinterpret_cast<const float4 *>(s + d), q = *reinterpret_cast<const float4 *>(t + d);
+    *reinterpret_cast<float4 *>(o + d) = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
+  }
+}
 // demb[b, ids_restore[b,l], :] = g[b,l,:] for kept positions (ids_restore is a permutation: no write conflicts)
 __global__ __launch_bounds__(256) void unshuffle_bwd_scatter(const float *g, const int64_t *ids_restore, int n_keep, int L, int D,
                                                              float *demb) {
@@ -234,6 +246,16 @@ extern "C" int evp_patchify(const float *x, const int64_t *ids_keep, int B, int 
   if (dtype == EVP_F32) hipLaunchKernelGGL(patchify_kernel<float>, dim3(B * n_keep), dim3(256), 0, s, x, ids_keep, C, H, W, patch, n_keep, (float *)cols);
   else hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(B * n_keep), dim3(256), 0, s, x, ids_keep, C, H, W, patch, n_keep, (bf16_t *)cols);
   EVP_CHECK_LAUNCH("evp_patchify");
+  return EVP_OK;
+}
+
+extern "C" int evp_add_rows_gather_f32(const float *x, const float *table, const int64_t *ids, int B, int n, int L, int D, float *out,
+                                       void *stream) {
+  EVP_CHECK_ARG(x && table && out, EVP_EINVAL, "evp_add_rows_gather_f32: null pointer");
+  EVP_CHECK_ARG(B > 0 && n > 0 && L > 0 && D % 4 == 0 && (ids || n == L), EVP_ESHAPE, "evp_add_rows_gather_f32: bad shape");
+  hipLaunchKernelGGL(add_rows_gather_kernel, dim3(B * n), dim3(D / 4 < 256 ? ((D / 4 + 63) / 64) * 64 : 256), 0, (hipStream_t)stream, x, table,
+                     ids, n, L, D, out);
+  EVP_CHECK_LAUNCH("evp_add_rows_gather_f32");
   return EVP_OK;
 }
 

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ..backbone import vit
+from ..backbone import convvit, vit
 from ..backbone.vit import init_linear_and_norm
 from ..sub_module.mlp_head import _build_mlp_2d, run_mlp_2d
 from . import pr_rec_decoder
@@ -34,9 +34,13 @@ class PrHubModel(nn.Module):
             if args.model_size not in factory:
                 raise ValueError(args.model_size)
             self.backbone = vit.__dict__[factory[args.model_size]](**common)
-        elif args.backbone_type in ("convvit", "swin"):
-            raise NotImplementedError(f"backbone_type={args.backbone_type}: not built yet on the MI355X path "
-                                      "(DESIGN.md, scope table rows a14/a15)")
+        elif args.backbone_type == "convvit":
+            factory = {"small": "convvit_small_patch16", "base": "convvit_base_patch16"}
+            if args.model_size not in factory:
+                raise ValueError(args.model_size)
+            self.backbone = convvit.__dict__[factory[args.model_size]](**common)
+        elif args.backbone_type == "swin":
+            raise NotImplementedError("backbone_type=swin: not built yet on the MI355X path (DESIGN.md, scope row a15)")
         else:
             raise ValueError(args.backbone_type)
 

@@ -496,7 +496,7 @@ class PatchEmbedFn(torch.autograd.Function):
         out = torch.empty(M, D, dtype=torch.float32, device=dev)
         mean = torch.empty(M, dtype=torch.float32, device=dev)
         rstd = torch.empty(M, dtype=torch.float32, device=dev)
-        pos2d = _chk(pos.detach().view(L, D), torch.float32)
+        pos2d = None if pos is None else _chk(pos.detach().view(L, D), torch.float32)
         call("evp_embed_post_fwd", ptr(y), ptr(gamma), ptr(beta), ptr(pos2d), ptr(ids_keep), B, n_keep, L, D, 1e-5,
              ptr(out), ptr(mean), ptr(rstd), stream_ptr())
         ctx.save_for_backward(cols, y, gamma, beta, mean, rstd)
@@ -862,3 +862,204 @@ def enqueue_keys(queue, keys, ptr_):
     B, L, C_ = keys.shape
     call("evp_enqueue_keys", ptr(_chk(queue, torch.float32)), ptr(_chk(keys.contiguous(), torch.float32)), int(ptr_), B, L, C_,
          queue.shape[2], stream_ptr())
+
+
+# ----------------------------------------------------------------------------------------------------- ConvViT stages
+class PatchEmbedNHWCFn(torch.autograd.Function):
+    """PatchEmbed (Conv2d k=s=p -> LayerNorm(eps 1e-5) -> GELU, vit_block.py:60-68) on a channels-last token map
+    x (B, H*W, C) f32, optionally restricted to ids_keep and with a positional table: the conv is a GEMM on the
+    gathered patch matrix (convvit.py:22-25,141,153)."""
+
+    @staticmethod
+    def forward(ctx, x, ids_keep, w, b, gamma, beta, pos, patch, H, W):
+        B = x.shape[0]
+        Cin = x.shape[-1]
+        D = w.shape[0]
+        L = (H // patch) * (W // patch)
+        n_keep = L if ids_keep is None else ids_keep.shape[1]
+        Kc = Cin * patch * patch
+        M = B * n_keep
+        T = _compute_dtype
+        dev = x.device
+        xin = _chk(x.detach().contiguous(), torch.float32)
+        cols = torch.empty(M, Kc, dtype=T, device=dev)
+        call("evp_patchify_nhwc", ptr(xin), ptr(ids_keep), B, H, W, Cin, patch, n_keep, ptr(cols), dt(cols), stream_ptr())
+        wl = lp_weight(w).view(D, Kc)
+        y = torch.empty(M, D, dtype=torch.float32, device=dev)
+        gemm(cols, wl, y, M=M, N=D, K=Kc, bias=b)
+        out = torch.empty(M, D, dtype=torch.float32, device=dev)
+        mean = torch.empty(M, dtype=torch.float32, device=dev)
+        rstd = torch.empty(M, dtype=torch.float32, device=dev)
+        pos2d = None if pos is None else _chk(pos.detach().view(L, D), torch.float32)
+        call("evp_embed_post_fwd", ptr(y), ptr(gamma), ptr(beta), ptr(pos2d), ptr(ids_keep), B, n_keep, L, D, 1e-5, ptr(out),
+             ptr(mean), ptr(rstd), stream_ptr())
+        ctx.save_for_backward(cols, y, gamma, beta, mean, rstd, wl, ids_keep)
+        ctx.cfg = (B, H, W, Cin, D, patch, n_keep, Kc, tuple(w.shape), x.requires_grad)
+        ctx.prm = (w, b)
+        return out.view(B, n_keep, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        cols, y, gamma, beta, mean, rstd, wl, ids_keep = ctx.saved_tensors
+        B, H, W, Cin, D, patch, n_keep, Kc, wshape, need_dx = ctx.cfg
+        M = B * n_keep
+        dev = g.device
+        g = _chk(g.contiguous(), torch.float32).view(M, D)
+        dy = torch.empty(M, D, dtype=cols.dtype, device=dev)
+        dgamma = torch.empty(D, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(D, dtype=torch.float32, device=dev)
+        nb = call("evp_layernorm_bwd_nblk", M)
+        ws = torch.empty(2 * nb * D, dtype=torch.float32, device=dev)
+        call("evp_embed_post_bwd", ptr(g), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), M, D, ptr(dy), dt(dy), ptr(dgamma),
+             ptr(dbeta), ptr(ws), stream_ptr())
+        dw = _wgrad(dy, cols, D, Kc, M, ctx.prm[0], wshape) if ctx.needs_input_grad[2] else None
+        db = _bgrad(dy, ctx.prm[1]) if ctx.needs_input_grad[3] else None
+        dx = None
+        if need_dx:
+            dcols = torch.empty(M, Kc, dtype=cols.dtype, device=dev)
+            gemm(dy, wl, dcols, M=M, N=Kc, K=D, trans_b=True, ldb=Kc)
+            dx = torch.empty(B, H * W, Cin, dtype=torch.float32, device=dev)
+            call("evp_unpatchify_nhwc", ptr(dcols), dt(dcols), ptr(ids_keep), B, H, W, Cin, patch, n_keep, 0, ptr(dx), stream_ptr())
+        return dx, None, dw, db, dgamma, dbeta, None, None, None, None
+
+
+class StridedConvTokensFn(torch.autograd.Function):
+    """Conv2d(k=s=p) + bias on a channels-last map, evaluated only at the tokens in ids_keep (the multi-scale fusion
+    convs stage1/2_output_decode followed by the gather, convvit.py:137-140,149-151)."""
+
+    @staticmethod
+    def forward(ctx, x, ids_keep, w, b, patch, H, W):
+        B, _, Cin = x.shape
+        D = w.shape[0]
+        L = (H // patch) * (W // patch)
+        n_keep = L if ids_keep is None else ids_keep.shape[1]
+        Kc = Cin * patch * patch
+        M = B * n_keep
+        T = _compute_dtype
+        dev = x.device
+        cols = torch.empty(M, Kc, dtype=T, device=dev)
+        call("evp_patchify_nhwc", ptr(_chk(x.detach().contiguous(), torch.float32)), ptr(ids_keep), B, H, W, Cin, patch, n_keep,
+             ptr(cols), dt(cols), stream_ptr())
+        wl = lp_weight(w).view(D, Kc)
+        y = torch.empty(M, D, dtype=torch.float32, device=dev)
+        gemm(cols, wl, y, M=M, N=D, K=Kc, bias=b)
+        ctx.save_for_backward(cols, wl, ids_keep)
+        ctx.cfg = (B, H, W, Cin, D, patch, n_keep, Kc, tuple(w.shape))
+        ctx.prm = (w, b)
+        return y.view(B, n_keep, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        cols, wl, ids_keep = ctx.saved_tensors
+        B, H, W, Cin, D, patch, n_keep, Kc, wshape = ctx.cfg
+        M = B * n_keep
+        dev = g.device
+        g2 = _chk(g.contiguous(), torch.float32).view(M, D)
+        gl = cast(g2, cols.dtype)
+        dw = _wgrad(gl, cols, D, Kc, M, ctx.prm[0], wshape) if ctx.needs_input_grad[2] else None
+        db = _bgrad(g2, ctx.prm[1]) if ctx.needs_input_grad[3] else None
+        dcols = torch.empty(M, Kc, dtype=cols.dtype, device=dev)
+        gemm(gl, wl, dcols, M=M, N=Kc, K=D, trans_b=True, ldb=Kc)
+        dx = torch.empty(B, H * W, Cin, dtype=torch.float32, device=dev)
+        call("evp_unpatchify_nhwc", ptr(dcols), dt(dcols), ptr(ids_keep), B, H, W, Cin, patch, n_keep, 0, ptr(dx), stream_ptr())
+        return dx, None, dw, db, None, None, None
+
+
+class AddPosGatherFn(torch.autograd.Function):
+    """x[b,j,:] + pos[ids[b,j],:] (pos is a frozen table)."""
+
+    @staticmethod
+    def forward(ctx, x, pos, ids):
+        B, n, D = x.shape
+        L = pos.shape[-2]
+        out = torch.empty(B, n, D, dtype=torch.float32, device=x.device)
+        call("evp_add_rows_gather_f32", ptr(_chk(x.detach().contiguous(), torch.float32)), ptr(_chk(pos.detach().view(L, D))),
+             ptr(ids), B, n, L, D, ptr(out), stream_ptr())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None
+
+
+class ConvBlockFn(torch.autograd.Function):
+    """ConvMAE-style block on a channels-last token map (conv_block.py:41-51):
+    x = x + conv2(dw5x5(keep * conv1(LN(x)))); x = x + fc2(GELU(fc1(LN(x)))), 1x1 convs as GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, c1w, c1b, aw, ab, c2w, c2b, n2w, n2b, f1w, f1b, f2w, f2b, mask, mask_scale, H, W):
+        B, HW, Cc = x.shape
+        M = B * HW
+        T = _compute_dtype
+        dev = x.device
+        x2d = _chk(x.detach().contiguous(), torch.float32).view(M, Cc)
+        w1, w2, wf1, wf2 = (lp_weight(c1w).view(Cc, Cc), lp_weight(c2w).view(Cc, Cc), lp_weight(f1w).view(-1, Cc),
+                            lp_weight(f2w).view(Cc, -1))
+        Hd = wf1.shape[0]
+        ln1, mean1, rstd1 = layernorm_fwd(x2d, n1w, n1b, 1e-5, T)
+        c1 = torch.empty(M, Cc, dtype=T, device=dev)
+        gemm(ln1, w1, c1, M=M, N=Cc, K=Cc, bias=c1b)
+        a = torch.empty(M, Cc, dtype=T, device=dev)
+        awf = _chk(aw.detach().contiguous(), torch.float32)
+        call("evp_dwconv5x5_fwd", ptr(c1), dt(c1), ptr(mask), int(mask_scale), ptr(awf), ptr(ab), B, H, W, Cc, ptr(a), stream_ptr())
+        x1 = torch.empty(M, Cc, dtype=torch.float32, device=dev)
+        gemm(a, w2, x1, M=M, N=Cc, K=Cc, bias=c2b, residual=x2d)
+        ln2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, 1e-5, T)
+        h_pre = torch.empty(M, Hd, dtype=T, device=dev)
+        h_act = torch.empty(M, Hd, dtype=T, device=dev)
+        gemm(ln2, wf1, h_act, M=M, N=Hd, K=Cc, bias=f1b, act=ACT_GELU, aux=h_pre)
+        x2 = torch.empty(M, Cc, dtype=torch.float32, device=dev)
+        gemm(h_act, wf2, x2, M=M, N=Cc, K=Hd, bias=f2b, residual=x1)
+        ctx.save_for_backward(x2d, n1w, n2w, mean1, rstd1, ln1, c1, a, x1, mean2, rstd2, ln2, h_pre, h_act, w1, w2, wf1, wf2, awf, mask)
+        ctx.cfg = (B, H, W, Cc, Hd, int(mask_scale), tuple(aw.shape))
+        ctx.prm = (c1w, c1b, c2w, c2b, f1w, f1b, f2w, f2b)
+        return x2.view(B, HW, Cc)
+
+    @staticmethod
+    def backward(ctx, g2):
+        (x2d, n1w, n2w, mean1, rstd1, ln1, c1, a, x1, mean2, rstd2, ln2, h_pre, h_act, w1, w2, wf1, wf2, awf, mask) = ctx.saved_tensors
+        B, H, W, Cc, Hd, mask_scale, awshape = ctx.cfg
+        c1w_, c1b_, c2w_, c2b_, f1w_, f1b_, f2w_, f2b_ = ctx.prm
+        need = ctx.needs_input_grad
+        M = B * H * W
+        T = c1.dtype
+        bf = T == torch.bfloat16
+        dev = g2.device
+        g2 = _chk(g2.contiguous(), torch.float32).view(M, Cc)
+        g2_lp = cast(g2, T)
+        db2 = _bgrad(g2, f2b_) if need[14] else None
+        dwf2 = _wgrad(g2_lp, h_act, Cc, Hd, M, f2w_, tuple(f2w_.shape)) if need[13] else None
+        dh_pre = torch.empty(M, Hd, dtype=T, device=dev)
+        gemm(g2_lp, wf2, dh_pre, M=M, N=Hd, K=Cc, trans_b=True, ldb=Hd, act=ACT_DGELU, aux=h_pre)
+        db1 = _bgrad(dh_pre, f1b_) if need[12] else None
+        dwf1 = _wgrad(dh_pre, ln2, Hd, Cc, M, f1w_, tuple(f1w_.shape)) if need[11] else None
+        dln2 = torch.empty(M, Cc, dtype=T, device=dev)
+        gemm(dh_pre, wf1, dln2, M=M, N=Cc, K=Hd, trans_b=True, ldb=Cc)
+        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf)
+        if not bf:
+            g1_lp = g1
+        # conv branch
+        dbc2 = _bgrad(g1, c2b_) if need[8] else None
+        dwc2 = _wgrad(g1_lp, a, Cc, Cc, M, c2w_, tuple(c2w_.shape)) if need[7] else None
+        da = torch.empty(M, Cc, dtype=T, device=dev)
+        gemm(g1_lp, w2, da, M=M, N=Cc, K=Cc, trans_b=True, ldb=Cc)
+        dc1 = torch.empty(M, Cc, dtype=T, device=dev)
+        daw = torch.empty(Cc, 25, dtype=torch.float32, device=dev)
+        dab = torch.empty(Cc, dtype=torch.float32, device=dev)
+        ns = call("evp_dwconv5x5_bwd_nslab", B, H, W)
+        ws = torch.empty(ns * 26 * Cc, dtype=torch.float32, device=dev)
+        call("evp_dwconv5x5_bwd", ptr(da), ptr(c1), dt(c1), ptr(mask), mask_scale, ptr(awf), B, H, W, Cc, ptr(dc1), ptr(daw), ptr(dab),
+             ptr(ws), stream_ptr())
+        dbc1 = _bgrad(dc1, c1b_) if need[4] else None
+        dwc1 = _wgrad(dc1, ln1, Cc, Cc, M, c1w_, tuple(c1w_.shape)) if need[3] else None
+        dln1 = torch.empty(M, Cc, dtype=T, device=dev)
+        gemm(dc1, w1, dln1, M=M, N=Cc, K=Cc, trans_b=True, ldb=Cc)
+        g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1)
+        return (g0.view(B, H * W, Cc), dn1w, dn1b, dwc1, dbc1, daw.view(awshape), dab, dwc2, dbc2, dn2w, dn2b, dwf1, db1, dwf2, db2,
+                None, None, None, None)
+
+
+def conv_block(x, blk, H, W, mask=None, mask_scale=1):
+    return ConvBlockFn.apply(x, blk.norm1.weight, blk.norm1.bias, blk.conv1.weight, blk.conv1.bias, blk.attn.weight, blk.attn.bias,
+                             blk.conv2.weight, blk.conv2.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight,
+                             blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, mask, mask_scale, H, W)

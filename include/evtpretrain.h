@@ -167,6 +167,31 @@ int evp_embed_post_bwd(const float *g, const float *y, const float *gamma, const
                        const float *rstd, int64_t M, int D, void *dy, int dy_dtype, float *dgamma, float *dbeta,
                        float *workspace, void *stream);
 
+/* out[b,j,:] = x[b,j,:] + table[ids[b,j],:] (ids NULL: j): the `x + pos_embed` then gather of convvit.py:158-159 with
+ * the gather done first. x/out float32 [B,n,D], table float32 [L,D]. */
+int evp_add_rows_gather_f32(const float *x, const float *table, const int64_t *ids, int B, int n, int L, int D, float *out,
+                            void *stream);
+
+/* ------------------------------------------------------------------------------------------------ K17 ConvViT stages
+ * Stage-1/2 feature maps are kept channels-last ([B,H,W,C] float32 tokens). A Conv2d with kernel = stride = p
+ * (PatchEmbed convvit.py:20-25; fusion convs :48-49) is a GEMM on the gathered patch matrix:
+ * cols[(b,j), c*p*p + py*p + px] = x[b, gy*p+py, gx*p+px, c] for token ids_keep[b,j] (NULL = all tokens in order);
+ * evp_unpatchify_nhwc is its adjoint (zero-fills dropped patches unless accumulate). */
+int evp_patchify_nhwc(const float *x, const int64_t *ids_keep, int B, int H, int W, int C, int patch, int n_keep, void *cols,
+                      int dtype, void *stream);
+int evp_unpatchify_nhwc(const void *dcols, int dtype, const int64_t *ids_keep, int B, int H, int W, int C, int patch,
+                        int n_keep, int accumulate, float *dx, void *stream);
+/* Depthwise 5x5 convolution, padding 2, groups = C (conv_block.py:30,43-46) on a channels-last map of `dtype`, with
+ * ConvBlock's keep-mask multiply fused into the input read: in_eff = (1 - mask[b, (y/s)*(W/s) + x/s]) * in, s =
+ * mask_scale (mask NULL: no masking). w float32 [C,1,5,5], bias float32 [C]. */
+int evp_dwconv5x5_fwd(const void *in, int dtype, const float *mask, int mask_scale, const float *w, const float *bias, int B,
+                      int H, int W, int C, void *out, void *stream);
+/* din (dtype), dw float32 [C,25], dbias float32 [C] (both overwritten); workspace float32
+ * [evp_dwconv5x5_bwd_nslab(B,H,W) * 26 * C]. `in` is the un-masked forward input. */
+int evp_dwconv5x5_bwd_nslab(int B, int H, int W);
+int evp_dwconv5x5_bwd(const void *dout, const void *in, int dtype, const float *mask, int mask_scale, const float *w, int B,
+                      int H, int W, int C, void *din, float *dw, float *dbias, float *workspace, void *stream);
+
 /* ------------------------------------------------------------------------------------------------ K10 decoder unshuffle
  * pr_rec_decoder.py:56-62: out[b,l,:] = (ids_restore[b,l] < n_keep ? emb[b,ids_restore[b,l],:] : mask_token) + pos[l].
  * emb float32 [B,n_keep,D] -> out float32 [B,L,D]. */

@@ -14,7 +14,7 @@ module object supplying `to_2tuple`, `trunc_normal_` and a `DropPath` that is
 never executed (all drop rates are 0 -> nn.Identity, vit_block.py:241) is put
 in sys.modules for the duration of this script.
 
-Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con]
+Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall]
 """
 import argparse
 import json
@@ -313,6 +313,22 @@ def gen_small():
     save("rec_small", **out)
 
 
+def gen_convsmall():
+    """ConvViT-Small through the as-shipped hub factory (BASELINE.json config 4 at the size the reference can build)."""
+    _ref()
+    from model.pretrain.pr_hub_model import pretrain_hub_model_small_patch16
+    cfg = dict(input=224, patch=16, dims=[128, 256, 384], depth=[2, 2, 11], heads=12, dec_dim=256, dec_depth=8, dec_heads=8,
+               mask_ratio=0.5, B=2)
+    a = make_args(model_size="small", pr_phase="rec", backbone_type="convvit")
+    hub = pretrain_hub_model_small_patch16(a, emb_frames_dim=512, queue_length=1024, T=0.07)
+    det_fill_module_(hub)
+    hub.train(True)
+    out = _run_rec("convsmall", cfg, lambda x, y: hub(x, y, is_rec=True), list(hub.named_parameters()))
+    out["cfg"] = np.array(json.dumps(cfg))
+    out["state_keys"] = np.array(json.dumps({k: list(v.shape) for k, v in hub.state_dict().items()}))
+    save("rec_convsmall", **out)
+
+
 # --------------------------------------------------------------------------- trainer trajectory
 def gen_train():
     """5 optimiser steps of the reference's own pr_rec_one_epoch (trainer/pretrain/pr_trainer.py:9-89) with
@@ -437,7 +453,7 @@ def gen_con():
 
 
 GENS = dict(voxel=gen_voxel, pos=gen_pos, mask=gen_mask, tiny=lambda: gen_composed("tiny"), small=gen_small,
-            base=lambda: gen_composed("base"), train=gen_train, con=gen_con)
+            base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -138,6 +138,63 @@ def vit_dense(sd, x, *, patch, heads, pre="backbone."):
     return taps[0], taps[1], layer_norm(t, sd[pre + "norm_layer.weight"], sd[pre + "norm_layer.bias"], 1e-6), attn
 
 
+# ----------------------------------------------------------------------------- model/backbone/convvit.py, conv_block.py
+def conv_block(sd, pre, x, keep=None):
+    """conv_block.py:41-51 on NCHW maps: LN over channels (eps 1e-5), 1x1 conv, keep-mask multiply, depthwise 5x5
+    (padding 2), 1x1 conv, residual; LN, 1x1 -> GELU -> 1x1, residual."""
+    def ln(t, n):
+        return layer_norm(t.permute(0, 2, 3, 1), sd[pre + n + ".weight"], sd[pre + n + ".bias"], 1e-5).permute(0, 3, 1, 2)
+    C = x.shape[1]
+    h = F.conv2d(ln(x, "norm1"), sd[pre + "conv1.weight"], sd[pre + "conv1.bias"])
+    if keep is not None:
+        h = keep * h
+    h = F.conv2d(h, sd[pre + "attn.weight"], sd[pre + "attn.bias"], padding=2, groups=C)
+    x = x + F.conv2d(h, sd[pre + "conv2.weight"], sd[pre + "conv2.bias"])
+    h = F.gelu(F.conv2d(ln(x, "norm2"), sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"]))
+    return x + F.conv2d(h, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+
+
+def _patch_embed_map(sd, pre, x, p):
+    """vit_block.py:60-68 kept as a (B,D,h,w) map."""
+    y = F.conv2d(x, sd[pre + "proj.weight"], sd[pre + "proj.bias"], stride=p)
+    y = layer_norm(y.permute(0, 2, 3, 1), sd[pre + "norm.weight"], sd[pre + "norm.bias"], 1e-5)
+    return F.gelu(y).permute(0, 3, 1, 2)
+
+
+def convvit_masked(sd, x, noise, *, heads, mask_ratio, fusion=True, pre="backbone."):
+    """convvit.py:126-171: three stages with the keep mask up-sampled to 56x56 / 28x28 by block repetition, multi-scale
+    fusion convs (k4s4, k2s2) gathered at the kept tokens, LN of the three-way sum."""
+    ids_keep, mask, ids_restore = masking_from_noise(noise, mask_ratio)
+    B = x.shape[0]
+    g = int(round(mask.shape[1] ** 0.5))
+    keep14 = (1 - mask).view(B, 1, g, g)
+    gidx = lambda t: torch.gather(t, 1, ids_keep.unsqueeze(-1).expand(-1, -1, t.shape[-1]))
+    t = _patch_embed_map(sd, pre + "patch_embed1.", x, 4)
+    for i in range(_depth(sd, pre + "conv_block1.")):
+        t = conv_block(sd, f"{pre}conv_block1.{i}.", t, keep14.repeat_interleave(4, 2).repeat_interleave(4, 3))
+    l1 = t
+    s1 = gidx(F.conv2d(t, sd[pre + "stage1_output_decode.weight"], sd[pre + "stage1_output_decode.bias"], stride=4).flatten(2).transpose(1, 2))
+    t = _patch_embed_map(sd, pre + "patch_embed2.", t, 2)
+    for i in range(_depth(sd, pre + "conv_block2.")):
+        t = conv_block(sd, f"{pre}conv_block2.{i}.", t, keep14.repeat_interleave(2, 2).repeat_interleave(2, 3))
+    l2 = t
+    s2 = gidx(F.conv2d(t, sd[pre + "stage2_output_decode.weight"], sd[pre + "stage2_output_decode.bias"], stride=2).flatten(2).transpose(1, 2))
+    t = _patch_embed_map(sd, pre + "patch_embed3.", t, 2).flatten(2).transpose(1, 2)
+    t = F.linear(t, sd[pre + "patch_embed4.weight"], sd[pre + "patch_embed4.bias"]) + sd[pre + "pos_embed"]
+    t = gidx(t)
+    for i in range(_depth(sd, pre + "vit_block.")):
+        t = vit_block(sd, f"{pre}vit_block.{i}.", t, heads)
+    fused = s1 + s2 + t if fusion else t
+    return l1, l2, layer_norm(fused, sd[pre + "norm_layer.weight"], sd[pre + "norm_layer.bias"], 1e-6), mask, ids_restore
+
+
+def convvit_rec_step(sd, x, target, noise, cfg):
+    l1, l2, lh, mask, ids_restore = convvit_masked(sd, x, noise, heads=cfg["heads"], mask_ratio=cfg["mask_ratio"])
+    pred = rec_decoder(sd, lh, ids_restore, heads=cfg["dec_heads"])
+    loss = rec_loss(pred, target, mask, cfg["patch"], cfg.get("norm_pix", True), cfg["mask_ratio"])
+    return loss, l1, l2, lh, pred, mask, ids_restore
+
+
 # ----------------------------------------------------------------------------- model/pretrain/pr_rec_decoder.py:53-70
 def rec_decoder(sd, x, ids_restore, *, heads, pre="pretrain_rec_decoder."):
     t = F.linear(x, sd[pre + "patch_embed.weight"], sd[pre + "patch_embed.bias"])

@@ -149,6 +149,65 @@ def test_training_trajectory_matches_reference_trainer():
         assert checksums(params[name])[2] == pytest.approx(ws, rel=2e-4, abs=tol), name
 
 
+def _conv_hub(dtype_mode="rec"):
+    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
+    from eventpretrain_amd.testing import det_fill_module_, make_args
+    a = make_args(model_size="small", pr_phase=dtype_mode, backbone_type="convvit", device="cuda")
+    m = hub.pretrain_hub_model_small_patch16(a, emb_frames_dim=512, queue_length=1024, T=0.07)
+    det_fill_module_(m)
+    return a, m.cuda().train()
+
+
+def test_convvit_rec_step_f32_matches_reference():
+    """BASELINE config 4 backbone (ConvViT, multi-scale conv patch embeds, masked depthwise conv blocks) in f32 mode
+    against the fixture made by the reference's own hub factory."""
+    from eventpretrain_amd import ops
+    d = load_golden("rec_convsmall")
+    a, m = _conv_hub()
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == jl(d["state_keys"])
+    x, y, noise = rec_inputs("convsmall", dict(B=2, input=224, patch=16))
+    ops.set_compute_dtype(torch.float32)
+    loss, l1, l2, lh, pred, mask, restore = m(x.cuda(), y.cuda(), is_rec=True, noise=noise.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert np.array_equal(mask.cpu().numpy(), d["mask"]) and np.array_equal(restore.cpu().numpy(), d["ids_restore"])
+    rel = abs(loss.item() - float(d["loss"])) / abs(float(d["loss"]))
+    assert rel <= F32_LOSS_RTOL, rel
+    assert tuple(l1.shape) == (2, 128, 56, 56) and tuple(l2.shape) == (2, 256, 28, 28)
+    assert_checksums(l1.contiguous(), d["emb_l1_checksums"], 1e-4)
+    assert_checksums(l2.contiguous(), d["emb_l2_checksums"], 1e-4)
+    assert_checksums(lh, d["emb_lh_checksums"], 1e-4)
+    assert_checksums(pred, d["pred_checksums"], 1e-4)
+    params = dict(m.named_parameters())
+    worst = 0.0
+    for n, gn in zip(jl(d["grad_names"]), d["grad_norms"]):
+        assert params[n].grad is not None, n
+        e = abs(params[n].grad.double().norm().item() - gn) / (gn + 1e-9)
+        worst = max(worst, e)
+        assert e <= 3e-3, (n, e)
+    print(f"[convvit-small] f32 loss rel err {rel:.2e}, worst grad-norm rel err {worst:.2e}")
+
+
+def test_convvit_rec_step_bf16_reported():
+    from eventpretrain_amd import ops
+    d = load_golden("rec_convsmall")
+    a, m = _conv_hub()
+    x, y, noise = rec_inputs("convsmall", dict(B=2, input=224, patch=16))
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        out = m(x.cuda(), y.cuda(), is_rec=True, noise=noise.cuda())
+        out[0].backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_compute_dtype(torch.float32)
+    assert np.array_equal(out[5].cpu().numpy(), d["mask"])
+    rel = abs(out[0].item() - float(d["loss"])) / abs(float(d["loss"]))
+    print(f"[convvit-small] bf16 loss rel err {rel:.2e}")
+    assert rel <= BF16_LOSS_RTOL
+    tot = math.sqrt(sum(p.grad.double().pow(2).sum().item() for p in m.parameters() if p.grad is not None))
+    assert abs(tot - float(d["total_grad_norm"])) / float(d["total_grad_norm"]) <= 5e-2
+
+
 @pytest.mark.parametrize("use_queue", [True, False])
 def test_contrastive_stage_f32_matches_reference(use_queue):
     """PrHubModel.forward(is_rec=False) (dense ViT-Small, MoCo-v3 heads with BatchNorm, CLIP-token branch, InfoNCE with
