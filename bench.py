@@ -123,7 +123,7 @@ class GemmTimer:
         act = kw.get("act", 0)
         epi = 1 if act in (1, 3) else 2 if act in (2, 4) else 0
         t128 = ((M + 127) // 128) * ((N + 127) // 128) * nb[0] * nb[1]
-        splittable = out.dtype == torch.float32 and kw.get("bias") is None and act == 0 and kw.get("residual") is None \
+        splittable = bool(kw.get("trans_a")) and out.dtype == torch.float32 and kw.get("bias") is None and act == 0 and kw.get("residual") is None \
             and kw.get("aux") is None and nb == (1, 1) and K >= 2048
         tile = kw.get("tile", 0) or (1 if (M >= 128 and N >= 128 and (t128 >= 192 or splittable)) else 2)
         return ("bf16" if a.dtype == torch.bfloat16 else "f32", "f32" if out.dtype == torch.float32 else "bf16", epi,

@@ -567,7 +567,9 @@ int launch(const evp_gemm_desc *d, hipStream_t s) {
     splitk = 1;
     const int tiles = p.tiles_m * tiles_n;
     const int ktiles = (d->K + BKc - 1) / BKc;
-    if (can_split && tiles < 384 && ktiles >= 16) {
+    // automatic split-K only for the weight-gradient layout: f32 atomics are order-dependent in the last bits, and
+    // activations must stay bit-reproducible run to run
+    if (can_split && d->transA && tiles < 384 && ktiles >= 16) {
       splitk = (512 + tiles - 1) / tiles;
       if (splitk > ktiles / 8) splitk = ktiles / 8;
       if (splitk < 1) splitk = 1;
@@ -610,8 +612,8 @@ template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(cons
   if (tile == 0) {
     const int64_t t128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * nb;
     const int64_t t256 = (int64_t)((d->M + 255) / 256) * ((d->N + 127) / 128) * nb;
-    const bool splittable = d->c_dtype == EVP_F32 && !d->bias && d->act == EVP_ACT_NONE && !d->residual && !d->aux &&
-                            nb == 1 && d->K >= 2048;
+    const bool splittable = d->transA && d->c_dtype == EVP_F32 && !d->bias && d->act == EVP_ACT_NONE && !d->residual &&
+                            !d->aux && nb == 1 && d->K >= 2048;
     // the 256x128 / 3-stage ring variant (tile 3) measured slower than 128x128 at this path's shapes (1 block per CU);
     // it stays selectable explicitly for A/B runs
     (void)t256;

@@ -262,13 +262,20 @@ class _DeferredGrads:
         once the pinned buffer exists, i.e. after one eager step)."""
         raw = torch.from_numpy(arr)
         n = raw.numel()
-        pin = self._pin.get(key)
-        if pin is None or pin.numel() < n:
-            pin = torch.empty(max(n, 1 << 16), dtype=torch.uint8).pin_memory()
-            self._pin[key] = pin
+        capturing = torch.cuda.is_current_stream_capturing()
+        ent = self._pin.get(key)
+        if ent is None or ent[0].numel() < n:
+            ent = [torch.empty(max(n, 1 << 16), dtype=torch.uint8).pin_memory(), None]
+            self._pin[key] = ent
+        pin, ev = ent
+        if ev is not None and not capturing:
+            ev.synchronize()              # the previous step's H2D copy out of this pinned buffer must have run
         pin[:n].copy_(raw)
         d = torch.empty(n, dtype=torch.uint8, device=dev)
         d.copy_(pin[:n], non_blocking=True)
+        if not capturing:
+            ent[1] = torch.cuda.Event()
+            ent[1].record()
         return d
 
     @staticmethod
@@ -296,28 +303,37 @@ class _DeferredGrads:
                     p_.grad = flat[o:o + p_.numel()].view_as(p_)
                     o += n_
                 self.flat_buffers.append(flat)
-            seen = set()
-            probs = np.zeros(len(w), dtype=np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i4"), ("N", "<i4"),
-                                                      ("K", "<i4"), ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4"),
-                                                      ("acc", "<i4"), ("pad", "<i4")]))
-            items = []
+            # A parameter used by several autograd nodes of one backward (rec+con: masked AND dense forward) has several
+            # queued contributions. Tiles of different problems run concurrently, so contributions to the SAME gradient
+            # go to successive launches (round r holds every parameter's r-th contribution; normally one round).
+            rounds, count = [], {}
+            for item in w:
+                r = count.get(id(item[0]), 0)
+                count[id(item[0])] = r + 1
+                while len(rounds) <= r:
+                    rounds.append([])
+                rounds[r].append(item)
             fresh_ids = {id(p_) for p_ in fresh}
-            for i, (param, dy, x, n_out, k_in, rows) in enumerate(w):
-                gt, acc = self._target(param)
-                if id(param) in fresh_ids and id(param) not in seen:
-                    acc = 0                      # first write into the freshly allocated flat slice
-                seen.add(id(param))
-                probs[i] = (dy.data_ptr(), x.data_ptr(), gt.data_ptr(), n_out, k_in, rows, n_out, k_in, k_in, acc, 0)
-                tm, tn = (n_out + 127) // 128, (k_in + 127) // 128
-                t = np.zeros((tn, tm, 4), dtype=np.int32)
-                t[..., 0] = i
-                t[..., 1] = np.arange(tm, dtype=np.int32)[None, :]
-                t[..., 2] = np.arange(tn, dtype=np.int32)[:, None]
-                items.append(t.reshape(-1, 4))
-            items = np.concatenate(items, 0)
-            pt = self._stage("wp", probs.view(np.uint8), dev)
-            it = self._stage("wi", items.view(np.uint8).reshape(-1), dev)
-            call("evp_gemm_grouped_tn_bf16", pt.data_ptr(), it.data_ptr(), int(items.shape[0]), stream_ptr())
+            for r, batch in enumerate(rounds):
+                probs = np.zeros(len(batch), dtype=np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i4"), ("N", "<i4"),
+                                                              ("K", "<i4"), ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4"),
+                                                              ("acc", "<i4"), ("pad", "<i4")]))
+                items = []
+                for i, (param, dy, x, n_out, k_in, rows) in enumerate(batch):
+                    gt, acc = self._target(param)
+                    if r == 0 and id(param) in fresh_ids:
+                        acc = 0                  # first write into the freshly allocated flat slice
+                    probs[i] = (dy.data_ptr(), x.data_ptr(), gt.data_ptr(), n_out, k_in, rows, n_out, k_in, k_in, acc, 0)
+                    tm, tn = (n_out + 127) // 128, (k_in + 127) // 128
+                    t = np.zeros((tn, tm, 4), dtype=np.int32)
+                    t[..., 0] = i
+                    t[..., 1] = np.arange(tm, dtype=np.int32)[None, :]
+                    t[..., 2] = np.arange(tn, dtype=np.int32)[:, None]
+                    items.append(t.reshape(-1, 4))
+                items = np.concatenate(items, 0)
+                pt = self._stage("wp%d" % r, probs.view(np.uint8), dev)
+                it = self._stage("wi%d" % r, items.view(np.uint8).reshape(-1), dev)
+                call("evp_gemm_grouped_tn_bf16", pt.data_ptr(), it.data_ptr(), int(items.shape[0]), stream_ptr())
         if b:
             dev = b[0][1].device
             probs = np.zeros(len(b), dtype=np.dtype([("x", "<u8"), ("out", "<u8"), ("M", "<i8"), ("N", "<i4"), ("ld", "<i4"),

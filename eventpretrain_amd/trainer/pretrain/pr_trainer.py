@@ -61,3 +61,49 @@ def pr_con_one_epoch(args, model, data_loader, optimizer, epoch, loss_scaler, lo
     """Contrastive / transfer epoch: model(events_voxel_grid, clip_emb)."""
     return _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, "contrastive_loss",
                  lambda x, y: model(x, y), vis_hook)
+
+
+def pr_rec_and_con_one_epoch(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer=None, vis_hook=None):
+    """Joint epoch (reference trainer/pretrain/pr_trainer.py:225-304): one masked-modeling forward and one contrastive
+    forward per batch, the two losses summed before the single backward."""
+    model.train(True)
+    logger = misc.MetricLogger(delimiter="  ")
+    logger.add_meter("lr", misc.SmoothedValue(window_size=1, fmt="{value:.6f}"))
+    header = "Epoch: [{}]".format(epoch + 1)
+    optimizer.zero_grad()
+    if log_writer is not None:
+        print("log_dir: {}".format(log_writer.log_dir))
+    n_iter = len(data_loader)
+    for it, (events_voxel_grid, sub_frame, clip_emb, image_name) in enumerate(
+            logger.log_every(args, data_loader, args.print_freq, header)):
+        if it % args.accum_iter == 0:
+            adjust_learning_rate(optimizer, it / n_iter + epoch, args)
+        events_voxel_grid = events_voxel_grid.to(args.device, non_blocking=True)
+        sub_frame = sub_frame.to(args.device, non_blocking=True)
+        clip_emb = clip_emb.to(args.device, non_blocking=True)
+        rec = model(events_voxel_grid, sub_frame, is_rec=True)
+        con = model(events_voxel_grid, clip_emb)
+        if vis_hook is not None and args.test_experiment and args.visualize:
+            vis_hook(args, events_voxel_grid, (sub_frame, clip_emb), (rec, con), image_name, epoch)
+        logger.update(reconstruct_loss=rec[0].item())
+        logger.update(contrastive_loss=con[0].item())
+        loss_total = (rec[0] + con[0]) / args.accum_iter
+        step_now = (it + 1) % args.accum_iter == 0
+        if args.backward:
+            loss_scaler(loss_total, optimizer, parameters=model.parameters(), update_grad=step_now)
+            if step_now:
+                optimizer.zero_grad()
+        if str(args.device).startswith("cuda"):
+            torch.cuda.synchronize()
+        lr = optimizer.param_groups[0]["lr"]
+        logger.update(lr=lr)
+        r_red = misc.all_reduce_mean(rec[0].item())
+        c_red = misc.all_reduce_mean(con[0].item())
+        if log_writer is not None and (it + 1) % args.log_freq == 0 and step_now:
+            x = int((it / n_iter + epoch) * 1000)
+            log_writer.add_scalar("reconstruct_loss", r_red, x)
+            log_writer.add_scalar("contrastive_loss", c_red, x)
+            log_writer.add_scalar("lr", lr, x)
+    logger.synchronize_between_processes()
+    print("Averaged stats:", logger)
+    return {k: m.global_avg for k, m in logger.meters.items()}

@@ -268,6 +268,65 @@ def test_contrastive_stage_bf16_runs():
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
 
 
+def test_rec_and_con_epoch_and_deferred_grads_agree():
+    """Joint rec+con epoch (two forwards, one backward): every backbone weight receives TWO queued gradient
+    contributions in the grouped launch. bf16 gradients from the deferred grouped path must equal those of the
+    per-layer path, and the f32 losses must equal the oracle's."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
+    from eventpretrain_amd.optim import FusedAdamW
+    from eventpretrain_amd.testing import det_fill_module_, det_normalish, det_uniform, make_args
+    from eventpretrain_amd.trainer.pretrain.pr_trainer import pr_rec_and_con_one_epoch
+    from eventpretrain_amd.utils.misc import NativeScalerWithGradNormCount
+    from oracle import model_oracle as mo
+    a = make_args(model_size="small", pr_phase="rec+con", use_queue=True, device="cuda", lr=1e-4, epochs=2, warmup_epochs=0)
+    m = hub.pretrain_hub_model_small_patch16(a, emb_frames_dim=512, queue_length=4, T=0.07)
+    det_fill_module_(m)
+    m = m.cuda().train()
+    x = (det_normalish("rc.voxels", (2, 5, 224, 224)) * 0.5).cuda()
+    y = det_normalish("rc.sub_frame", (2, 1, 224, 224)).cuda()
+    clip = det_normalish("rc.clip", (2, 197, 512)).cuda()
+    noise = det_uniform("rc.noise", (2, 196), 0.0, 1.0).cuda()
+    grads = {}
+    for deferred in (True, False):
+        ops.set_compute_dtype(torch.bfloat16)
+        ops.set_deferred_grads(deferred)
+        try:
+            for p in m.parameters():
+                p.grad = None
+            q0 = m.queue.clone()
+            rec = m(x, y, is_rec=True, noise=noise)
+            con = m(x, clip)
+            (rec[0] + con[0]).backward()
+            torch.cuda.synchronize()
+            m.queue.copy_(q0)
+            m.queue_ptr.zero_()
+            grads[deferred] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            ops.set_compute_dtype(torch.float32)
+            ops.set_deferred_grads(True)
+    assert grads[True].keys() == grads[False].keys()
+    for n in grads[True]:
+        a_, b_ = grads[True][n], grads[False][n]
+        assert torch.allclose(a_, b_, atol=2e-3 * b_.abs().max().item() + 1e-7, rtol=2e-2), n
+    # f32 losses against the oracle
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    cfg = dict(patch=16, heads=12, dec_heads=8, mask_ratio=0.5, T=0.07, use_queue=True)
+    rl = mo.rec_step(sd, x.cpu(), y.cpu(), noise.cpu(), cfg)[0]
+    cl = mo.con_step(sd, x.cpu(), clip.cpu(), cfg)[0]
+    rec = m(x, y, is_rec=True, noise=noise)
+    con = m(x, clip)
+    assert abs(rec[0].item() - rl.item()) <= F32_LOSS_RTOL * abs(rl.item())
+    assert abs(con[0].item() - cl.item()) <= F32_LOSS_RTOL * abs(cl.item())
+    # the trainer loop runs and returns both meters
+    for p in m.parameters():
+        p.grad = None
+    opt = FusedAdamW([{"params": [p for p in m.parameters() if p.requires_grad]}], lr=a.lr, betas=(0.9, 0.95))
+    batches = [dict(events_voxel_grid=x.cpu(), sub_frame=y.cpu(), clip_emb=clip.cpu(), image_name=["a", "b"])] * 2
+    stats = pr_rec_and_con_one_epoch(a, m, batches, opt, 0, NativeScalerWithGradNormCount())
+    assert set(stats) == {"lr", "reconstruct_loss", "contrastive_loss"} and all(np.isfinite(v) for v in stats.values())
+
+
 def test_no_cpu_fallback():
     from eventpretrain_amd import ops
     from eventpretrain_amd._lib import EvpError
