@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
 
 # name -> argtypes (all return int status unless listed in _OTHER_RESTYPE)
 SIGNATURES = {
-    "evp_voxel_scatter_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "evp_voxel_scatter_f32": [_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "evp_events_sorted_check": [_vp, _vp, _i, _i, _vp, _vp],
     "evp_mask_from_noise": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "evp_density_noise": [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp],

@@ -9,7 +9,8 @@
 //                          every output byte written exactly once.
 //      Blocks of one clip are mapped to one XCD (blockIdx % 8) so the slab re-reads (one per bin / y-tile) are
 //      served by that XCD's L2, not by HBM.
-// algo 1 keeps the plain global-atomic formulation (memset + 2 atomics per event) for A/B measurements.
+// algo 1 keeps the plain global-atomic formulation (memset + 2 atomics per event), algo 2 a decode-once two-pass form
+// (12-byte packed records); both measured slower than the default (5.3x and 1.3x) and stay for A/B measurements.
 //
 // HBM-bound. Algorithmic bytes per clip: n*32 B of events read + bins*H*W*4 B written.
 #include "evp_common.h"
@@ -88,7 +89,7 @@ __device__ __forceinline__ bool contribution(const Event &e, double t0, double d
   return true;
 }
 
-constexpr int VB_THREADS = 512;
+constexpr int VB_THREADS = 1024;
 constexpr int VB_UNROLL = 4;
 
 __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *events, const int64_t *offsets, const int64_t *cuts,
@@ -151,6 +152,95 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *eve
   }
 }
 
+// ---- two-pass form (algo 2): decode once, bin from packed records ------------------------------------------------
+// Pass A decodes every event exactly once (the float64 time normalisation with its division is the expensive part)
+// into three 4-byte streams: key = pix | floor(ts) << 24 | invalid << 31, and the two float32 contributions
+// val_left = p*(1-dt), val_right = p*dt. Pass B (one workgroup per clip x bin x y-tile, tile in LDS) then only reads
+// the 4-byte key of every event of its slab and touches a value only when the event lands in its tile.
+constexpr uint32_t KEY_INVALID = 0x80000000u;
+__global__ __launch_bounds__(256) void voxel_pack_kernel(const double *events, const int64_t *offsets, int bins, int H, int W, int is_txyp,
+                                                         uint32_t *keys, float *vleft, float *vright) {
+  const int clip = blockIdx.y;
+  const int64_t beg = offsets[clip], n = offsets[clip + 1] - beg;
+  if (n <= 0) return;
+  const double *ev = events + beg * 4;
+  const double t0 = stamp(ev, 0, is_txyp), t1 = stamp(ev, n - 1, is_txyp);
+  double dT = t1 - t0;
+  if (dT == 0) dT = 1.0;
+  const int64_t plane = (int64_t)H * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const Event e = load_event(ev, i, is_txyp);
+    const double ts = ts_of(e.t, t0, dT, bins);
+    const double tf = floor(ts);
+    float p = (float)e.p;
+    if (p == 0.0f) p = -1.0f;
+    const float dt = (float)(ts - tf);
+    const int64_t pix = (int64_t)e.x + (int64_t)e.y * (int64_t)W;
+    uint32_t key = KEY_INVALID;
+    if (tf >= 0.0 && tf < (double)bins && pix >= 0 && pix < plane) key = (uint32_t)pix | ((uint32_t)tf << 24);
+    keys[beg + i] = key;
+    vleft[beg + i] = p * (1.0f - dt);
+    vright[beg + i] = p * dt;
+  }
+}
+
+__global__ __launch_bounds__(VB_THREADS) void voxel_bin_packed_kernel(const uint32_t *keys, const float *vleft, const float *vright,
+                                                                      const int64_t *offsets, const int64_t *cuts, int n_clips, int bins,
+                                                                      int H, int W, int assume_sorted, int tile_rows, int n_yt, float *out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *tile = reinterpret_cast<float *>(smem_raw);
+  const int per_clip = bins * n_yt;
+  int clip, sub;
+  if ((n_clips & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    clip = (slot / per_clip) * 8 + xcd;
+    sub = slot % per_clip;
+  } else {
+    clip = blockIdx.x / per_clip;
+    sub = blockIdx.x % per_clip;
+  }
+  const int b = sub / n_yt, yt = sub % n_yt;
+  const int y0 = yt * tile_rows, y1 = (y0 + tile_rows < H) ? y0 + tile_rows : H;
+  const int tile_elems = (y1 - y0) * W;
+  for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) tile[i] = 0.f;
+  __syncthreads();
+  const int64_t beg = offsets[clip], n = offsets[clip + 1] - beg;
+  float *dst = out + (((int64_t)clip * bins + b) * H + y0) * W;
+  if (n > 0) {
+    const int64_t *cc = cuts + (int64_t)clip * (bins + 2);
+    const int64_t lo = assume_sorted ? cc[b > 0 ? b - 1 : 0] : 0;
+    const int64_t hi = assume_sorted ? cc[b + 1] : n;
+    const uint32_t pix0 = (uint32_t)(y0 * W), pix1 = (uint32_t)(y1 * W);
+    const uint32_t *kk = keys + beg;
+    const float *vl = vleft + beg, *vr = vright + beg;
+    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)VB_THREADS * 8) {
+      uint32_t k[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t i = i0 + (int64_t)u * VB_THREADS;
+        k[u] = i < hi ? kk[i] : KEY_INVALID;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (k[u] & KEY_INVALID) continue;
+        const uint32_t pix = k[u] & 0xFFFFFFu;
+        const int tf = (int)(k[u] >> 24);
+        if (pix < pix0 || pix >= pix1) continue;
+        const int64_t i = i0 + (int64_t)u * VB_THREADS;
+        if (tf == b) atomicAdd(&tile[pix - pix0], vl[i]);             // left neighbour (tf < bins by construction)
+        else if (tf + 1 == b) atomicAdd(&tile[pix - pix0], vr[i]);    // right neighbour
+      }
+    }
+  }
+  __syncthreads();
+  if ((W & 3) == 0) {
+    for (int i = threadIdx.x; i < tile_elems / 4; i += VB_THREADS)
+      reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(tile)[i];
+  } else {
+    for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) dst[i] = tile[i];
+  }
+}
+
 // algo 1: two global float atomics per event into a pre-zeroed grid
 __global__ __launch_bounds__(256) void voxel_atomic_kernel(const double *events, const int64_t *offsets, int bins, int H, int W,
                                                            int is_txyp, float *out) {
@@ -196,9 +286,9 @@ __global__ __launch_bounds__(256) void sorted_check_kernel(const double *events,
 
 }  // namespace
 
-extern "C" int evp_voxel_scatter_f32(const double *events, const int64_t *clip_offsets, int n_clips, int bins, int H, int W,
-                                     int is_txyp, int assume_sorted, int algo, int tile_rows, int64_t *workspace, float *out,
-                                     void *stream) {
+extern "C" int evp_voxel_scatter_f32(const double *events, const int64_t *clip_offsets, int n_clips, int64_t n_events_total, int bins,
+                                     int H, int W, int is_txyp, int assume_sorted, int algo, int tile_rows, int64_t *workspace,
+                                     float *out, void *stream) {
   EVP_CHECK_ARG(events && clip_offsets && out, EVP_EINVAL, "evp_voxel_scatter_f32: null pointer");
   EVP_CHECK_ARG(n_clips > 0 && bins > 0 && bins <= 64 && H > 0 && W > 0, EVP_ESHAPE,
                 "evp_voxel_scatter_f32: need n_clips>0, 0<bins<=64, H,W>0 (got %d,%d,%d,%d)", n_clips, bins, H, W);
@@ -211,10 +301,12 @@ extern "C" int evp_voxel_scatter_f32(const double *events, const int64_t *clip_o
     EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(atomic)");
     return EVP_OK;
   }
-  EVP_CHECK_ARG(algo == 0, EVP_EINVAL, "evp_voxel_scatter_f32: unknown algo %d", algo);
-  EVP_CHECK_ARG(workspace, EVP_EINVAL, "evp_voxel_scatter_f32: workspace (int64[n_clips*(bins+2)]) required for algo 0");
+  EVP_CHECK_ARG(algo == 0 || algo == 2, EVP_EINVAL, "evp_voxel_scatter_f32: unknown algo %d", algo);
+  EVP_CHECK_ARG(workspace, EVP_EINVAL, "evp_voxel_scatter_f32: workspace required for the LDS-binned algorithms");
+  EVP_CHECK_ARG(algo != 2 || (n_events_total > 0 && (int64_t)H * W <= (1 << 24)), EVP_ESHAPE,
+                "evp_voxel_scatter_f32: algo 2 needs n_events_total and H*W <= 2^24");
   if (tile_rows <= 0) {
-    const int max_rows = (56 * 1024) / (W * 4);  // <= 56 KiB of LDS per block: 2-3 blocks per CU
+    const int max_rows = (100 * 1024) / (W * 4);  // <= 100 KiB of LDS: big tiles halve the slab re-reads (measured best)
     tile_rows = max_rows < 1 ? 1 : (max_rows > H ? H : max_rows);
     const int nyt = (H + tile_rows - 1) / tile_rows;
     tile_rows = (H + nyt - 1) / nyt;  // balance the tiles
@@ -222,13 +314,27 @@ extern "C" int evp_voxel_scatter_f32(const double *events, const int64_t *clip_o
   EVP_CHECK_ARG((size_t)tile_rows * W * 4 <= 160 * 1024, EVP_ESHAPE, "evp_voxel_scatter_f32: tile of %d rows x %d exceeds LDS", tile_rows, W);
   const int n_yt = (H + tile_rows - 1) / tile_rows;
   const size_t smem = (size_t)tile_rows * W * sizeof(float);
-  if (smem > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(voxel_bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_voxel_scatter_f32: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
-  }
   if (assume_sorted) {
     hipLaunchKernelGGL(voxel_cuts_kernel, dim3(n_clips), dim3(256), 0, s, events, clip_offsets, bins, is_txyp, workspace);
     EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(cuts)");
+  }
+  if (algo == 2) {
+    uint32_t *keys = reinterpret_cast<uint32_t *>(workspace + (int64_t)n_clips * (bins + 2));
+    float *vl = reinterpret_cast<float *>(keys + n_events_total), *vr = vl + n_events_total;
+    hipLaunchKernelGGL(voxel_pack_kernel, dim3(64, n_clips), dim3(256), 0, s, events, clip_offsets, bins, H, W, is_txyp, keys, vl, vr);
+    EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(pack)");
+    if (smem > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(voxel_bin_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_voxel_scatter_f32: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(voxel_bin_packed_kernel, dim3(n_clips * bins * n_yt), dim3(VB_THREADS), smem, s, keys, vl, vr, clip_offsets, workspace,
+                       n_clips, bins, H, W, assume_sorted, tile_rows, n_yt, out);
+    EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(bin packed)");
+    return EVP_OK;
+  }
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(voxel_bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_voxel_scatter_f32: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
   }
   hipLaunchKernelGGL(voxel_bin_kernel, dim3(n_clips * bins * n_yt), dim3(VB_THREADS), smem, s, events, clip_offsets, workspace, n_clips,
                      bins, H, W, is_txyp, assume_sorted, tile_rows, n_yt, out);

@@ -21,8 +21,9 @@ def voxel_grid_batch(events, clip_offsets, num_bins, size, is_txyp=False, assume
     dev = events.device
     if out is None:
         out = torch.empty(n_clips, num_bins, H, W, dtype=torch.float32, device=dev)
-    ws = torch.empty(n_clips * (num_bins + 2), dtype=torch.int64, device=dev)
-    call("evp_voxel_scatter_f32", ptr(events), ptr(clip_offsets), n_clips, int(num_bins), H, W, int(bool(is_txyp)),
+    n_total = int(events.shape[0])
+    ws = torch.empty(n_clips * (num_bins + 2) + (3 * n_total + 1) // 2 + 2, dtype=torch.int64, device=dev)
+    call("evp_voxel_scatter_f32", ptr(events), ptr(clip_offsets), n_clips, n_total, int(num_bins), H, W, int(bool(is_txyp)),
          int(bool(assume_sorted)), int(algo), int(tile_rows), ptr(ws), ptr(out), stream_ptr())
     return out
 

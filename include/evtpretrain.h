@@ -42,11 +42,16 @@ const char *evp_target_arch(void);
  * assume_sorted != 0: rows of each clip are non-decreasing in t (what every reference dataset produces; the
  * reference itself relies on it for t0/t1, :19-22) -> each block scans only its time slab. assume_sorted == 0:
  * correct for any row order (every block scans the whole clip).
- * workspace: int64 [n_clips*(bins+2)] scratch. algo: 0 = LDS-binned (default), 1 = global float atomics.
+ * n_events_total = clip_offsets[n_clips] (known to the host that built the offsets).
+ * algo 0 (default) = single-pass LDS-binned straight from the float64 rows, workspace int64 [n_clips*(bins+2)].
+ * algo 2 = decode-once two-pass form: pass A packs every event into 12 bytes (pixel/bin key + the two float32
+ * contributions), pass B bins the packed streams; workspace int64 [n_clips*(bins+2) + (3*n_events_total + 1)/2]
+ * (measured 1.3x slower than algo 0 on MI355X; kept for A/B). algo 1 = memset + global float atomics, no workspace
+ * (5.3x slower).
  * tile_rows: rows of one bin plane held in LDS per block (0 = auto). */
-int evp_voxel_scatter_f32(const double *events, const int64_t *clip_offsets, int n_clips, int bins, int H, int W,
-                          int is_txyp, int assume_sorted, int algo, int tile_rows, int64_t *workspace, float *out,
-                          void *stream);
+int evp_voxel_scatter_f32(const double *events, const int64_t *clip_offsets, int n_clips, int64_t n_events_total, int bins,
+                          int H, int W, int is_txyp, int assume_sorted, int algo, int tile_rows, int64_t *workspace,
+                          float *out, void *stream);
 /* sorted_flags[c] = 1 if clip c's stamps are non-decreasing, else 0 (device int32 [n_clips]). */
 int evp_events_sorted_check(const double *events, const int64_t *clip_offsets, int n_clips, int is_txyp,
                             int32_t *sorted_flags, void *stream);

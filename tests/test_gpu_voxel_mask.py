@@ -18,14 +18,14 @@ def _batch(evs, bins, size, **kw):
     return voxel_grid_batch(ev, torch.from_numpy(off).cuda(), bins, size, **kw).cpu().numpy()
 
 
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1, 2])
 def test_voxel_kat_exact(algo):
     d = load_golden("voxel")
     g = _batch([d["kat_events"]], 5, (4, 4), algo=algo)[0]
     assert np.array_equal(g, d["kat_grid"])
 
 
-@pytest.mark.parametrize("algo,tile_rows", [(0, 0), (0, 1), (0, 5), (0, 1000), (1, 0)])
+@pytest.mark.parametrize("algo,tile_rows", [(0, 0), (0, 1), (0, 5), (0, 1000), (2, 0), (2, 3), (1, 0)])
 def test_voxel_cases_vs_reference(algo, tile_rows):
     from oracle.voxel_oracle import voxel_grid
     d = load_golden("voxel")
@@ -86,8 +86,9 @@ def test_voxel_full_size_batch():
         dtf = (ts - tf).astype(np.float32).astype(np.float64)
         expect = np.sum(p * (1 - dtf) * (tf < 5)) + np.sum(p * dtf * (tf + 1 < 5))
         assert abs(float(g[i].astype(np.float64).sum()) - expect) <= 2e-2, i
-    ga = _batch(evs[:8], 5, (224, 224), algo=1)
-    assert np.abs(ga - g[:8]).max() <= 2e-5
+    for algo in (1, 2):
+        ga = _batch(evs[:8], 5, (224, 224), algo=algo)
+        assert np.abs(ga - g[:8]).max() <= 2e-5, algo
 
 
 def test_sorted_check_kernel():
