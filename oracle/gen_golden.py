@@ -14,7 +14,7 @@ module object supplying `to_2tuple`, `trunc_normal_` and a `DropPath` that is
 never executed (all drop rates are 0 -> nn.Identity, vit_block.py:241) is put
 in sys.modules for the duration of this script.
 
-Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall]
+Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin]
 """
 import argparse
 import json
@@ -329,6 +329,48 @@ def gen_convsmall():
     save("rec_convsmall", **out)
 
 
+def gen_swin():
+    """Swin-Tiny (window 7) through the as-shipped hub factory, masked reconstruction step (BASELINE.json config 5;
+    model/backbone/swin.py:174-246 + model/sub_module/swin_block.py), B=2, 224x224, decoder patch 32."""
+    _ref()
+    from model.pretrain.pr_hub_model import pretrain_hub_model_swin_tiny_patch16
+    cfg = dict(input=224, patch=32, dims=[96, 192, 384, 768], depths=[2, 2, 6, 2], heads=[3, 6, 12, 24], window=7,
+               dec_dim=256, dec_depth=8, dec_heads=8, mask_ratio=0.5, B=2)
+    a = make_args(model_size="tiny", pr_phase="rec", backbone_type="swin")
+    hub = pretrain_hub_model_swin_tiny_patch16(a, emb_frames_dim=512, queue_length=1024, T=0.07)
+    det_fill_module_(hub)
+    hub.train(True)
+    keep = {}
+
+    def fwd(x, y):
+        r = hub(x, y, is_rec=True)
+        (loss, emb_l1, emb_l2, emb_l3, emb_l4, emb_lh, c1, c2, c3, c4, pred, mask, ids_restore, attn) = r
+        keep.update(emb_l3=emb_l3, emb_l4=emb_l4, c1=c1, c2=c2, c3=c3, c4=c4, attn=attn)
+        return loss, emb_l1, emb_l2, emb_lh, pred, mask, ids_restore
+
+    def extra(res):
+        e = dict(emb_l3_checksums=checksums(keep["emb_l3"]), emb_l4_checksums=checksums(keep["emb_l4"]),
+                 attn_checksums=checksums(keep["attn"]), attn_shape=np.array(keep["attn"].shape),
+                 coords_l1=keep["c1"], coords_l2=keep["c2"], coords_l3=keep["c3"], coords_l4=keep["c4"],
+                 emb_l4=keep["emb_l4"], emb_lh=res[3])
+        sd = dict(hub.named_parameters())
+        for n in ["backbone.swin_block.0.blocks.0.attn.relative_position_bias_table",
+                  "backbone.swin_block.2.blocks.1.attn.relative_position_bias_table",
+                  "backbone.swin_block.0.downsample.reduction.weight", "backbone.stage1_output_decode.weight",
+                  "backbone.patch_embed.proj.weight", "backbone.swin_block.3.blocks.1.mlp.fc2.bias"]:
+            g = sd[n].grad
+            if g.numel() <= 20000:
+                e["grad::" + n] = g
+            else:
+                e["gradsum::" + n] = checksums(g)
+        return e
+
+    out = _run_rec("swin", cfg, fwd, list(hub.named_parameters()), extra)
+    out["cfg"] = np.array(json.dumps(cfg))
+    out["state_keys"] = np.array(json.dumps({k: list(v.shape) for k, v in hub.state_dict().items()}))
+    save("rec_swin_tiny", **out)
+
+
 # --------------------------------------------------------------------------- trainer trajectory
 def gen_train():
     """5 optimiser steps of the reference's own pr_rec_one_epoch (trainer/pretrain/pr_trainer.py:9-89) with
@@ -453,7 +495,7 @@ def gen_con():
 
 
 GENS = dict(voxel=gen_voxel, pos=gen_pos, mask=gen_mask, tiny=lambda: gen_composed("tiny"), small=gen_small,
-            base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall)
+            base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall, swin=gen_swin)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -195,6 +195,192 @@ def convvit_rec_step(sd, x, target, noise, cfg):
     return loss, l1, l2, lh, pred, mask, ids_restore
 
 
+# ----------------------------------------------------------------------------- model/sub_module/swin_block.py, backbone/swin.py
+def swin_knapsack(cap, wt):
+    """swin_block.py:277-319: 0/1 knapsack with value == weight; back-tracking from the last item, an item is taken
+    whenever the table value differs from the row above. Returns (best, increasing index list)."""
+    n = len(wt)
+    K = np.zeros((n + 1, cap + 1), dtype=np.int64)
+    for i in range(1, n + 1):
+        w = wt[i - 1]
+        K[i] = K[i - 1]
+        if w <= cap:
+            K[i, w:] = np.maximum(K[i - 1, w:], K[i - 1, :cap + 1 - w] + w)
+    res, c, picked = int(K[n, cap]), cap, []
+    best = res
+    for i in range(n, 0, -1):
+        if res <= 0:
+            break
+        if res == K[i - 1, c]:
+            continue
+        picked.append(i - 1)
+        res -= wt[i - 1]
+        c -= wt[i - 1]
+    return best, picked[::-1]
+
+
+def swin_group_windows(cap, counts):
+    """swin_block.py:322-347: greedy repetition of the knapsack over the windows that are still unassigned."""
+    wt, ori = list(counts), list(range(len(counts)))
+    sizes, groups = [], []
+    while wt:
+        best, idx = swin_knapsack(cap, wt)
+        sizes.append(best)
+        groups.append([ori[i] for i in idx])
+        keep = [i for i in range(len(wt)) if i not in set(idx)]
+        wt, ori = [wt[i] for i in keep], [ori[i] for i in keep]
+    return sizes, groups
+
+
+def _swin_mask_from_ids(gid):
+    """swin_block.py:366-373: 0 where two slots carry the same non-negative window id, else -100."""
+    same = (gid[:, :, None] == gid[:, None, :]) & ~((gid[:, :, None] == -1) & (gid[:, None, :] == -1))
+    return torch.where(same, torch.zeros(()), torch.full((), -100.0))
+
+
+def _swin_rel_idx(c, window):
+    """swin_block.py:375-381 on coords [..., n, 2]."""
+    d = c[..., :, None, :] - c[..., None, :, :] + (window - 1)
+    return d[..., 0] * (2 * window - 1) + d[..., 1]
+
+
+def swin_plan(coords, window, shift, n_tokens):
+    """GroupingModule.prepare (swin_block.py:383-452). coords: LongTensor [n,2] (shared over the batch).
+    Returns dict(mode, gather [nG*GS] (pads -> 0), scatter [n], mask [nG,GS,GS] f32, rel [nG,GS,GS] int64)."""
+    wid = (coords + (window - shift) % window) // window
+    wid = wid[:, 0] * coords.shape[0] + wid[:, 1]
+    if n_tokens <= 2 * window * window:
+        mask = _swin_mask_from_ids(wid[None])
+        return dict(mode="masking", mask=mask, rel=_swin_rel_idx(coords[None], window), gs=n_tokens)
+    order = torch.argsort(wid, stable=True)
+    swid = wid[order]
+    counts = torch.unique_consecutive(swid, return_counts=True)[1].tolist()
+    gs = min(window * window, max(counts))
+    sizes, groups = swin_group_windows(gs, counts)
+    ord_spl, wid_spl = order.split(counts), swid.split(counts)
+    gather, gids = [], []
+    for n_el, g in zip(sizes, groups):
+        pad = gs - n_el
+        gather.append(F.pad(torch.cat([ord_spl[i] for i in g]), (0, pad), value=-1))
+        gids.append(F.pad(torch.cat([wid_spl[i] for i in g]), (0, pad), value=-1))
+    gather = torch.cat(gather)
+    scatter = torch.argsort(gather, stable=True)[-sum(sizes):]
+    gather = gather.clamp_min(0)
+    mask = _swin_mask_from_ids(torch.stack(gids))
+    rel = _swin_rel_idx(coords[gather].reshape(-1, gs, 2), window)
+    rel = rel * (mask == 0)
+    return dict(mode="grouping", gather=gather, scatter=scatter, mask=mask, rel=rel, gs=gs)
+
+
+def window_attention(sd, pre, x, mask, rel, heads):
+    """swin_block.py:124-162: scaled q, + table[rel] (zeroed where masked) + mask, softmax, AV, proj."""
+    Bg, N, C = x.shape
+    dh = C // heads
+    qkv = F.linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"]).reshape(Bg, N, 3, heads, dh)
+    q, k, v = qkv.permute(2, 0, 3, 1, 4)
+    att = (q * dh ** -0.5) @ k.transpose(-2, -1)
+    blocked = mask != 0
+    table = sd[pre + "relative_position_bias_table"]
+    bias = table[rel.masked_fill(blocked, 0).reshape(-1)].view(-1, N, N, heads) * (~blocked).view(-1, N, N, 1).float()
+    nG = bias.shape[0]
+    att = att.view(Bg // nG, nG, heads, N, N) + bias.permute(0, 3, 1, 2).unsqueeze(0) + mask.view(1, nG, 1, N, N)
+    p = torch.softmax(att.view(Bg, heads, N, N), dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(Bg, N, C)
+    return F.linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"]), p
+
+
+def swin_block(sd, pre, x, plan, heads, eps=1e-6):
+    """swin_block.py:260-273 wrapped in GroupingModule.group/merge (swin_block.py:454-466)."""
+    B, n, C = x.shape
+    if plan["mode"] == "grouping":
+        x = x[:, plan["gather"]].reshape(-1, plan["gs"], C)
+    a, p = window_attention(sd, pre + "attn.", layer_norm(x, sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], eps),
+                            plan["mask"], plan["rel"], heads)
+    x = x + a
+    h = layer_norm(x, sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], eps)
+    h = F.gelu(F.linear(h, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"]))
+    x = x + F.linear(h, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    if plan["mode"] == "grouping":
+        x = x.reshape(B, -1, C)[:, plan["scatter"]]
+    return x, p
+
+
+def swin_patch_merging(sd, pre, x, vis, res, eps=1e-6):
+    """swin_block.py:179-209. x [B,n,C] in row-major order of the visible cells, vis BoolTensor [res*res].
+    2x2 neighbours are concatenated in the order (0,0),(1,0),(0,1),(1,1), LayerNorm(4C), Linear(4C->2C, no bias)."""
+    B, n, C = x.shape
+    rank = torch.cumsum(vis.long(), 0) - 1                       # row-major index among the visible cells
+    yy, xx = torch.meshgrid(torch.arange(res), torch.arange(res), indexing="ij")
+    blk = lambda t: t.reshape(res // 2, 2, res // 2, 2).permute(0, 2, 1, 3).reshape(-1, 4)
+    vis_b, rank_b = blk(vis), blk(rank)
+    rows = rank_b[vis_b.any(1)]                                   # [n/4, 4] in order (0,0),(0,1),(1,0),(1,1)
+    t = torch.cat([x[:, rows[:, 0]], x[:, rows[:, 2]], x[:, rows[:, 1]], x[:, rows[:, 3]]], dim=-1)
+    t = layer_norm(t, sd[pre + "norm.weight"], sd[pre + "norm.bias"], eps)
+    t = F.linear(t, sd[pre + "reduction.weight"])
+    vis_new = vis_b.any(1)
+    c = torch.stack([yy[::2, ::2].reshape(-1) // 2, xx[::2, ::2].reshape(-1) // 2], -1)[vis_new]
+    return t, c, vis_new
+
+
+def swin_stages(sd, t, coords, vis, cfg, pre="backbone."):
+    """BasicBlock.forward x4 (swin_block.py:523-553, swin.py:184-188). Returns per-stage (tokens, coords) and the
+    last block's attention probabilities."""
+    outs, attn = [], None
+    res = cfg["input"] // 4
+    W = cfg["window"]
+    n_stage = len(cfg["depths"])
+    for s in range(n_stage):
+        win = min(W, res)
+        plan0 = swin_plan(coords, win, 0, t.shape[1])
+        plan1 = swin_plan(coords, win, W // 2, t.shape[1]) if win < res else plan0
+        for i in range(cfg["depths"][s]):
+            t, attn = swin_block(sd, f"{pre}swin_block.{s}.blocks.{i}.", t, plan0 if i % 2 == 0 else plan1, cfg["heads"][s])
+        outs.append((t, coords))
+        if s < n_stage - 1:
+            t, coords, vis = swin_patch_merging(sd, f"{pre}swin_block.{s}.downsample.", t, vis, res)
+            res //= 2
+    return outs, attn
+
+
+def swin_masked(sd, x, noise, cfg, fusion=True, pre="backbone."):
+    """swin.py:174-246. The visibility pattern of sample 0 is applied to the WHOLE batch (swin.py:151), while the
+    fusion convs' outputs are gathered with each sample's own ids_keep (swin.py:207) -- restated as is."""
+    B = x.shape[0]
+    ids_keep, mask, ids_restore = masking_from_noise(noise, cfg["mask_ratio"])
+    t = F.conv2d(x, sd[pre + "patch_embed.proj.weight"], sd[pre + "patch_embed.proj.bias"], stride=4).flatten(2).transpose(1, 2)
+    t = layer_norm(t, sd[pre + "patch_embed.norm.weight"], sd[pre + "patch_embed.norm.bias"], 1e-6)
+    res = cfg["input"] // 4
+    g = int(round(mask.shape[1] ** 0.5))
+    rep = res // g
+    vis = (mask[0] == 0).view(g, 1, g, 1).expand(g, rep, g, rep).reshape(-1)
+    yy, xx = torch.meshgrid(torch.arange(res), torch.arange(res), indexing="ij")
+    coords = torch.stack([yy.reshape(-1), xx.reshape(-1)], -1)[vis]
+    t = t[:, vis]
+    outs, attn = swin_stages(sd, t, coords, vis, cfg, pre)
+    gidx = lambda e: torch.gather(e, 1, ids_keep.unsqueeze(-1).expand(-1, -1, e.shape[-1]))
+    fused = outs[-1][0]
+    if fusion:
+        for s in range(len(outs) - 1):
+            e, c = outs[s]
+            r = res >> s
+            dense = torch.zeros(B, r * r, e.shape[-1])
+            dense[:, c[:, 0] * r + c[:, 1]] = e
+            dense = dense.view(B, r, r, -1).permute(0, 3, 1, 2)
+            k = r // g
+            d = F.conv2d(dense, sd[f"{pre}stage{s + 1}_output_decode.weight"], sd[f"{pre}stage{s + 1}_output_decode.bias"], stride=k)
+            fused = fused + gidx(d.flatten(2).transpose(1, 2))
+    lh = layer_norm(fused, sd[pre + "norm_layer.weight"], sd[pre + "norm_layer.bias"], 1e-6)
+    return outs, lh, mask, ids_restore, attn
+
+
+def swin_rec_step(sd, x, target, noise, cfg):
+    """PrHubModel.forward(is_rec=True) for the Swin backbone (pr_hub_model.py:194-204)."""
+    outs, lh, mask, ids_restore, attn = swin_masked(sd, x, noise, cfg)
+    pred = rec_decoder(sd, lh, ids_restore, heads=cfg["dec_heads"])
+    loss = rec_loss(pred, target, mask, cfg["patch"], cfg.get("norm_pix", True), cfg["mask_ratio"])
+    return loss, outs, lh, pred, mask, ids_restore, attn
+
+
 # ----------------------------------------------------------------------------- model/pretrain/pr_rec_decoder.py:53-70
 def rec_decoder(sd, x, ids_restore, *, heads, pre="pretrain_rec_decoder."):
     t = F.linear(x, sd[pre + "patch_embed.weight"], sd[pre + "patch_embed.bias"])

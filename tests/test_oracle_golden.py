@@ -130,6 +130,55 @@ def test_rec_convvit_small_matches_reference():
         assert abs(sd[n].grad.double().norm().item() - gn) <= 2e-4 * gn + 1e-9, n
 
 
+def swin_state_dict(d):
+    from eventpretrain_amd.testing import det_value_for
+    sd = {}
+    for k, shp in jl(d["state_keys"]).items():
+        if k.endswith("relative_position_index"):
+            continue                                   # unused at pre-training (swin_block.py:100)
+        if k.endswith("pos_embed"):
+            sd[k] = torch.from_numpy(mo.sincos_2d(shp[-1], 7)).float().unsqueeze(0)
+        else:
+            sd[k] = det_value_for(k, shp).requires_grad_(True)
+    return sd
+
+
+def test_swin_knapsack_grouping():
+    """Host grouping known answers (hand-checked against swin_block.py:277-347)."""
+    assert mo.swin_knapsack(10, [5, 4, 6, 3]) == (10, [1, 2])
+    assert mo.swin_knapsack(49, [49, 49]) == (49, [0])
+    sizes, groups = mo.swin_group_windows(49, [21, 28, 49, 7, 14, 28])
+    assert sizes == [49, 49, 49] and sorted(sum(groups, [])) == list(range(6))
+    assert all(sum([21, 28, 49, 7, 14, 28][i] for i in g) == s for g, s in zip(groups, sizes))
+
+
+def test_rec_swin_tiny_matches_reference():
+    """Swin-T masked reconstruction step (BASELINE config 5) through the oracle vs the reference's own outputs."""
+    d = load_golden("rec_swin_tiny")
+    cfg = jl(d["cfg"])
+    sd = swin_state_dict(d)
+    x, y, noise = rec_inputs("swin", cfg)
+    assert np.array_equal(noise.numpy(), d["noise"])
+    loss, outs, lh, pred, mask, restore, attn = mo.swin_rec_step(sd, x, y, noise, cfg)
+    assert np.array_equal(mask.numpy(), d["mask"]) and np.array_equal(restore.numpy(), d["ids_restore"])
+    for i in range(4):
+        assert np.array_equal(outs[i][1].numpy(), d[f"coords_l{i + 1}"][0])
+    assert abs(loss.item() - float(d["loss"])) <= 2e-6 * abs(float(d["loss"]))
+    assert list(attn.shape) == list(d["attn_shape"])
+    for t, k in ((outs[0][0], "emb_l1"), (outs[1][0], "emb_l2"), (outs[2][0], "emb_l3"), (outs[3][0], "emb_l4"),
+                 (lh, "emb_lh"), (pred, "pred"), (attn, "attn")):
+        assert_checksums(t, d[k + "_checksums"], 2e-5, k)
+    assert torch.allclose(lh, torch.from_numpy(d["emb_lh"]), atol=3e-5, rtol=1e-5)
+    loss.backward()
+    for n, gn in zip(jl(d["grad_names"]), d["grad_norms"]):
+        assert sd[n].grad is not None, n
+        assert abs(sd[n].grad.double().norm().item() - gn) <= 2e-4 * gn + 1e-9, n
+    for k in d.files:
+        if k.startswith("grad::"):
+            ref = torch.from_numpy(d[k])
+            assert torch.allclose(sd[k[6:]].grad, ref, atol=1e-6 + 2e-4 * ref.abs().max().item(), rtol=1e-4), k
+
+
 @pytest.mark.slow
 def test_rec_base_matches_reference():
     _check_rec("base")
