@@ -1,0 +1,160 @@
+"""Swin-T backbone on sparse tokens (reference model/backbone/swin.py:13-302): same constructor, factory, return tuples
+and state-dict keys.
+
+Per step the only data-dependent host decision is the 49-cell visibility pattern of sample 0, which the reference
+applies to the whole batch (swin.py:151). It is read back once (49 floats), turned into per-stage `StagePlan`s (window
+groups, gather tables, relative-position indices; cached per pattern) and everything else stays on the GPU: the 4x4
+patch projection is evaluated only at the visible tokens, the stage blocks run on grouped tokens, and the three
+stage-fusion convs are evaluated only at each sample's kept decoder cells (ops.SwinFuseConvFn) instead of
+re-densifying into zero grids."""
+from collections import OrderedDict
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..sub_module.swin_block import BasicBlock, PatchEmbed, PatchMerging, StagePlan, TokenLayout, _dev_i32
+from .vit import init_linear_and_norm
+
+_PLAN_CACHE_SIZE = 32
+
+
+class _PatternPlan:
+    """All host-derived tables for one visibility pattern."""
+
+    def __init__(self, model, vis_cells, device):
+        res = model.patches_resolution[0]
+        g = int(round(vis_cells.shape[0] ** 0.5))
+        rep = res // g
+        vis = np.repeat(np.repeat(vis_cells.reshape(g, g), rep, 0), rep, 1).reshape(-1)
+        ys, xs = np.nonzero(vis.reshape(res, res))
+        layout = TokenLayout(np.stack([ys, xs], -1), vis, res)
+        self.tok_ids = torch.from_numpy(np.nonzero(vis)[0].astype(np.int64)).to(device)      # visible stage-1 tokens
+        self.stages, self.fuse = [], []
+        for blk in model.swin_block:
+            sp = StagePlan(blk, layout, device)
+            self.stages.append(sp)
+            r = layout.res
+            tokmap = np.full(r * r, -1, dtype=np.int32)
+            tokmap[layout.coords[:, 0] * r + layout.coords[:, 1]] = np.arange(layout.n, dtype=np.int32)
+            self.fuse.append((_dev_i32(tokmap, device), _dev_i32(layout.coords, device), r, r // g))
+            if sp.merge is not None:
+                layout = sp.merge[2]
+
+
+class SwinTransformer(nn.Module):
+    def __init__(self, args, img_size=224, patch_size=4, decoder_num_patches=49, num_bins=3, mask_ratio=0.50,
+                 embed_dim=[96, 192, 384, 768], depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7,
+                 out_indices=(0, 1, 2, 3), mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0.2, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs):
+        super().__init__()
+        if drop_rate or attn_drop_rate or drop_path_rate:
+            raise NotImplementedError("drop rates > 0 are not used on the pre-training path")
+        self.args = args
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.num_patches = decoder_num_patches
+        self.num_layers = len(depths)
+        self.embed_dim = embed_dim[0]
+        self.out_indices = out_indices
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=num_bins, embed_dim=embed_dim[0],
+                                      norm_layer=norm_layer)
+        self.patches_resolution = self.patch_embed.patches_resolution
+        res = self.patches_resolution
+        self.swin_block = nn.ModuleList([
+            BasicBlock(dim=int(embed_dim[0] * 2 ** i), input_resolution=(res[0] // (2 ** i), res[1] // (2 ** i)),
+                       depth=depths[i], num_heads=num_heads[i], window_size=window_size, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                       qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate, drop_path=0., norm_layer=norm_layer,
+                       downsample=PatchMerging if (i < self.num_layers - 1) else None)
+            for i in range(self.num_layers)])
+        self.norm_layer = norm_layer(embed_dim[-1])
+        if args.phase == "pretrain" and args.pr_phase in ("rec", "rec+con", "rec-n"):
+            self.mask_ratio = mask_ratio
+            self.stage1_output_decode = nn.Conv2d(embed_dim[0], embed_dim[-1], kernel_size=8, stride=8)
+            self.stage2_output_decode = nn.Conv2d(embed_dim[1], embed_dim[-1], kernel_size=4, stride=4)
+            self.stage3_output_decode = nn.Conv2d(embed_dim[2], embed_dim[-1], kernel_size=2, stride=2)
+        if args.phase in ("finetune_semseg", "finetune_flow"):
+            raise NotImplementedError("dense-prediction fine-tuning heads are out of scope (SURVEY.md section 2, rows 18-21)")
+        self._plans = OrderedDict()
+
+    _init_weights = staticmethod(init_linear_and_norm)
+
+    # ------------------------------------------------------------------------------------------------ masking
+    def masking_noise(self, x):
+        strategy = self.args.masking_strategy
+        if strategy == "random":
+            return torch.rand(x.shape[0], self.num_patches, device=x.device)
+        if strategy in ("density", "anti-density"):
+            p = self.img_size // int(round(self.num_patches ** .5))          # AvgPool2d(32, 32) at 224 (swin.py:125)
+            return ops.density_noise(x.detach(), p, 1.0 if strategy == "density" else -1.0)
+        raise ValueError(strategy)
+
+    def random_masking(self, x, noise=None):
+        """-> (ids_keep [B,K], mask [B,L] (1 = removed), ids_restore [B,L]) on the coarse decoder grid (swin.py:109-145)."""
+        if noise is None:
+            noise = self.masking_noise(x)
+        return ops.mask_from_noise(noise.contiguous().float(), self.mask_ratio)
+
+    def _pattern_plan(self, vis_cells, device):
+        key = (vis_cells.tobytes(), str(device))
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _PatternPlan(self, vis_cells, device)
+            self._plans[key] = plan
+            if len(self._plans) > _PLAN_CACHE_SIZE:
+                self._plans.popitem(last=False)
+        else:
+            self._plans.move_to_end(key)
+        return plan
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def _run_stages(self, x, plan, want_attn):
+        B = x.shape[0]
+        ids = plan.tok_ids.unsqueeze(0).expand(B, -1).contiguous()
+        t = self.patch_embed(x, ids)
+        outs, attn = [], None
+        last = len(self.swin_block) - 1
+        for i, blk in enumerate(self.swin_block):
+            sp = plan.stages[i]
+            if i < last:
+                e, lay, t, _, _ = blk(t, sp.layout, sp)
+            else:
+                e, lay, attn = blk(t, sp.layout, sp, return_attn=want_attn)
+            outs.append((e, lay))
+        return outs, attn
+
+    def forward(self, x, mask=False, noise=None):
+        eps = self.norm_layer.eps
+        dev = x.device
+        if mask:
+            ids_keep, mask_t, ids_restore = self.random_masking(x, noise)
+            vis_cells = mask_t[0].detach().cpu().numpy() == 0          # the one host read-back of the step
+            plan = self._pattern_plan(vis_cells, dev)
+            outs, attn = self._run_stages(x, plan, True)
+            emb_stage4 = outs[-1][0]
+            if self.args.use_feature_fusion:
+                fused = []
+                for i, conv in enumerate((self.stage1_output_decode, self.stage2_output_decode, self.stage3_output_decode)):
+                    tokmap, coords, r, k = plan.fuse[i]
+                    fused.append(ops.SwinFuseConvFn.apply(outs[i][0], conv.weight, conv.bias, tokmap, coords, ids_keep,
+                                                          ids_restore, r, k))
+                s12 = ops.AddFn.apply(fused[0], fused[1])
+                emb_lh = ops.LayerNormFn.apply(s12, fused[2], emb_stage4, self.norm_layer.weight, self.norm_layer.bias, eps)
+            else:
+                emb_lh = ops.LayerNormFn.apply(emb_stage4, None, None, self.norm_layer.weight, self.norm_layer.bias, eps)
+            coords = [lay.coords_tensor(dev) for _, lay in outs]
+            return (outs[0][0], outs[1][0], outs[2][0], outs[3][0], emb_lh, coords[0], coords[1], coords[2], coords[3],
+                    mask_t, ids_restore, attn)
+
+        plan = self._pattern_plan(np.ones(self.num_patches, dtype=bool), dev)
+        outs, attn = self._run_stages(x, plan, True)
+        emb_h = ops.LayerNormFn.apply(outs[-1][0], None, None, self.norm_layer.weight, self.norm_layer.bias, eps)
+        return outs[0][0], outs[1][0], outs[2][0], outs[3][0], emb_h, attn
+
+
+def swin_tiny_window7(args, **kwargs):
+    return SwinTransformer(args=args, pretrain_img_size=224, patch_size=4, decoder_num_patches=49,
+                           embed_dim=[96, 192, 384, 768], depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7,
+                           mlp_ratio=4., norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ..backbone import convvit, vit
+from ..backbone import convvit, swin, vit
 from ..backbone.vit import init_linear_and_norm
 from ..sub_module.mlp_head import _build_mlp_2d, run_mlp_2d
 from . import pr_rec_decoder
@@ -40,7 +40,7 @@ class PrHubModel(nn.Module):
                 raise ValueError(args.model_size)
             self.backbone = convvit.__dict__[factory[args.model_size]](**common)
         elif args.backbone_type == "swin":
-            raise NotImplementedError("backbone_type=swin: not built yet on the MI355X path (DESIGN.md, scope row a15)")
+            self.backbone = swin.__dict__["swin_tiny_window7"](**common)
         else:
             raise ValueError(args.backbone_type)
 
@@ -48,7 +48,8 @@ class PrHubModel(nn.Module):
             # The reference always builds the 384-wide "small" decoder here (pr_hub_model.py:77), which cannot take
             # a 768-wide backbone (SURVEY.md header). `rec_decoder_factory` lets the base / tiny factories pick the
             # decoder that fits; the default reproduces the reference.
-            name = rec_decoder_factory or "pretrain_rec_decoder_small_patch16"
+            default = "pretrain_rec_decoder_swin_tiny_patch32" if args.backbone_type == "swin" else "pretrain_rec_decoder_small_patch16"
+            name = rec_decoder_factory or default
             self.pretrain_rec_decoder = pr_rec_decoder.__dict__[name](frame_chans=args.frame_chans)
 
         if args.pr_phase in _CON_PHASES:
@@ -61,7 +62,10 @@ class PrHubModel(nn.Module):
             self.emb_h_proj = _build_mlp_2d(proj_mlp_layers, C_out, mlp_dim, C_out)
             self.emb_h_pred = _build_mlp_2d(pred_mlp_layers, C_out, mlp_dim, C_out)
             self.norm_clip_emb = norm_layer(emb_frames_dim)
-            self.clip_emb_proj = nn.Linear(emb_frames_dim, C_out, bias=False)
+            if args.backbone_type == "swin":          # 14x14 CLIP tokens -> the 7x7 grid of the last Swin stage
+                self.clip_emb_proj = nn.Conv2d(emb_frames_dim, C_out, 2, stride=2)
+            else:
+                self.clip_emb_proj = nn.Linear(emb_frames_dim, C_out, bias=False)
         self.apply(init_linear_and_norm)
 
     # ------------------------------------------------------------------------------------------------ losses
@@ -91,18 +95,34 @@ class PrHubModel(nn.Module):
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, events_voxel_grid, supp_data, is_rec=False, noise=None):
+        swin_ = self.backbone_type == "swin"
+        if is_rec and swin_:
+            (emb_l1, emb_l2, emb_l3, emb_l4, emb_lh, coords_l1, coords_l2, coords_l3, coords_l4, mask, ids_restore,
+             attn) = self.backbone(events_voxel_grid, mask=True, noise=noise)
+            reconstruct_pred = self.pretrain_rec_decoder(emb_lh, ids_restore)
+            reconstruct_loss = self.reconstruct_loss(reconstruct_pred, supp_data, mask)
+            return (reconstruct_loss, emb_l1, emb_l2, emb_l3, emb_l4, emb_lh, coords_l1, coords_l2, coords_l3, coords_l4,
+                    reconstruct_pred, mask, ids_restore, attn)
         if is_rec:
             emb_l1, emb_l2, emb_lh, mask, ids_restore = self.backbone(events_voxel_grid, mask=True, noise=noise)
             reconstruct_pred = self.pretrain_rec_decoder(emb_lh, ids_restore)
             reconstruct_loss = self.reconstruct_loss(reconstruct_pred, supp_data, mask)
             return reconstruct_loss, emb_l1, emb_l2, emb_lh, reconstruct_pred, mask, ids_restore
 
-        _, _, emb_h, attn = self.backbone(events_voxel_grid)
+        if swin_:
+            _, _, _, _, emb_h, attn = self.backbone(events_voxel_grid)
+        else:
+            _, _, emb_h, attn = self.backbone(events_voxel_grid)
         emb_h_org = emb_h.detach().clone()
         clip_emb = ops.LayerNormFn.apply(supp_data[:, 1:, :], None, None, self.norm_clip_emb.weight,
                                          self.norm_clip_emb.bias, self.norm_clip_emb.eps)
         clip_emb_org = clip_emb.detach().clone()
-        clip_emb_proj = ops.LinearFn.apply(clip_emb, self.clip_emb_proj.weight, None)
+        if swin_:
+            g = int(round(clip_emb.shape[1] ** 0.5))
+            clip_emb_proj = ops.StridedConvTokensFn.apply(clip_emb, None, self.clip_emb_proj.weight, self.clip_emb_proj.bias,
+                                                          2, g, g)
+        else:
+            clip_emb_proj = ops.LinearFn.apply(clip_emb, self.clip_emb_proj.weight, None)
         emb_h = run_mlp_2d(self.emb_h_proj, emb_h)
         emb_h_proj = run_mlp_2d(self.emb_h_pred, emb_h)
         if self.args.use_queue:
@@ -124,6 +144,12 @@ def concat_all_gather(tensor):
 
 def pretrain_hub_model_small_patch16(args, **kwargs):
     return PrHubModel(args=args, patch_size=16, num_patches=196, embed_dim=[128, 256, 384], mlp_dim=4096,
+                      proj_mlp_layers=3, pred_mlp_layers=2, norm_layer=nn.LayerNorm, **kwargs)
+
+
+def pretrain_hub_model_swin_tiny_patch16(args, **kwargs):
+    """Swin-T hub (BASELINE.json config 5): 49 decoder cells of 32x32 pixels (pr_hub_model.py:269-274)."""
+    return PrHubModel(args=args, patch_size=32, num_patches=49, embed_dim=[96, 192, 384, 768], mlp_dim=4096,
                       proj_mlp_layers=3, pred_mlp_layers=2, norm_layer=nn.LayerNorm, **kwargs)
 
 

@@ -1079,3 +1079,208 @@ def conv_block(x, blk, H, W, mask=None, mask_scale=1):
     return ConvBlockFn.apply(x, blk.norm1.weight, blk.norm1.bias, blk.conv1.weight, blk.conv1.bias, blk.attn.weight, blk.attn.bias,
                              blk.conv2.weight, blk.conv2.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight,
                              blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, mask, mask_scale, H, W)
+
+
+# ----------------------------------------------------------------------------------------------------- Swin (row a15)
+def gather_rows(x, idx, n_in=None):
+    """out[b,s,:] = idx[s] >= 0 ? x[b,idx[s],:] : 0 for f32 tokens [B,n_in,C]; idx int32 [n_out] shared by the batch."""
+    B, n, C = x.shape
+    n_out = idx.shape[0]
+    out = torch.empty(B, n_out, C, dtype=torch.float32, device=x.device)
+    call("evp_gather_rows_f32", ptr(_chk(x, torch.float32)), ptr(_chk(idx, torch.int32)), ptr(out), B, n, n_out, C, 0, stream_ptr())
+    return out
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """GroupingModule.group / merge and PatchMerging's regrouping (swin_block.py:454-466,193-201) as one row gather.
+    `idx_bwd` is the index of the adjoint gather: the real entries of `idx_fwd` form a permutation, padding slots
+    (which the reference fills with a copy of token 0 and later drops) receive and send no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, idx_fwd, idx_bwd):
+        ctx.save_for_backward(idx_bwd)
+        return gather_rows(x.detach().contiguous(), idx_fwd)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx_bwd,) = ctx.saved_tensors
+        return gather_rows(g.contiguous(), idx_bwd), None, None
+
+
+class PatchProjFn(torch.autograd.Function):
+    """Conv2d(k=s=patch) of an NCHW f32 image evaluated only at the tokens `ids_keep` (int64 [B,n_keep]), returned as
+    f32 tokens [B,n_keep,D] (swin_block.py:58-62 before its norm; gathering first is equivalent, every step is per token)."""
+
+    @staticmethod
+    def forward(ctx, x, ids_keep, w, b, patch):
+        B, Cc, H, W = x.shape
+        L = (H // patch) * (W // patch)
+        n_keep = L if ids_keep is None else ids_keep.shape[1]
+        D = w.shape[0]
+        Kc = Cc * patch * patch
+        M = B * n_keep
+        cols = torch.empty(M, Kc, dtype=_compute_dtype, device=x.device)
+        call("evp_patchify", ptr(_chk(x.detach(), torch.float32)), ptr(ids_keep), B, Cc, H, W, patch, n_keep, ptr(cols),
+             dt(cols), stream_ptr())
+        y = torch.empty(M, D, dtype=torch.float32, device=x.device)
+        gemm(cols, lp_weight(w).view(D, Kc), y, M=M, N=D, K=Kc, bias=b)
+        ctx.save_for_backward(cols)
+        ctx.wshape = tuple(w.shape)
+        ctx.prm = (w, b)
+        return y.view(B, n_keep, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        (cols,) = ctx.saved_tensors
+        M, Kc = cols.shape
+        D = ctx.wshape[0]
+        g2d = _chk(g.contiguous(), torch.float32).view(M, D)
+        gl = cast(g2d, cols.dtype)
+        dw = _wgrad(gl, cols, D, Kc, M, ctx.prm[0], ctx.wshape) if ctx.needs_input_grad[2] else None
+        db = _bgrad(g2d, ctx.prm[1]) if ctx.needs_input_grad[3] else None
+        return None, None, dw, db, None
+
+
+class SwinFuseConvFn(torch.autograd.Function):
+    """swin.py:201-208: scatter the visible stage tokens into a zero R x R grid, Conv2d(k, stride k) down to the
+    decoder grid, gather each sample's ids_keep cells -- formed directly as the [B*K, C*k*k] patch rows of the kept
+    cells times weight.view(out, C*k*k)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, tokmap, coords, ids_keep, ids_restore, R, k):
+        B, n, C = x.shape
+        K = ids_keep.shape[1]
+        Dout = w.shape[0]
+        Kc = C * k * k
+        M = B * K
+        A = torch.empty(M, Kc, dtype=torch.float32, device=x.device)
+        call("evp_swin_fuse_gather_f32", ptr(_chk(x.detach().contiguous(), torch.float32)), ptr(_chk(tokmap, torch.int32)),
+             ptr(_chk(ids_keep, torch.int64)), ptr(A), B, n, K, C, R, k, stream_ptr())
+        Al = cast(A, _compute_dtype)
+        wl = lp_weight(w).view(Dout, Kc)
+        y = torch.empty(M, Dout, dtype=torch.float32, device=x.device)
+        gemm(Al, wl, y, M=M, N=Dout, K=Kc, bias=b)
+        ctx.save_for_backward(Al, wl, coords, ids_restore)
+        ctx.dims = (B, n, K, C, R, k, Dout, Kc)
+        ctx.wshape = tuple(w.shape)
+        ctx.prm = (w, b)
+        return y.view(B, K, Dout)
+
+    @staticmethod
+    def backward(ctx, g):
+        Al, wl, coords, ids_restore = ctx.saved_tensors
+        B, n, K, C, R, k, Dout, Kc = ctx.dims
+        M = B * K
+        g2d = _chk(g.contiguous(), torch.float32).view(M, Dout)
+        gl = cast(g2d, Al.dtype)
+        dw = _wgrad(gl, Al, Dout, Kc, M, ctx.prm[0], ctx.wshape) if ctx.needs_input_grad[1] else None
+        db = _bgrad(g2d, ctx.prm[1]) if ctx.needs_input_grad[2] else None
+        dA = torch.empty(M, Kc, dtype=torch.float32, device=g.device)
+        gemm(gl, wl, dA, M=M, N=Kc, K=Dout, trans_b=True, ldb=Kc)
+        dx = torch.empty(B, n, C, dtype=torch.float32, device=g.device)
+        call("evp_swin_fuse_gather_bwd_f32", ptr(dA), ptr(coords), ptr(ids_restore), ptr(dx), B, n, K, C, R, k, stream_ptr())
+        return dx, dw, db, None, None, None, None, None, None
+
+
+class SwinBlockFn(torch.autograd.Function):
+    """SwinTransformerBlock.forward (swin_block.py:260-273) on grouped tokens [Bg, N, D] (Bg = batch * n_groups):
+    pre-LN, window attention with the gathered relative-position bias and the -100 group mask (:135-158), MLP."""
+
+    @staticmethod
+    def forward(ctx, x, table, rel, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, heads, eps, want_attn):
+        Bg, N, D = x.shape
+        nG = rel.shape[0]
+        M = Bg * N
+        dh = D // heads
+        if dh != 32:
+            raise _lib.EvpError(f"window attention kernel is built for d_h=32 (got {dh})")
+        T = _compute_dtype
+        dev = x.device
+        x2d = _chk(x.detach().contiguous(), torch.float32).view(M, D)
+        wq, wp, w1, w2 = lp_weight(qkvw), lp_weight(pw), lp_weight(f1w), lp_weight(f2w)
+        ln1, mean1, rstd1 = layernorm_fwd(x2d, n1w, n1b, eps, T)
+        qkv = torch.empty(M, 3 * D, dtype=T, device=dev)
+        gemm(ln1, wq, qkv, M=M, N=3 * D, K=D, bias=qkvb)
+        att = torch.empty(M, D, dtype=T, device=dev)
+        probs = torch.empty(Bg, heads, N, N, dtype=torch.float32, device=dev) if want_attn else None
+        tab = _chk(table.detach(), torch.float32)
+        R = tab.shape[0]
+        scale = dh ** -0.5
+        call("evp_window_attention_fwd", ptr(qkv), ptr(tab), ptr(_chk(rel, torch.int32)), ptr(att), ptr(probs), Bg, nG, N, heads, R,
+             scale, dt(qkv), stream_ptr())
+        x1 = torch.empty(M, D, dtype=torch.float32, device=dev)
+        gemm(att, wp, x1, M=M, N=D, K=D, bias=pb, residual=x2d)
+        ln2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, eps, T)
+        Hd = f1w.shape[0]
+        h_pre = torch.empty(M, Hd, dtype=T, device=dev)
+        h_act = torch.empty(M, Hd, dtype=T, device=dev)
+        gemm(ln2, w1, h_act, M=M, N=Hd, K=D, bias=f1b, act=ACT_GELU, aux=h_pre)
+        x2 = torch.empty(M, D, dtype=torch.float32, device=dev)
+        gemm(h_act, w2, x2, M=M, N=D, K=Hd, bias=f2b, residual=x1)
+        ctx.save_for_backward(x2d, n1w, n2w, mean1, rstd1, ln1, qkv, att, x1, mean2, rstd2, ln2, h_pre, h_act, wq, wp, w1, w2,
+                              tab, rel)
+        ctx.dims = (Bg, nG, N, D, heads, dh, Hd, R, scale)
+        ctx.prm = (qkvw, qkvb, pw, pb, f1w, f1b, f2w, f2b)
+        out = x2.view(Bg, N, D)
+        if want_attn:
+            ctx.mark_non_differentiable(probs)
+            return out, probs
+        return out
+
+    @staticmethod
+    def backward(ctx, g2, *_):
+        (x2d, n1w, n2w, mean1, rstd1, ln1, qkv, att, x1, mean2, rstd2, ln2, h_pre, h_act, wq, wp, w1, w2, tab, rel) = \
+            ctx.saved_tensors
+        Bg, nG, N, D, heads, dh, Hd, R, scale = ctx.dims
+        M = Bg * N
+        T = qkv.dtype
+        dev = g2.device
+        bf = T == torch.bfloat16
+        g2 = _chk(g2.contiguous(), torch.float32).view(M, D)
+        g2_lp = cast(g2, T)
+        qkvw_, qkvb_, pw_, pb_, f1w_, f1b_, f2w_, f2b_ = ctx.prm
+        need = ctx.needs_input_grad
+        db2 = _bgrad(g2, f2b_) if need[14] else None
+        dw2 = _wgrad(g2_lp, h_act, D, Hd, M, f2w_) if need[13] else None
+        dh_pre = torch.empty(M, Hd, dtype=T, device=dev)
+        gemm(g2_lp, w2, dh_pre, M=M, N=Hd, K=D, trans_b=True, ldb=Hd, act=ACT_DGELU, aux=h_pre)
+        db1 = _bgrad(dh_pre, f1b_) if need[12] else None
+        dw1 = _wgrad(dh_pre, ln2, Hd, D, M, f1w_) if need[11] else None
+        dln2 = torch.empty(M, D, dtype=T, device=dev)
+        gemm(dh_pre, w1, dln2, M=M, N=D, K=Hd, trans_b=True, ldb=D)
+        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf)
+        if not bf:
+            g1_lp = g1
+        dbp = _bgrad(g1, pb_) if need[8] else None
+        dwp = _wgrad(g1_lp, att, D, D, M, pw_) if need[7] else None
+        datt = torch.empty(M, D, dtype=T, device=dev)
+        gemm(g1_lp, wp, datt, M=M, N=D, K=D, trans_b=True, ldb=D)
+        dqkv = torch.empty(M, 3 * D, dtype=T, device=dev)
+        dtable = torch.empty(R, heads, dtype=torch.float32, device=dev)
+        call("evp_window_attention_bwd", ptr(qkv), ptr(tab), ptr(rel), ptr(att), ptr(datt), ptr(dqkv), ptr(dtable), Bg, nG, N, heads,
+             R, scale, dt(qkv), stream_ptr())
+        dbq = _bgrad(dqkv, qkvb_) if need[6] else None
+        dwq = _wgrad(dqkv, ln1, 3 * D, D, M, qkvw_) if need[5] else None
+        dln1 = torch.empty(M, D, dtype=T, device=dev)
+        gemm(dqkv, wq, dln1, M=M, N=D, K=3 * D, trans_b=True, ldb=D)
+        g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1)
+        return (g0.view(Bg, N, D), dtable, None, dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None)
+
+
+def swin_block(x, blk, rel, eps, want_attn=False):
+    a = blk.attn
+    return SwinBlockFn.apply(x, a.relative_position_bias_table, rel, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias,
+                             a.proj.weight, a.proj.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+                             blk.mlp.fc2.weight, blk.mlp.fc2.bias, a.num_heads, eps, want_attn)
+
+
+class AddFn(torch.autograd.Function):
+    """a + b on f32 tokens (the 4-way stage sum of swin.py:239 exceeds LayerNormFn's three fused inputs)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return add(a.detach().contiguous(), b.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g

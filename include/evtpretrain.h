@@ -277,6 +277,45 @@ int evp_infonce_queue(const float *pos, const float *neg, int64_t R, int K, int6
 /* _dequeue_and_enqueue (pr_hub_model.py:112-122): queue[c,l,ptr+b] = keys[b,l,c]; queue float32 [C,L,K]. */
 int evp_enqueue_keys(float *queue, const float *keys, int ptr, int B, int L, int C, int K, void *stream);
 
+/* ------------------------------------------------------------------------------------------------ K17 Swin windows
+ * Grouped window attention with the gathered relative-position bias, replacing WindowAttention.forward's core
+ * (model/sub_module/swin_block.py:135-158) for every head width d_h = 32 (all four Swin-T stages):
+ *   S = (scale*q) k^T + bias,  bias[g,i,j] = rel[g,i,j] >= 0 ? table[rel[g,i,j], h] : -100,  P = softmax(S),  out = P v.
+ * qkv dtype [Bg, N, 3, H, 32] (the packed qkv Linear output), Bg = batch * nG with group index g = bg % nG;
+ * table float32 [R, H] (relative_position_bias_table); rel int32 [nG, N, N] with -1 marking the pairs the
+ * reference masks (different window, or padding: it zeroes their bias and adds -100, :140-149);
+ * out dtype [Bg, N, H*32]; probs (may be NULL) float32 [Bg, H, N, N]. N <= 128, R <= 512. */
+int evp_window_attention_fwd(const void *qkv, const float *table, const int32_t *rel, void *out, float *probs, int Bg,
+                             int nG, int N, int H, int R, float scale, int dtype, void *stream);
+/* Backward of the above: recomputes P, writes dqkv (same layout as qkv) and dtable float32 [R, H] (zeroed here,
+ * accumulated with LDS-privatised atomics; masked pairs contribute nothing, as in the reference). `out` is the
+ * forward output (used for rowsum(P*dP) = dO.O). */
+int evp_window_attention_bwd(const void *qkv, const float *table, const int32_t *rel, const void *out,
+                             const void *dout, void *dqkv, float *dtable, int Bg, int nG, int N, int H, int R,
+                             float scale, int dtype, void *stream);
+/* Token row gather used by GroupingModule.group/merge (swin_block.py:454-466) and PatchMerging's 2x2 regrouping
+ * (:193-201): out[b, s, :] = idx[s] >= 0 ? x[b, idx[s], :] : 0; x float32 [B, n_in, C], out float32 [B, n_out, C],
+ * idx int32 [n_out] (shared by the batch) or [B, n_out] when idx_per_sample != 0. C % 4 == 0. The backward of a
+ * gather whose real (non-padding) indices form a permutation is the same call with the inverse index. */
+int evp_gather_rows_f32(const float *x, const int32_t *idx, float *out, int B, int n_in, int n_out, int C,
+                        int idx_per_sample, void *stream);
+/* Stage-fusion patch rows (model/backbone/swin.py:201-208,213-218,223-228: zero grid, scatter visible tokens,
+ * Conv2d(k, stride k), gather by ids_keep): A float32 [B*K, C*k*k] holds, for each kept decoder cell
+ * ids_keep[b][j] (int64 [B,K]) of the (R/k)x(R/k) grid, the k*k tokens under it in Conv2d weight order (c, ky, kx);
+ * hidden positions give zeros. x float32 [B, n, C] visible tokens, tokmap int32 [R*R] dense position -> token
+ * index or -1. The conv itself is then one GEMM against weight.view(out, C*k*k). */
+int evp_swin_fuse_gather_f32(const float *x, const int32_t *tokmap, const int64_t *ids_keep, float *A, int B, int n,
+                             int K, int C, int R, int k, void *stream);
+/* Its backward: dx float32 [B, n, C] from dA; coords int32 [n, 2] (row, col of each visible token),
+ * ids_restore int64 [B, (R/k)^2] (a cell is kept iff ids_restore < K, and then sits at row ids_restore). */
+int evp_swin_fuse_gather_bwd_f32(const float *dA, const int32_t *coords, const int64_t *ids_restore, float *dx, int B,
+                                 int n, int K, int C, int R, int k, void *stream);
+/* HOST function (no GPU work): group_windows of swin_block.py:322-347 with knapsack :277-319. counts int32
+ * [n_windows] visible tokens per window (1..cap); outputs group_of_window int32 [n_windows], group_sizes int32
+ * [<= n_windows] tokens per group, *n_groups. Inside a group the windows keep increasing index order. */
+int evp_swin_group_windows(const int32_t *counts, int n_windows, int cap, int32_t *group_of_window,
+                           int32_t *group_sizes, int32_t *n_groups);
+
 #ifdef __cplusplus
 }
 #endif

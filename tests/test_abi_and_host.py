@@ -113,3 +113,38 @@ def test_checkpoint_key_remap():
     assert set(out) == {"backbone.norm_layer.weight", "backbone.norm_layer.bias", "backbone.vit_block.0.norm1.weight"}
     out = remap_stage_checkpoint({"backbone.norm_h.weight": 1}, "con")
     assert set(out) == {"backbone.norm_layer.weight"}
+
+
+def test_swin_host_grouping_matches_oracle():
+    """Host-side window grouping of the Swin path (knapsack in C, index tables in numpy) against the oracle's restatement
+    of swin_block.py:277-452, on the reference fixture's token coordinates and on random window occupancies."""
+    import torch
+    from conftest import load_golden
+    from oracle import model_oracle as mo
+    from eventpretrain_amd.model.sub_module.swin_block import GroupingModule, PatchMerging, TokenLayout, group_windows, knapsack
+    rng = np.random.default_rng(3)
+    for _ in range(100):
+        cap = int(rng.integers(4, 50))
+        wt = rng.integers(1, cap + 1, size=int(rng.integers(1, 30))).tolist()
+        assert knapsack(cap, wt) == mo.swin_knapsack(cap, wt)
+        assert group_windows(cap, wt) == mo.swin_group_windows(cap, wt)
+    d = load_golden("rec_swin_tiny")
+    for lvl, res in ((1, 56), (2, 28), (3, 14), (4, 7)):
+        c = d[f"coords_l{lvl}"][0]
+        for shift in (0, 3):
+            if res <= 7 and shift:
+                continue
+            p = GroupingModule(7, shift).plan(c, c.shape[0])
+            o = mo.swin_plan(torch.from_numpy(c), 7, shift, c.shape[0])
+            assert p["mode"] == o["mode"]
+            assert np.array_equal(p["rel"], np.where((o["mask"] != 0).numpy(), -1, o["rel"].numpy()))
+            if p["mode"] == "grouping":
+                assert np.array_equal(p["gather"], o["gather"].numpy()) and np.array_equal(p["scatter"], o["scatter"].numpy())
+                assert np.array_equal(p["scatter_adj"][p["gather_adj"]], np.arange(c.shape[0]))
+    vis_cells = d["mask"][0] == 0
+    vis = np.repeat(np.repeat(vis_cells.reshape(7, 7), 8, 0), 8, 1).reshape(-1)
+    ys, xs = np.nonzero(vis.reshape(56, 56))
+    lay = TokenLayout(np.stack([ys, xs], -1), vis, 56)
+    assert np.array_equal(lay.coords, d["coords_l1"][0])
+    rows, inv, lay2 = PatchMerging.plan(lay)
+    assert np.array_equal(lay2.coords, d["coords_l2"][0]) and np.array_equal(rows[inv], np.arange(lay.n))
