@@ -14,7 +14,7 @@ module object supplying `to_2tuple`, `trunc_normal_` and a `DropPath` that is
 never executed (all drop rates are 0 -> nn.Identity, vit_block.py:241) is put
 in sys.modules for the duration of this script.
 
-Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin]
+Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin,swincon]
 """
 import argparse
 import json
@@ -494,8 +494,36 @@ def gen_con():
         save("con_small_queue" if use_queue else "con_small_noqueue", **out)
 
 
+def gen_swincon():
+    """PrHubModel.forward(is_rec=False) on the Swin-T hub with the queue (dense Swin forward swin.py:248-290, Conv2d
+    CLIP-token projection pr_hub_model.py:219-220), B=2, queue_length=4."""
+    _ref()
+    from model.pretrain.pr_hub_model import pretrain_hub_model_swin_tiny_patch16
+    a = make_args(model_size="tiny", pr_phase="con", backbone_type="swin", use_queue=True, mask_ratio=0.0)
+    hub = pretrain_hub_model_swin_tiny_patch16(a, emb_frames_dim=512, queue_length=4, T=0.07)
+    det_fill_module_(hub)
+    hub.train(True)
+    x = det_normalish("con.voxels", (2, 5, 224, 224)) * 0.5
+    clip = det_normalish("con.clip_emb", (2, 197, 512))
+    loss, emb_h_org, emb_h_proj, clip_org, clip_proj, attn = hub(x, clip)
+    loss.backward()
+    out = dict(loss=loss.detach().double(), emb_h_org_checksums=checksums(emb_h_org),
+               emb_h_proj_checksums=checksums(emb_h_proj), clip_org_checksums=checksums(clip_org),
+               clip_proj_checksums=checksums(clip_proj), attn_checksums=checksums(attn), attn_shape=np.array(attn.shape))
+    names, gn = [], []
+    for n, p in hub.named_parameters():
+        if p.grad is not None:
+            names.append(n)
+            gn.append(p.grad.double().norm().item())
+    out["grad_names"], out["grad_norms"] = np.array(json.dumps(names)), np.array(gn)
+    out["queue_after_checksums"] = checksums(hub.queue)
+    out["queue_ptr_after"] = hub.queue_ptr.clone()
+    out["state_keys"] = np.array(json.dumps({k: list(v.shape) for k, v in hub.state_dict().items()}))
+    save("con_swin_tiny_queue", **out)
+
+
 GENS = dict(voxel=gen_voxel, pos=gen_pos, mask=gen_mask, tiny=lambda: gen_composed("tiny"), small=gen_small,
-            base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall, swin=gen_swin)
+            base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall, swin=gen_swin, swincon=gen_swincon)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

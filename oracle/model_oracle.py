@@ -511,6 +511,37 @@ def con_step(sd, x, clip_emb, cfg, training=True, rank=0, gather=None):
     return loss, emb_h_org, h, clip_org, clip_proj, attn, side
 
 
+def swin_dense(sd, x, cfg, pre="backbone."):
+    """swin.py:248-290 (pretrain phases): every cell visible, LN of the last stage; returns the last block's probs."""
+    t = F.conv2d(x, sd[pre + "patch_embed.proj.weight"], sd[pre + "patch_embed.proj.bias"], stride=4).flatten(2).transpose(1, 2)
+    t = layer_norm(t, sd[pre + "patch_embed.norm.weight"], sd[pre + "patch_embed.norm.bias"], 1e-6)
+    res = cfg["input"] // 4
+    yy, xx = torch.meshgrid(torch.arange(res), torch.arange(res), indexing="ij")
+    coords = torch.stack([yy.reshape(-1), xx.reshape(-1)], -1)
+    outs, attn = swin_stages(sd, t, coords, torch.ones(res * res, dtype=torch.bool), cfg, pre)
+    return outs, layer_norm(outs[-1][0], sd[pre + "norm_layer.weight"], sd[pre + "norm_layer.bias"], 1e-6), attn
+
+
+def swin_con_step(sd, x, clip_emb, cfg, training=True):
+    """PrHubModel.forward(is_rec=False) for the Swin backbone with the queue (pr_hub_model.py:208-245): the CLIP tokens
+    go through Conv2d(512, 768, 2, stride 2) on their 14x14 grid (:219-220) to meet the 7x7 grid of the last stage."""
+    _, emb_h, attn = swin_dense(sd, x, cfg)
+    emb_h_org = emb_h.detach().clone()
+    clip = layer_norm(clip_emb[:, 1:, :], sd["norm_clip_emb.weight"], sd["norm_clip_emb.bias"], 1e-5)
+    clip_org = clip.detach().clone()
+    B, L, Cc = clip.shape
+    g = int(round(L ** 0.5))
+    cmap = clip.transpose(1, 2).reshape(B, Cc, g, g)
+    clip_proj = F.conv2d(cmap, sd["clip_emb_proj.weight"], sd["clip_emb_proj.bias"], stride=2).flatten(2).transpose(1, 2)
+    h, s1 = mlp_head(sd, "emb_h_proj.", emb_h, 3, training)
+    h, s2 = mlp_head(sd, "emb_h_pred.", h, 2, training)
+    side = {**s1, **s2}
+    loss, k = info_nce_queue(h, clip_proj, sd["queue"], cfg["T"])
+    side["queue"], ptr = enqueue(sd["queue"], int(sd["queue_ptr"]), k)
+    side["queue_ptr"] = torch.tensor([ptr])
+    return loss, emb_h_org, h, clip_org, clip_proj, attn, side
+
+
 # ----------------------------------------------------------------------------- optimiser-side glue
 def cosine_lr(epoch, lr, min_lr, warmup_epochs, epochs):
     """utils/lr_sched.py:3-16."""

@@ -249,3 +249,60 @@ def test_swin_plan_cache_and_second_pattern():
     exp_mask = torch.ones(2, 49)
     exp_mask.scatter_(1, keep, 0.0)
     assert torch.equal(out[11].cpu(), exp_mask) and math.isfinite(out[0].item())
+
+
+def test_swin_contrastive_stage_f32_matches_reference():
+    """PrHubModel.forward(is_rec=False) on the Swin-T hub: dense Swin forward (64/16/4 full windows + one 49-token group),
+    Conv2d(512,768,2,2) CLIP-token projection, MoCo heads, queue InfoNCE and enqueue -- against the reference's outputs."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.testing import det_normalish
+    d = load_golden("con_swin_tiny_queue")
+    a, m = _swin_hub(pr_phase="con", use_queue=True, mask_ratio=0.0)
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == jl(d["state_keys"])
+    x = det_normalish("con.voxels", (2, 5, 224, 224)) * 0.5
+    clip = det_normalish("con.clip_emb", (2, 197, 512))
+    ops.set_compute_dtype(torch.float32)
+    loss, h_org, h_proj, c_org, c_proj, attn = m(x.cuda(), clip.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(d["loss"])) <= F32_LOSS_RTOL * abs(float(d["loss"]))
+    assert list(attn.shape) == list(d["attn_shape"])
+    assert_checksums(h_org, d["emb_h_org_checksums"], 1e-4)
+    assert_checksums(h_proj, d["emb_h_proj_checksums"], 2e-4)
+    assert_checksums(c_org, d["clip_org_checksums"], 1e-4)
+    assert_checksums(c_proj, d["clip_proj_checksums"], 1e-4)
+    assert_checksums(attn.float(), d["attn_checksums"], 1e-4)
+    params = dict(m.named_parameters())
+    for n, gn in zip(jl(d["grad_names"]), d["grad_norms"]):
+        assert params[n].grad is not None, n
+        assert params[n].grad.double().norm().item() == pytest.approx(gn, rel=5e-3, abs=2e-6), n
+    assert_checksums(m.queue, d["queue_after_checksums"], 1e-5)
+    assert int(m.queue_ptr) == int(d["queue_ptr_after"][0])
+    assert len(m.backbone._plans) == 1
+
+
+def test_swin_trainer_epoch_runs_and_learns():
+    """The reference's epoch loop signature on the Swin hub with FusedAdamW: 4 steps on one repeated batch lower the loss."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.optim import FusedAdamW
+    from eventpretrain_amd.testing import det_normalish
+    from eventpretrain_amd.trainer.pretrain.pr_trainer import pr_rec_one_epoch
+    from eventpretrain_amd.utils import lr_decay as lrd
+    from eventpretrain_amd.utils.misc import NativeScalerWithGradNormCount
+    a, m = _swin_hub()
+    a.lr, a.min_lr, a.warmup_epochs, a.epochs, a.batch_size = 2e-3, 1e-6, 0, 4, 2
+    x = det_normalish("swin.voxels", (2, 5, 224, 224)) * 0.5
+    y = det_normalish("swin.sub_frame", (2, 1, 224, 224))
+    loader = [dict(events_voxel_grid=x, sub_frame=y, image_name=["a", "b"])] * 4
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(0)
+        opt = FusedAdamW(lrd.param_groups_lrd(a, m, a.weight_decay, layer_decay=1), lr=a.lr, betas=(0.9, 0.95))
+        scaler = NativeScalerWithGradNormCount()
+        first = pr_rec_one_epoch(a, m, loader[:1], opt, 0, scaler)["reconstruct_loss"]
+        for ep in range(1, 4):
+            last = pr_rec_one_epoch(a, m, loader[:1], opt, ep, scaler)["reconstruct_loss"]
+    finally:
+        ops.set_compute_dtype(torch.float32)
+    print(f"[swin-tiny] trainer loss {first:.4f} -> {last:.4f}")
+    assert math.isfinite(last) and last < first
