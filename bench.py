@@ -362,21 +362,29 @@ def main():
         grouped = {}
         orig_call = _ops.call
 
+        GROUPED = {"evp_gemm_grouped_tn_bf16": ("gemm_grouped_tn_kernel<128,128>", 128),
+                   "evp_gemm_grouped_tn256_bf16": ("gemm256_grouped_tn_kernel (256x256 ring)", 256)}
+
         def timed_call(name, *a_):
-            if name != "evp_gemm_grouped_tn_bf16":
+            if name not in GROUPED:
                 return orig_call(name, *a_)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = orig_call(name, *a_)
             e1.record()
-            grouped["ev"] = (e0, e1)
+            grouped.setdefault(name, {})["ev"] = (e0, e1)
             return r
 
         orig_flush = _ops._deferred.flush
 
         def counting_flush():
-            grouped["flops"] = sum(2.0 * n_out * k_in * rows for (_, _, _, n_out, k_in, rows) in _ops._deferred.w)
-            grouped["tiles"] = sum(((n_out + 127) // 128) * ((k_in + 127) // 128) for (_, _, _, n_out, k_in, rows) in _ops._deferred.w)
+            for (_, _, _, n_out, k_in, rows) in _ops._deferred.w:
+                big = _ops._use_wgrad256 and rows % 64 == 0 and n_out >= 256 and k_in >= 256      # the routing rule of flush()
+                name = "evp_gemm_grouped_tn256_bf16" if big else "evp_gemm_grouped_tn_bf16"
+                T_ = GROUPED[name][1]
+                g_ = grouped.setdefault(name, {})
+                g_["flops"] = g_.get("flops", 0.0) + 2.0 * n_out * k_in * rows
+                g_["tiles"] = g_.get("tiles", 0) + ((n_out + T_ - 1) // T_) * ((k_in + T_ - 1) // T_)
             return orig_flush()
 
         _ops.call, _ops._deferred.flush = timed_call, counting_flush
@@ -386,13 +394,15 @@ def main():
         _ops.call, _ops._deferred.flush = orig_call, orig_flush
         ks = timer.summary()
         timer.calls = []
-        if "ev" in grouped:
-            torch.cuda.synchronize()
-            sec = grouped["ev"][0].elapsed_time(grouped["ev"][1]) * 1e-3
-            ks.append(dict(kernel="gemm_grouped_tn_kernel<128,128> (all weight gradients of the step, %d tiles)" % grouped["tiles"],
-                           launches_per_step=1, avg_us=sec * 1e6, tflops=grouped["flops"] / sec / 1e12, ms_per_step=sec * 1e3,
-                           flops_per_step=grouped["flops"]))
-            ks.sort(key=lambda d: -d["ms_per_step"])
+        torch.cuda.synchronize()
+        for name, g_ in grouped.items():
+            if "ev" not in g_:
+                continue
+            sec = g_["ev"][0].elapsed_time(g_["ev"][1]) * 1e-3
+            ks.append(dict(kernel="%s (weight gradients of the step, %d tiles)" % (GROUPED[name][0], g_["tiles"]),
+                           launches_per_step=1, avg_us=sec * 1e6, tflops=g_["flops"] / sec / 1e12, ms_per_step=sec * 1e3,
+                           flops_per_step=g_["flops"]))
+        ks.sort(key=lambda d: -d["ms_per_step"])
         if ks:
             top = ks[0]
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3

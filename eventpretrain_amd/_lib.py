@@ -37,6 +37,7 @@ SIGNATURES = {
     "evp_density_noise": [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "evp_gemm": [C.POINTER(GemmDesc), _vp],
     "evp_gemm_grouped_tn_bf16": [_vp, _vp, _i, _vp],
+    "evp_gemm_grouped_tn256_bf16": [_vp, _vp, _i, _vp],
     "evp_gemm_set_variant": [_i],
     "evp_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp, _i, _vp, _vp, _vp],
     "evp_layernorm_bwd_nblk": [_i64],

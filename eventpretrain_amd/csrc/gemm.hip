@@ -11,6 +11,8 @@
 // Replaces the reference's nn.Linear / matmul / einsum call sites listed in include/evtpretrain.h (evp_gemm).
 #include "evp_common.h"
 
+#include <type_traits>
+
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short i16x4;
@@ -606,6 +608,212 @@ int launch(const evp_gemm_desc *d, hipStream_t s) {
   return EVP_OK;
 }
 
+
+// ---- 256x256x64 tile, 8 waves, half-tile ring ("8-phase" schedule) ----------------------------------------------
+// The 128x128 body above re-reads 16 KiB of LDS per wave for every 32 MFMAs, which is exactly the LDS port's rate at
+// MFMA peak: that structure tops out near 900 TFLOP/s. Here a wave owns 128x64 of a 256x256 tile (24 KiB per 64 MFMAs)
+// and the K loop is cut into four phases per K tile, each = [fragment ds_reads | one half-tile of LDS-DMA prefetch |
+// counted vmcnt] barrier [16 MFMAs on one 64x32 quadrant] barrier. The two wave rows (wr = 0 / 1; waves w and w+4 share
+// a SIMD) run one barrier apart, so one row's MFMA cluster overlaps the other row's ds_read / prefetch segment.
+// (Issuing the next phase's ds_reads under the same wave's MFMAs instead measured 20 % slower: the segments must stay
+// separate.) One workgroup per CU (128 KiB of LDS): it pays where there are many tiles and a long K -- the weight
+// gradients (K = batch x tokens) -- and not on the forward / dgrad shapes of this path, whose 75-300 tiles of 256x256
+// quantise badly on 256 CUs.
+//
+// Half-tiles (128 rows x 64 k, 16 KiB) in the order the phases first need them:
+//   h=0 A(mh=0): rows wr*128 +      [0,64)   needed in phase 1        h=2 B(nh=1): cols wc*64 + 32 + [0,32)  phase 2
+//   h=1 B(nh=0): cols wc*64 +       [0,32)   needed in phase 1        h=3 A(mh=1): rows wr*128 + 64 + [0,64) phase 3
+// Ring of 8 slots (2 K tiles x 4). Half-tile s = 4t+h is issued in global phase s-5 and every phase ends its first
+// segment with vmcnt(6): everything but the three newest half-tiles has landed, i.e. all s <= g+2, which is what phase
+// g+1 reads (RAW: the wait sits before that phase's barriers, the read one phase later). A slot is re-staged >= 3
+// phases after its last ds_read (WAR), also across the one-barrier stagger of the two wave rows.
+template <typename TC, int EPI, bool TA, bool TB>
+__device__ __forceinline__ void gemm256_body(const GemmParams &p, const int tile_m, const int tile_n, const int bz) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HALF = 16384;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const int b0 = bz / p.batch1, b1 = bz % p.batch1;
+  const bf16_t *A = reinterpret_cast<const bf16_t *>(p.A) + b0 * p.sA0 + b1 * p.sA1;
+  const bf16_t *B = reinterpret_cast<const bf16_t *>(p.B) + b0 * p.sB0 + b1 * p.sB1;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(A), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(B), 0, 0x7FFFFFFF, 0x00020000);
+  const int lda = (int)p.lda, ldb = (int)p.ldb;
+  const int nk = p.K / 64;
+
+  // per-lane source byte offsets of this wave's two 1-KiB pieces of each half-tile (the K-tile advance goes in soffset).
+  // An LDS-DMA piece is written lane-linearly, so the image's XOR swizzle is applied to the source address.
+  int voff[4][2];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = wave * 2 + i;
+      const bool isA = (h == 0) || (h == 3);
+      const bool tr = isA ? TA : TB;
+      const int sub = (h >= 2) ? 1 : 0;                 // mh for the A halves, nh for the B halves
+      const int ld = isA ? lda : ldb, lim = isA ? p.M : p.N, o0 = isA ? m0 : n0;
+      int off;
+      if (!tr) {                                        // k contiguous: 8 rows x 8 chunks per piece
+        const int row = piece * 8 + (lane >> 3), pos = lane & 7;
+        const int gr = isA ? o0 + (row >> 6) * 128 + sub * 64 + (row & 63) : o0 + (row >> 5) * 64 + sub * 32 + (row & 31);
+        off = gr < lim ? (gr * ld + ((pos ^ (row & 7)) << 3)) * 2 : (int)0x80000000;
+      } else {                                          // k strided: 4 k-rows x 16 chunks per piece
+        const int k = piece * 4 + (lane >> 4), pos = lane & 15;
+        const int rl = (pos ^ (((k & 3) << 2) | ((k >> 2) & 3))) << 3;
+        const int gr = isA ? o0 + (rl >> 6) * 128 + sub * 64 + (rl & 63) : o0 + (rl >> 5) * 64 + sub * 32 + (rl & 31);
+        off = gr < lim ? (k * ld + gr) * 2 : (int)0x80000000;
+      }
+      voff[h][i] = off;
+    }
+  }
+  const int kstepA = TA ? 64 * lda * 2 : 128, kstepB = TB ? 64 * ldb * 2 : 128;   // bytes per K tile
+
+  auto issue = [&](auto Hc, int t) {
+    constexpr int h = decltype(Hc)::value;
+    char *slot = smem + (((t & 1) << 2) + h) * HALF + wave * 2048;
+    if constexpr (h == 0 || h == 3) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void *)(slot), 16, voff[h][0], t * kstepA, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void *)(slot + 1024), 16, voff[h][1], t * kstepA, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void *)(slot), 16, voff[h][0], t * kstepB, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void *)(slot + 1024), 16, voff[h][1], t * kstepB, 0, 0);
+    }
+  };
+  auto wait_halves = [](int rem) {                      // leave the `rem` (0..3) newest half-tiles in flight
+    if (rem >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (rem == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 af[4][2], bq0[2][2], bq1[2][2];
+
+  const int last = 4 * nk - 1;              // index of the last half-tile
+  constexpr int AHEAD = 5;                  // half-tile s is issued in global phase s - AHEAD
+  issue(std::integral_constant<int, 0>{}, 0);
+  issue(std::integral_constant<int, 1>{}, 0);
+  issue(std::integral_constant<int, 2>{}, 0);
+  issue(std::integral_constant<int, 3>{}, 0);
+  if (nk > 1) issue(std::integral_constant<int, 0>{}, 1);
+  wait_halves((last < AHEAD - 1 ? last : AHEAD - 1) - 1);      // half-tiles 0 and 1 have landed
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger the second wave row by one barrier
+
+  auto phase = [&](auto Pc, int t) {
+    constexpr int P = decltype(Pc)::value;
+    const char *base = smem + ((t & 1) << 2) * HALF;
+    if constexpr (P == 0) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) bq0[jj][ks] = frag_bf16<TB, 128, 64>(base + 1 * HALF, wc * 32 + jj * 16, ks, lane);
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) af[ii][ks] = frag_bf16<TA, 128, 64>(base, wr * 64 + ii * 16, ks, lane);
+    } else if constexpr (P == 1) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) bq1[jj][ks] = frag_bf16<TB, 128, 64>(base + 2 * HALF, wc * 32 + jj * 16, ks, lane);
+    } else if constexpr (P == 2) {
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) af[ii][ks] = frag_bf16<TA, 128, 64>(base + 3 * HALF, wr * 64 + ii * 16, ks, lane);
+    }
+    const int g = 4 * t + P;
+    if (g + AHEAD <= last) issue(std::integral_constant<int, (P + AHEAD) & 3>{}, (g + AHEAD) >> 2);
+    {
+      const int newest = g + AHEAD <= last ? g + AHEAD : last;
+      const int rem = newest - (g + 2);
+      wait_halves(rem < 0 ? 0 : rem);
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    constexpr int mh = (P >= 2) ? 1 : 0, nh = (P == 1 || P == 2) ? 1 : 0;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          acc[mh * 4 + ii][nh * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nh ? bq1[jj][ks] : bq0[jj][ks], af[ii][ks],
+                                                                                  acc[mh * 4 + ii][nh * 2 + jj], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+
+  for (int t = 0; t < nk; ++t) {
+    phase(std::integral_constant<int, 0>{}, t);
+    phase(std::integral_constant<int, 1>{}, t);
+    phase(std::integral_constant<int, 2>{}, t);
+    phase(std::integral_constant<int, 3>{}, t);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();   // balances the stagger barrier of the other wave row
+
+  const int64_t coff = b0 * p.sC0 + b1 * p.sC1;
+  epilogue<TC, EPI, 8, 4>(acc, p, coff, m0 + wr * 128 + (lane & 15), n0 + wc * 64 + (lane >> 4) * 4, true);
+}
+
+template <typename TC, int EPI, bool TA, bool TB>
+__global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
+  int tile_m, tile_n;
+  map_tile(gridDim.x, blockIdx.x, p.tiles_m, tile_m, tile_n);
+  gemm256_body<TC, EPI, TA, TB>(p, tile_m, tile_n, blockIdx.z);
+}
+
+// grouped weight gradients on the 256x256 ring: same problem / item tables as gemm_grouped_tn_kernel, 256x256 items
+__global__ __launch_bounds__(512) void gemm256_grouped_tn_kernel(const GroupedProblem *__restrict__ probs, const GroupedItem *__restrict__ items) {
+  const GroupedItem it = items[blockIdx.x];
+  const GroupedProblem g = probs[it.prob];
+  GemmParams p;
+  p.M = g.M; p.N = g.N; p.K = g.K;
+  p.A = g.A; p.lda = g.lda; p.sA0 = 0; p.sA1 = 0;
+  p.B = g.B; p.ldb = g.ldb; p.sB0 = 0; p.sB1 = 0;
+  p.C = g.C; p.c_dtype = EVP_F32; p.ldc = g.ldc; p.sC0 = 0; p.sC1 = 0;
+  p.batch1 = 1; p.alpha = 1.0f; p.bias = nullptr; p.act = EVP_ACT_NONE; p.aux = nullptr; p.ldaux = 0;
+  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1;
+  p.k_per_split = g.K;
+  gemm256_body<float, 0, true, true>(p, it.tile_m, it.tile_n, 0);
+}
+
+template <typename TC, int EPI, bool TA, bool TB> int launch256(const evp_gemm_desc *d, hipStream_t s) {
+  GemmParams p;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.A = d->A; p.lda = d->lda; p.sA0 = d->strideA0; p.sA1 = d->strideA1;
+  p.B = d->B; p.ldb = d->ldb; p.sB0 = d->strideB0; p.sB1 = d->strideB1;
+  p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = d->strideC0; p.sC1 = d->strideC1;
+  p.batch1 = d->batch1 > 0 ? d->batch1 : 1;
+  p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
+  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate;
+  p.tiles_m = (d->M + 255) / 256;
+  p.splitk = 1; p.k_per_split = d->K;
+  const int tiles_n = (d->N + 255) / 256;
+  const int nb = (d->batch0 > 0 ? d->batch0 : 1) * p.batch1;
+  constexpr int smem = 8 * 16384;
+  auto k = gemm256_kernel<TC, EPI, TA, TB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { evp_set_error("evp_gemm: hipFuncSetAttribute(%d) failed: %s", smem, hipGetErrorString(e)); return EVP_ELAUNCH; }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)(p.tiles_m * tiles_n), 1, (unsigned)nb), dim3(512), smem, s, p);
+  EVP_CHECK_LAUNCH("evp_gemm");
+  return EVP_OK;
+}
+
 template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(const evp_gemm_desc *d, hipStream_t s) {
   int tile = d->tile;
   const int64_t nb = (int64_t)(d->batch0 > 0 ? d->batch0 : 1) * (d->batch1 > 0 ? d->batch1 : 1);
@@ -620,6 +828,12 @@ template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(cons
     tile = (d->M >= 128 && d->N >= 128 && (t128 >= 192 || splittable)) ? 1 : 2;
   }
   // bf16: LDS-DMA staging (variant 1, default) or register staging (variant 2, kept for A/B runs); f32: registers
+  if constexpr (sizeof(T) == 2) {
+    if (tile == 6) {
+      if (d->K % 64 != 0) { evp_set_error("evp_gemm: tile 6 (256x256 ring) needs K %% 64 == 0 (K=%d)", d->K); return EVP_ESHAPE; }
+      return launch256<TC, EPI, TA, TB>(d, s);
+    }
+  }
   if constexpr (sizeof(T) == 2) {
     if (g_gemm_variant != 2) {
       if (tile == 3) return launch<T, TC, EPI, TA, TB, 256, 128, 4, 2, true, 3>(d, s);   // 8 waves, 144 KiB ring
@@ -672,6 +886,22 @@ extern "C" int evp_gemm_grouped_tn_bf16(const void *problems, const void *items,
   hipLaunchKernelGGL(k, dim3((unsigned)n_items), dim3(256), smem, (hipStream_t)stream,
                      reinterpret_cast<const GroupedProblem *>(problems), reinterpret_cast<const GroupedItem *>(items));
   EVP_CHECK_LAUNCH("evp_gemm_grouped_tn_bf16");
+  return EVP_OK;
+}
+
+extern "C" int evp_gemm_grouped_tn256_bf16(const void *problems, const void *items, int n_items, void *stream) {
+  EVP_CHECK_ARG(problems && items && n_items > 0, EVP_EINVAL, "evp_gemm_grouped_tn256_bf16: bad argument");
+  auto k = gemm256_grouped_tn_kernel;
+  constexpr int smem = 8 * 16384;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_gemm_grouped_tn256_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)n_items), dim3(512), smem, (hipStream_t)stream,
+                     reinterpret_cast<const GroupedProblem *>(problems), reinterpret_cast<const GroupedItem *>(items));
+  EVP_CHECK_LAUNCH("evp_gemm_grouped_tn256_bf16");
   return EVP_OK;
 }
 

@@ -9,6 +9,8 @@ Every tensor handed to a kernel is allocated by PyTorch; all arithmetic happens 
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -314,26 +316,34 @@ class _DeferredGrads:
                     rounds.append([])
                 rounds[r].append(item)
             fresh_ids = {id(p_) for p_ in fresh}
+            pdt = np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("lda", "<i4"),
+                            ("ldb", "<i4"), ("ldc", "<i4"), ("acc", "<i4"), ("pad", "<i4")])
             for r, batch in enumerate(rounds):
-                probs = np.zeros(len(batch), dtype=np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i4"), ("N", "<i4"),
-                                                              ("K", "<i4"), ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4"),
-                                                              ("acc", "<i4"), ("pad", "<i4")]))
-                items = []
-                for i, (param, dy, x, n_out, k_in, rows) in enumerate(batch):
-                    gt, acc = self._target(param)
-                    if r == 0 and id(param) in fresh_ids:
-                        acc = 0                  # first write into the freshly allocated flat slice
-                    probs[i] = (dy.data_ptr(), x.data_ptr(), gt.data_ptr(), n_out, k_in, rows, n_out, k_in, k_in, acc, 0)
-                    tm, tn = (n_out + 127) // 128, (k_in + 127) // 128
-                    t = np.zeros((tn, tm, 4), dtype=np.int32)
-                    t[..., 0] = i
-                    t[..., 1] = np.arange(tm, dtype=np.int32)[None, :]
-                    t[..., 2] = np.arange(tn, dtype=np.int32)[:, None]
-                    items.append(t.reshape(-1, 4))
-                items = np.concatenate(items, 0)
-                pt = self._stage("wp%d" % r, probs.view(np.uint8), dev)
-                it = self._stage("wi%d" % r, items.view(np.uint8).reshape(-1), dev)
-                call("evp_gemm_grouped_tn_bf16", pt.data_ptr(), it.data_ptr(), int(items.shape[0]), stream_ptr())
+                # long-K problems with >= 256-wide outputs go to the 256x256 ring kernel (one launch), the rest to the
+                # 128x128 kernel (one launch); inside a launch the longest-K tiles are listed first
+                big = [it for it in batch if _use_wgrad256 and it[5] % 64 == 0 and it[3] >= 256 and it[4] >= 256]
+                small = [it for it in batch if not (_use_wgrad256 and it[5] % 64 == 0 and it[3] >= 256 and it[4] >= 256)]
+                for tag, part, T_, entry in (("w256", big, 256, "evp_gemm_grouped_tn256_bf16"), ("w128", small, 128, "evp_gemm_grouped_tn_bf16")):
+                    if not part:
+                        continue
+                    part = sorted(part, key=lambda it: -it[5])
+                    probs = np.zeros(len(part), dtype=pdt)
+                    items = []
+                    for i, (param, dy, x, n_out, k_in, rows) in enumerate(part):
+                        gt, acc = self._target(param)
+                        if r == 0 and id(param) in fresh_ids:
+                            acc = 0                  # first write into the freshly allocated flat slice
+                        probs[i] = (dy.data_ptr(), x.data_ptr(), gt.data_ptr(), n_out, k_in, rows, n_out, k_in, k_in, acc, 0)
+                        tm, tn = (n_out + T_ - 1) // T_, (k_in + T_ - 1) // T_
+                        t = np.zeros((tn, tm, 4), dtype=np.int32)
+                        t[..., 0] = i
+                        t[..., 1] = np.arange(tm, dtype=np.int32)[None, :]
+                        t[..., 2] = np.arange(tn, dtype=np.int32)[:, None]
+                        items.append(t.reshape(-1, 4))
+                    items = np.concatenate(items, 0)
+                    pt = self._stage("%sp%d" % (tag, r), probs.view(np.uint8), dev)
+                    it_ = self._stage("%si%d" % (tag, r), items.view(np.uint8).reshape(-1), dev)
+                    call(entry, pt.data_ptr(), it_.data_ptr(), int(items.shape[0]), stream_ptr())
         if b:
             dev = b[0][1].device
             probs = np.zeros(len(b), dtype=np.dtype([("x", "<u8"), ("out", "<u8"), ("M", "<i8"), ("N", "<i4"), ("ld", "<i4"),
@@ -366,6 +376,13 @@ class _DeferredGrads:
 
 
 _deferred = _DeferredGrads()
+_use_wgrad256 = os.environ.get("EVP_WGRAD256", "1") != "0"
+
+
+def set_wgrad256(flag):
+    """A/B switch: route long-K weight gradients to the 256x256 ring kernel (default) or keep all on 128x128 tiles."""
+    global _use_wgrad256
+    _use_wgrad256 = bool(flag)
 
 
 def set_deferred_grads(flag):

@@ -91,7 +91,7 @@ typedef struct {
   void *aux; int64_t ldaux;            /* element type = c_dtype; batch strides = C's */
   const float *residual; int64_t ldres; /* batch strides = C's */
   int accumulate;
-  int tile;                             /* 0 auto, 1 = 128x128, 2 = 64x64 */
+  int tile;                             /* 0 auto, 1 = 128x128, 2 = 64x64, 6 = 256x256 ring (bf16, K % 64 == 0) */
   int splitk;                           /* 0 auto, n = cut K into n slices summed with f32 atomics (plain f32 C only) */
 } evp_gemm_desc;
 int evp_gemm(const evp_gemm_desc *d, void *stream);
@@ -102,6 +102,9 @@ int evp_gemm(const evp_gemm_desc *d, void *stream);
  *   accumulate != 0: C_g += ...)
  * and `items` a device array of  struct { int prob, tile_m, tile_n, pad; }  listing every 128x128 output tile. */
 int evp_gemm_grouped_tn_bf16(const void *problems, const void *items, int n_items, void *stream);
+/* Same problem table, but `items` lists 256x256 output tiles and every K_g must be a multiple of 64: the 8-wave
+ * half-tile-ring kernel (one workgroup per CU), the faster form when K_g is long (K_g = batch x tokens here). */
+int evp_gemm_grouped_tn256_bf16(const void *problems, const void *items, int n_items, void *stream);
 /* Tuning switch for A/B measurements: 1 = LDS-DMA (buffer_load ... lds) staging for bf16 (default), 2 = register
  * staging. Returns the previous value; any other argument only queries. Results are identical. */
 int evp_gemm_set_variant(int v);
