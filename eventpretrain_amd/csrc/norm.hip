@@ -552,8 +552,10 @@ extern "C" int evp_layernorm_bwd(const void *dy, int dy_dtype, const float *x, c
     hipLaunchKernelGGL(ln_bwd_kernel<V>, dim3(g), dim3(256), sh, s, dy, dy_dtype, x, x2, x3, gamma, mean, rstd, gres, M, D, dx, dx_lp, workspace);
   });
   EVP_CHECK_LAUNCH("evp_layernorm_bwd");
-  hipLaunchKernelGGL(ln_bwd_finalize, dim3((2 * D + 63) / 64), dim3(1024), 0, s, workspace, g, D, dgamma, dbeta);
-  EVP_CHECK_LAUNCH("evp_layernorm_bwd(finalize)");
+  if (dgamma || dbeta) {   // both NULL: the caller reduces the per-block partials workspace[g][2][D] itself (deferred, grouped)
+    hipLaunchKernelGGL(ln_bwd_finalize, dim3((2 * D + 63) / 64), dim3(1024), 0, s, workspace, g, D, dgamma, dbeta);
+    EVP_CHECK_LAUNCH("evp_layernorm_bwd(finalize)");
+  }
   return EVP_OK;
 }
 

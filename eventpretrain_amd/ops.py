@@ -129,17 +129,25 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype, x2=None, x3=None):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, gres=None, x2=None, x3=None, want_lp=False):
-    """Returns (dx f32, dx_lp bf16|None, dgamma, dbeta)."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, gres=None, x2=None, x3=None, want_lp=False, params=None):
+    """Returns (dx f32, dx_lp bf16|None, dgamma, dbeta). With `params=(weight, bias)` leaf Parameters that may take
+    deferred gradients, the per-block dgamma/dbeta partials are queued for the step's grouped column-sum launch
+    instead of being reduced by a kernel of their own, and (dx, dx_lp, None, None) is returned."""
     M, D = x.shape
     dx = torch.empty(M, D, dtype=torch.float32, device=x.device)
     dx_lp = torch.empty(M, D, dtype=torch.bfloat16, device=x.device) if want_lp else None
-    dgamma = torch.empty(D, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(D, dtype=torch.float32, device=x.device)
     nb = call("evp_layernorm_bwd_nblk", M)
-    ws = torch.empty(2 * nb * D, dtype=torch.float32, device=x.device)
+    ws = torch.empty(nb, 2 * D, dtype=torch.float32, device=x.device)
+    defer = (params is not None and D % 8 == 0 and _deferred.can_defer(params[0]) and _deferred.can_defer(params[1]))
+    dgamma = dbeta = None
+    if not defer:
+        dgamma = torch.empty(D, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(D, dtype=torch.float32, device=x.device)
     call("evp_layernorm_bwd", ptr(_chk(dy)), dt(dy), ptr(x), ptr(x2), ptr(x3), ptr(gamma), ptr(mean), ptr(rstd),
          ptr(gres), M, D, ptr(dx), ptr(dx_lp), ptr(dgamma), ptr(dbeta), ptr(ws), stream_ptr())
+    if defer:
+        _deferred.colsum(params[0], ws[:, :D])
+        _deferred.colsum(params[1], ws[:, D:])
     return dx, dx_lp, dgamma, dbeta
 
 
@@ -362,7 +370,7 @@ class _DeferredGrads:
             for i, (param, x2d) in enumerate(b):
                 M, N = x2d.shape
                 gt, acc = self._target(param)
-                probs[i] = (x2d.data_ptr(), gt.data_ptr(), M, N, N, dt(x2d), 0)
+                probs[i] = (x2d.data_ptr(), gt.data_ptr(), M, N, x2d.stride(0), dt(x2d), 0)
                 cb, rs = (N + 127) // 128, (M + 255) // 256
                 t = np.zeros((rs, cb, 4), dtype=np.int32)
                 t[..., 0] = i
@@ -457,6 +465,7 @@ class ViTBlockFn(torch.autograd.Function):
         ctx.dims = (B, N, D, heads, dh, Hd)
         ctx.fused = fused
         ctx.prm = (qkvw, qkvb, pw, pb, f1w, f1b, f2w, f2b)     # leaf parameters: targets of the deferred gradients
+        ctx.nprm = (n1w, n1b, n2w, n2b)
         out = x2.view(B, N, D)
         if want_attn:
             attn = probs[..., :N]
@@ -486,7 +495,7 @@ class ViTBlockFn(torch.autograd.Function):
         dw1 = _wgrad(dh_pre, ln2, Hd, D, M, f1w_) if need[9] else None
         dln2 = torch.empty(M, D, dtype=T, device=dev)
         gemm(dh_pre, w1, dln2, M=M, N=D, K=Hd, trans_b=True, ldb=D)
-        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf)
+        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf, params=ctx.nprm[2:])
         if not bf:
             g1_lp = g1
         # attention
@@ -502,7 +511,7 @@ class ViTBlockFn(torch.autograd.Function):
         dwq = _wgrad(dqkv, ln1, 3 * D, D, M, qkvw_) if need[3] else None
         dln1 = torch.empty(M, D, dtype=T, device=dev)
         gemm(dqkv, wq, dln1, M=M, N=D, K=3 * D, trans_b=True, ldb=D)
-        g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1)
+        g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1, params=ctx.nprm[:2])
         return (g0.view(B, N, D), dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None)
 
 
@@ -566,6 +575,7 @@ class LayerNormFn(torch.autograd.Function):
         xs = [None if t is None else _chk(t.detach().contiguous(), torch.float32).view(-1, D) for t in (x, x2, x3)]
         y, mean, rstd = layernorm_fwd(xs[0], gamma, beta, eps, torch.float32, xs[1], xs[2])
         ctx.save_for_backward(gamma, mean, rstd, *[t for t in xs if t is not None])
+        ctx.prm = (gamma, beta)
         ctx.n_in = sum(t is not None for t in xs)
         ctx.has = (x2 is not None, x3 is not None)
         return y.view(shp)
@@ -579,7 +589,7 @@ class LayerNormFn(torch.autograd.Function):
         x2 = rest.pop(0) if ctx.has[0] else None
         x3 = rest.pop(0) if ctx.has[1] else None
         g2d = _chk(g.contiguous(), torch.float32).view(-1, D)
-        dx, _, dgamma, dbeta = layernorm_bwd(g2d, x, gamma, mean, rstd, x2=x2, x3=x3)
+        dx, _, dgamma, dbeta = layernorm_bwd(g2d, x, gamma, mean, rstd, x2=x2, x3=x3, params=ctx.prm)
         dx = dx.view(g.shape)
         return dx, (dx if ctx.has[0] else None), (dx if ctx.has[1] else None), dgamma, dbeta, None
 
@@ -1238,6 +1248,7 @@ class SwinBlockFn(torch.autograd.Function):
                               tab, rel)
         ctx.dims = (Bg, nG, N, D, heads, dh, Hd, R, scale)
         ctx.prm = (qkvw, qkvb, pw, pb, f1w, f1b, f2w, f2b)
+        ctx.nprm = (n1w, n1b, n2w, n2b)
         out = x2.view(Bg, N, D)
         if want_attn:
             ctx.mark_non_differentiable(probs)
@@ -1265,7 +1276,7 @@ class SwinBlockFn(torch.autograd.Function):
         dw1 = _wgrad(dh_pre, ln2, Hd, D, M, f1w_) if need[11] else None
         dln2 = torch.empty(M, D, dtype=T, device=dev)
         gemm(dh_pre, w1, dln2, M=M, N=D, K=Hd, trans_b=True, ldb=D)
-        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf)
+        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf, params=ctx.nprm[2:])
         if not bf:
             g1_lp = g1
         dbp = _bgrad(g1, pb_) if need[8] else None
@@ -1280,7 +1291,7 @@ class SwinBlockFn(torch.autograd.Function):
         dwq = _wgrad(dqkv, ln1, 3 * D, D, M, qkvw_) if need[5] else None
         dln1 = torch.empty(M, D, dtype=T, device=dev)
         gemm(dqkv, wq, dln1, M=M, N=D, K=3 * D, trans_b=True, ldb=D)
-        g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1)
+        g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1, params=ctx.nprm[:2])
         return (g0.view(Bg, N, D), dtable, None, dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None)
 
 

@@ -116,7 +116,9 @@ int evp_layernorm_fwd(const float *x, const float *x2, const float *x3, const fl
                       int64_t M, int D, float eps, void *y, int y_dtype, float *mean, float *rstd, void *stream);
 /* dx = (gres ? gres : 0) + LN'(dy): dy dy_dtype [M,D]; x.. as forward; dx float32 [M,D]; dx_lp (optional, bf16) a
  * low-precision copy of dx for the next GEMM; dgamma/dbeta float32 [D] are OVERWRITTEN (partials: workspace float32
- * [2*nblk*D], nblk = evp_layernorm_bwd_nblk(M)). */
+ * [2*nblk*D], nblk = evp_layernorm_bwd_nblk(M)). With dgamma == dbeta == NULL the final reduction is skipped and the
+ * per-block partials stay in workspace as [nblk][2][D] (dgamma rows first) for the caller to column-sum, e.g. with
+ * the step's one evp_colsum_grouped launch. */
 int evp_layernorm_bwd_nblk(int64_t M);
 int evp_layernorm_bwd(const void *dy, int dy_dtype, const float *x, const float *x2, const float *x3,
                       const float *gamma, const float *mean, const float *rstd, const float *gres, int64_t M, int D,
