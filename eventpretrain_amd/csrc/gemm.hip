@@ -20,6 +20,8 @@ typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 static int g_gemm_variant = 1;
+static int g_gemm_dbg = 0;
+static unsigned long long *g_gemm_dbgbuf = nullptr;
 
 namespace {
 
@@ -37,6 +39,8 @@ struct GemmParams {
   int accumulate;
   int tiles_m;
   int splitk, k_per_split;   // blockIdx.y = K slice
+  int dbg;                   // measurement aid (evp_gemm_set_variant(101): skip the epilogue; results are then garbage)
+  unsigned long long *dbgbuf; // measurement aid: per-workgroup cycle counters of the persistent kernel
 };
 
 template <typename T> struct Cfg;
@@ -219,7 +223,7 @@ __device__ __forceinline__ float gelu_sel(float x, bool fast) {
   erf_pdf_fast(x, e, pdf);
   return 0.5f * x * (1.0f + e);
 }
-__device__ __forceinline__ float dgelu_sel(float x, bool fast) {
+__device__ __forceinline__ float dgelu_sel(float x, bool fast) {     // ragged-edge (scalar) path only
   if (!fast) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
     return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
@@ -227,6 +231,62 @@ __device__ __forceinline__ float dgelu_sel(float x, bool fast) {
   float e, pdf;
   erf_pdf_fast(x, e, pdf);
   return 0.5f * (1.0f + e) + x * pdf;
+}
+
+// bf16-mode activations on PAIRS of values (v_pk_fma_f32 / v_pk_mul_f32: two f32 per lane and instruction) and without
+// transcendentals: Phi(x) = 0.5 + xc*P(xc^2) and phi(x) = Q(xc^2) with xc = clamp(x, -4, 4), P / Q degree-7 / -8
+// minimax fits (|Phi err| <= 5.3e-5, |x*phi err| <= 5.2e-5 in f32 Horner form; beyond +-4 the clamp leaves <= 5e-4).
+// The GELU epilogue of a 128x128 tile was ~25 VALU-equivalents per element -- as long as the tile's whole MFMA work at
+// K = 768; this is ~6. f32 parity mode keeps erff / expf.
+typedef float __attribute__((ext_vector_type(2))) f32x2;
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float c) { return f32x2{c, c}; }
+__device__ __forceinline__ f32x2 cdf_poly2(f32x2 xc, f32x2 t) {
+  f32x2 p = splat2(-1.580980095e-09f);
+  p = fma2(p, t, splat2(1.217218683e-07f));
+  p = fma2(p, t, splat2(-4.101103530e-06f));
+  p = fma2(p, t, splat2(8.067003135e-05f));
+  p = fma2(p, t, splat2(-1.048219917e-03f));
+  p = fma2(p, t, splat2(9.664920407e-03f));
+  p = fma2(p, t, splat2(-6.617543876e-02f));
+  p = fma2(p, t, splat2(3.988475314e-01f));
+  return fma2(p, xc, splat2(0.5f));
+}
+__device__ __forceinline__ f32x2 pdf_poly2(f32x2 t) {
+  f32x2 q = splat2(8.990855908e-10f);
+  q = fma2(q, t, splat2(-7.519181097e-08f));
+  q = fma2(q, t, splat2(2.756920725e-06f));
+  q = fma2(q, t, splat2(-5.866515477e-05f));
+  q = fma2(q, t, splat2(8.084384011e-04f));
+  q = fma2(q, t, splat2(-7.582483969e-03f));
+  q = fma2(q, t, splat2(4.857881561e-02f));
+  q = fma2(q, t, splat2(-1.984161263e-01f));
+  return fma2(q, t, splat2(3.986868918e-01f));
+}
+__device__ __forceinline__ f32x2 clamp4(f32x2 x) {
+  return f32x2{__builtin_amdgcn_fmed3f(x.x, -4.f, 4.f), __builtin_amdgcn_fmed3f(x.y, -4.f, 4.f)};
+}
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+  const f32x2 xc = clamp4(x);
+  return x * cdf_poly2(xc, xc * xc);
+}
+__device__ __forceinline__ f32x2 dgelu_fast2(f32x2 h) {       // Phi(h) + h*phi(h)
+  const f32x2 xc = clamp4(h), t = xc * xc;
+  return fma2(xc, pdf_poly2(t), cdf_poly2(xc, t));
+}
+__device__ __forceinline__ float4 gelu4(float4 v, bool fast) {
+  if (fast) {
+    const f32x2 a = gelu_fast2(f32x2{v.x, v.y}), b = gelu_fast2(f32x2{v.z, v.w});
+    return make_float4(a.x, a.y, b.x, b.y);
+  }
+  return make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
+}
+__device__ __forceinline__ float4 dgelu_mul4(float4 v, float4 h, bool fast) {      // v * gelu'(h)
+  if (fast) {
+    const f32x2 a = f32x2{v.x, v.y} * dgelu_fast2(f32x2{h.x, h.y}), b = f32x2{v.z, v.w} * dgelu_fast2(f32x2{h.z, h.w});
+    return make_float4(a.x, a.y, b.x, b.y);
+  }
+  return make_float4(v.x * dgelu_sel(h.x, false), v.y * dgelu_sel(h.y, false), v.z * dgelu_sel(h.z, false), v.w * dgelu_sel(h.w, false));
 }
 
 template <typename TC> __device__ __forceinline__ float4 ld4(const TC *p);
@@ -271,9 +331,116 @@ __device__ __noinline__ void epilogue_edge(TC *C, TC *aux, const float *bias, co
 
 // EPI: 0 = linear (bias / residual / accumulate), 1 = activation forward (GELU / ReLU, optional pre-activation store),
 //      2 = activation backward (multiply by act'(aux))
+// One 4-wide piece C[m][n..n+3] of the epilogue; `a` = raw accumulators.
+template <typename TC, int EPI>
+__device__ __forceinline__ void epi_apply4(float4 a, const GemmParams &p, int64_t coff, int m, int n, float4 bias4, bool fast) {
+  TC *C = reinterpret_cast<TC *>(p.C);
+  if (n + 3 >= p.N) {
+    epilogue_edge<TC>(C, reinterpret_cast<TC *>(p.aux), p.bias, p.residual, p.alpha, p.act, p.accumulate, p.splitk,
+                      coff + (int64_t)m * p.ldc + n, coff + (int64_t)m * p.ldaux + n, coff + (int64_t)m * p.ldres + n, n,
+                      p.N - n, a.x, a.y, a.z, fast);
+    return;
+  }
+  float4 v = make_float4(a.x * p.alpha + bias4.x, a.y * p.alpha + bias4.y, a.z * p.alpha + bias4.z, a.w * p.alpha + bias4.w);
+  const int64_t ao = coff + (int64_t)m * p.ldaux + n;
+  if constexpr (EPI == 1) {
+    if (p.aux) st4<TC>(reinterpret_cast<TC *>(p.aux) + ao, v);
+    if (p.act == EVP_ACT_GELU) v = gelu4(v, fast);
+    else v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+  } else if constexpr (EPI == 2) {
+    const float4 h = ld4<TC>(reinterpret_cast<const TC *>(p.aux) + ao);
+    if (p.act == EVP_ACT_DGELU) v = dgelu_mul4(v, h, fast);
+    else v = make_float4(h.x > 0.f ? v.x : 0.f, h.y > 0.f ? v.y : 0.f, h.z > 0.f ? v.z : 0.f, h.w > 0.f ? v.w : 0.f);
+  }
+  if (p.residual) {
+    const float4 r = *reinterpret_cast<const float4 *>(p.residual + coff + (int64_t)m * p.ldres + n);
+    v = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
+  }
+  const int64_t o = coff + (int64_t)m * p.ldc + n;
+  if (p.splitk > 1) {          // split-K partial sums meet in HBM (f32 C, zeroed by the launcher)
+    float *c = reinterpret_cast<float *>(p.C) + o;
+    atomicAdd(c + 0, v.x); atomicAdd(c + 1, v.y); atomicAdd(c + 2, v.z); atomicAdd(c + 3, v.w);
+    return;
+  }
+  if (p.accumulate) {
+    const float4 c = ld4<TC>(C + o);
+    v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
+  }
+  st4<TC>(C + o, v);
+}
+
+// Interior fast path of the epilogue for one row of NI 4-wide pieces (n = n0 + 16 j): the optional operands are
+// template flags, so the code is branch-free and the compiler issues the NI aux / residual / C loads back to back and
+// waits once (with run-time `if (p.residual)` tests around every piece it emitted load -> s_waitcnt vmcnt(0) -> store,
+// 16 serial HBM round trips per tile: the epilogue then took 8.7k cycles per 128x128 tile against 28k for its K loop).
+template <typename TC, int EPI, int NI, bool RES, bool ACC, bool AUXST>
+__device__ __forceinline__ void epi_row_fast(const float4 (&a)[NI], const GemmParams &p, const float4 (&bias4)[NI], TC *crow, TC *auxrow,
+                                             const float *resrow, bool fast) {
+  float4 h[NI], r[NI], c[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    if constexpr (EPI == 2) h[j] = ld4<TC>(auxrow + j * 16);
+    if constexpr (RES) r[j] = *reinterpret_cast<const float4 *>(resrow + j * 16);
+    if constexpr (ACC) c[j] = ld4<TC>(crow + j * 16);
+  }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    float4 v = make_float4(a[j].x * p.alpha + bias4[j].x, a[j].y * p.alpha + bias4[j].y, a[j].z * p.alpha + bias4[j].z,
+                           a[j].w * p.alpha + bias4[j].w);
+    if constexpr (EPI == 1) {
+      if constexpr (AUXST) st4<TC>(auxrow + j * 16, v);
+      if (p.act == EVP_ACT_GELU) v = gelu4(v, fast);
+      else v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    } else if constexpr (EPI == 2) {
+      if (p.act == EVP_ACT_DGELU) v = dgelu_mul4(v, h[j], fast);
+      else v = make_float4(h[j].x > 0.f ? v.x : 0.f, h[j].y > 0.f ? v.y : 0.f, h[j].z > 0.f ? v.z : 0.f, h[j].w > 0.f ? v.w : 0.f);
+    }
+    if constexpr (RES) v = make_float4(v.x + r[j].x, v.y + r[j].y, v.z + r[j].z, v.w + r[j].w);
+    if constexpr (ACC) v = make_float4(v.x + c[j].x, v.y + c[j].y, v.z + c[j].z, v.w + c[j].w);
+    st4<TC>(crow + j * 16, v);
+  }
+}
+
+template <typename TC, int EPI, int MI, int NI, bool RES, bool ACC, bool AUXST>
+__device__ __forceinline__ void epilogue_fast(const f32x4 (&acc)[MI][NI], const GemmParams &p, int64_t coff, int mbase, int nbase, bool fast) {
+  float4 bias4[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+    bias4[j] = p.bias ? *reinterpret_cast<const float4 *>(p.bias + nbase + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+  TC *C = reinterpret_cast<TC *>(p.C) + coff + (int64_t)mbase * p.ldc + nbase;
+  TC *aux = reinterpret_cast<TC *>(p.aux) + coff + (int64_t)mbase * p.ldaux + nbase;
+  const float *res = p.residual + coff + (int64_t)mbase * p.ldres + nbase;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    float4 a[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) a[j] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    if (p.dbg == 2 && i > 0 && a[0].x != 12345.678f) continue;      // measurement aid: a quarter of the stores
+    epi_row_fast<TC, EPI, NI, RES, ACC, AUXST>(a, p, bias4, C + (int64_t)i * 16 * p.ldc, aux + (int64_t)i * 16 * p.ldaux,
+                                                res + (int64_t)i * 16 * p.ldres, fast);
+  }
+}
+
+// Straight from the MFMA accumulators: lane holds C[m][n..n+3] with m = mbase + 16 i, n = nbase + 16 j. Interior lanes
+// (every piece in range, no split-K) take the branch-free path specialised on which optional operands exist; the rest
+// (ragged edges) the generic piece-by-piece path.
 template <typename TC, int EPI, int MI, int NI>
 __device__ __forceinline__ void epilogue(const f32x4 (&acc)[MI][NI], const GemmParams &p, int64_t coff, int mbase, int nbase, bool fast) {
-  TC *C = reinterpret_cast<TC *>(p.C);
+  if (p.dbg == 1 && acc[0][0][0] != 12345.678f) return;
+  const bool interior = mbase + (MI - 1) * 16 < p.M && nbase + (NI - 1) * 16 + 3 < p.N && p.splitk <= 1;
+  if (interior) {
+    const bool res = p.residual != nullptr, accu = p.accumulate != 0, auxst = p.aux != nullptr;
+    if (res) {
+      if (accu) epilogue_fast<TC, EPI, MI, NI, true, true, true>(acc, p, coff, mbase, nbase, fast);      // rare: keep one generic-ish form
+      else if (auxst || EPI != 1) epilogue_fast<TC, EPI, MI, NI, true, false, true>(acc, p, coff, mbase, nbase, fast);
+      else epilogue_fast<TC, EPI, MI, NI, true, false, false>(acc, p, coff, mbase, nbase, fast);
+    } else {
+      if (accu) epilogue_fast<TC, EPI, MI, NI, false, true, true>(acc, p, coff, mbase, nbase, fast);
+      else if (auxst || EPI != 1) epilogue_fast<TC, EPI, MI, NI, false, false, true>(acc, p, coff, mbase, nbase, fast);
+      else epilogue_fast<TC, EPI, MI, NI, false, false, false>(acc, p, coff, mbase, nbase, fast);
+    }
+    return;
+  }
   float4 bias4[NI];
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -288,41 +455,94 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[MI][NI], const GemmP
     for (int j = 0; j < NI; ++j) {
       const int n = nbase + j * 16;
       if (n >= p.N) continue;
-      const float4 a = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-      if (n + 3 >= p.N) {
-        epilogue_edge<TC>(C, reinterpret_cast<TC *>(p.aux), p.bias, p.residual, p.alpha, p.act, p.accumulate, p.splitk,
-                          coff + (int64_t)m * p.ldc + n, coff + (int64_t)m * p.ldaux + n, coff + (int64_t)m * p.ldres + n, n,
-                          p.N - n, a.x, a.y, a.z, fast);
-        continue;
-      }
-      float4 v = make_float4(a.x * p.alpha + bias4[j].x, a.y * p.alpha + bias4[j].y, a.z * p.alpha + bias4[j].z, a.w * p.alpha + bias4[j].w);
-      const int64_t ao = coff + (int64_t)m * p.ldaux + n;
+      epi_apply4<TC, EPI>(make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]), p, coff, m, n, bias4[j], fast);
+    }
+  }
+}
+
+// Through an f32 tile in LDS (the operand stages, free once the K loop has ended): the accumulators are parked with a
+// 16-byte-chunk XOR swizzle (chunk ^ (row & 15): conflict-free ds_write_b128 and ds_read_b128), then every thread
+// walks rows with a FIXED 4-column group, so each wave instruction of the epilogue -- the C store, and the aux /
+// residual / accumulate loads and the pre-activation store -- covers whole contiguous rows (BN*4 B of f32, BN*2 B of
+// bf16) instead of 16 rows x 32-64 B. The direct form above ran the bf16 stores at ~2.6 TB/s and was a quarter of a
+// K = 768 GEMM's time.
+template <typename TC, int EPI, int BM, int BN, int NT, bool RES, bool ACC, bool AUXST>
+__device__ __forceinline__ void epilogue_lds_rows(const float4 *tile, const GemmParams &p, int64_t coff, int m0, int n, int ch, int r0, float4 bias4,
+                                                  bool fast) {
+  constexpr int CPR = BN / 4, RPP = NT / CPR, STEPS = BM / RPP;
+  static_assert(STEPS % 4 == 0, "rows per thread must come in fours");
+  TC *C = reinterpret_cast<TC *>(p.C) + coff + n;
+  TC *aux = reinterpret_cast<TC *>(p.aux) + coff + n;
+  const float *res = p.residual + coff + n;
+#pragma unroll 1
+  for (int s = 0; s < STEPS; s += 4) {
+    float4 a[4], h[4], r[4], c[4];
+    int m[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = r0 + (s + u) * RPP;
+      m[u] = m0 + row;
+      a[u] = tile[row * CPR + (ch ^ (row & 15))];
+      if constexpr (EPI == 2) h[u] = ld4<TC>(aux + (int64_t)m[u] * p.ldaux);
+      if constexpr (RES) r[u] = *reinterpret_cast<const float4 *>(res + (int64_t)m[u] * p.ldres);
+      if constexpr (ACC) c[u] = ld4<TC>(C + (int64_t)m[u] * p.ldc);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float4 v = make_float4(a[u].x * p.alpha + bias4.x, a[u].y * p.alpha + bias4.y, a[u].z * p.alpha + bias4.z, a[u].w * p.alpha + bias4.w);
       if constexpr (EPI == 1) {
-        if (p.aux) st4<TC>(reinterpret_cast<TC *>(p.aux) + ao, v);
-        if (p.act == EVP_ACT_GELU) v = make_float4(gelu_sel(v.x, fast), gelu_sel(v.y, fast), gelu_sel(v.z, fast), gelu_sel(v.w, fast));
+        if constexpr (AUXST) st4<TC>(aux + (int64_t)m[u] * p.ldaux, v);
+        if (p.act == EVP_ACT_GELU) v = gelu4(v, fast);
         else v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
       } else if constexpr (EPI == 2) {
-        const float4 h = ld4<TC>(reinterpret_cast<const TC *>(p.aux) + ao);
-        if (p.act == EVP_ACT_DGELU)
-          v = make_float4(v.x * dgelu_sel(h.x, fast), v.y * dgelu_sel(h.y, fast), v.z * dgelu_sel(h.z, fast), v.w * dgelu_sel(h.w, fast));
-        else v = make_float4(h.x > 0.f ? v.x : 0.f, h.y > 0.f ? v.y : 0.f, h.z > 0.f ? v.z : 0.f, h.w > 0.f ? v.w : 0.f);
+        if (p.act == EVP_ACT_DGELU) v = dgelu_mul4(v, h[u], fast);
+        else v = make_float4(h[u].x > 0.f ? v.x : 0.f, h[u].y > 0.f ? v.y : 0.f, h[u].z > 0.f ? v.z : 0.f, h[u].w > 0.f ? v.w : 0.f);
       }
-      if (p.residual) {
-        const float4 r = *reinterpret_cast<const float4 *>(p.residual + coff + (int64_t)m * p.ldres + n);
-        v = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
-      }
-      const int64_t o = coff + (int64_t)m * p.ldc + n;
-      if (p.splitk > 1) {          // split-K partial sums meet in HBM (f32 C, zeroed by the launcher)
-        float *c = reinterpret_cast<float *>(p.C) + o;
-        atomicAdd(c + 0, v.x); atomicAdd(c + 1, v.y); atomicAdd(c + 2, v.z); atomicAdd(c + 3, v.w);
-        continue;
-      }
-      if (p.accumulate) {
-        const float4 c = ld4<TC>(C + o);
-        v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + c.w);
-      }
-      st4<TC>(C + o, v);
+      if constexpr (RES) v = make_float4(v.x + r[u].x, v.y + r[u].y, v.z + r[u].z, v.w + r[u].w);
+      if constexpr (ACC) v = make_float4(v.x + c[u].x, v.y + c[u].y, v.z + c[u].z, v.w + c[u].w);
+      st4<TC>(C + (int64_t)m[u] * p.ldc, v);
     }
+  }
+}
+
+template <typename TC, int EPI, int BM, int BN, int NT, int MI, int NI>
+__device__ __forceinline__ void epilogue_lds(const f32x4 (&acc)[MI][NI], const GemmParams &p, int64_t coff, char *smem, int m0, int n0,
+                                             int wrow, int wcol, bool fast) {
+  if (p.dbg == 1 && acc[0][0][0] != 12345.678f) return;
+  constexpr int CPR = BN / 4;                      // 16-byte chunks per tile row
+  static_assert(CPR >= 16 && NT % CPR == 0, "tile too narrow for the chunk swizzle");
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  float4 *tile = reinterpret_cast<float4 *>(smem);
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int row = wrow + i * 16 + li, ch = (wcol >> 2) + j * 4 + lg;
+      tile[row * CPR + (ch ^ (row & 15))] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  __syncthreads();
+  const int ch = tid % CPR, r0 = tid / CPR;
+  const int n = n0 + ch * 4;
+  if (n >= p.N) return;
+  const float4 bias4 = (p.bias && n + 3 < p.N) ? *reinterpret_cast<const float4 *>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int RPP = NT / CPR;                    // rows per pass
+  if (m0 + BM <= p.M && n + 3 < p.N && p.splitk <= 1) {      // interior: branch-free, loads batched four rows at a time
+    const bool res = p.residual != nullptr, accu = p.accumulate != 0, auxst = p.aux != nullptr;
+    if (res) {
+      if (accu) epilogue_lds_rows<TC, EPI, BM, BN, NT, true, true, true>(tile, p, coff, m0, n, ch, r0, bias4, fast);
+      else if (auxst || EPI != 1) epilogue_lds_rows<TC, EPI, BM, BN, NT, true, false, true>(tile, p, coff, m0, n, ch, r0, bias4, fast);
+      else epilogue_lds_rows<TC, EPI, BM, BN, NT, true, false, false>(tile, p, coff, m0, n, ch, r0, bias4, fast);
+    } else {
+      if (accu) epilogue_lds_rows<TC, EPI, BM, BN, NT, false, true, true>(tile, p, coff, m0, n, ch, r0, bias4, fast);
+      else if (auxst || EPI != 1) epilogue_lds_rows<TC, EPI, BM, BN, NT, false, false, true>(tile, p, coff, m0, n, ch, r0, bias4, fast);
+      else epilogue_lds_rows<TC, EPI, BM, BN, NT, false, false, false>(tile, p, coff, m0, n, ch, r0, bias4, fast);
+    }
+    return;
+  }
+  for (int r = r0; r < BM; r += RPP) {
+    const int m = m0 + r;
+    if (m >= p.M) break;
+    epi_apply4<TC, EPI>(tile[r * CPR + (ch ^ (r & 15))], p, coff, m, n, bias4, fast);
   }
 }
 
@@ -494,7 +714,11 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m,
     }
   }
   const bool fast = sizeof(T) == 2;   // bf16 mode may use the fast erf; f32 parity mode uses erff
-  epilogue<TC, EPI, MI, NI>(acc, p, coff, m0 + wm * WTM + li, n0 + wn * WTN + lg * 4, fast);
+  if constexpr (sizeof(T) == 2 && STAGES * (A_BYTES + B_BYTES) >= BM * BN * 4 && BN >= 64) {
+    epilogue_lds<TC, EPI, BM, BN, NT, MI, NI>(acc, p, coff, smem, m0, n0, wm * WTM, wn * WTN, fast);   // every K loop ends on a barrier
+  } else {
+    epilogue<TC, EPI, MI, NI>(acc, p, coff, m0 + wm * WTM + li, n0 + wn * WTN + lg * 4, fast);
+  }
 }
 
 // Block -> tile map (speed only, never correctness): (1) blocks b and b+8 share an XCD, so renumber to give every XCD
@@ -542,7 +766,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_tn_kernel(const GroupedProbl
   p.B = g.B; p.ldb = g.ldb; p.sB0 = 0; p.sB1 = 0;
   p.C = g.C; p.c_dtype = EVP_F32; p.ldc = g.ldc; p.sC0 = 0; p.sC1 = 0;
   p.batch1 = 1; p.alpha = 1.0f; p.bias = nullptr; p.act = EVP_ACT_NONE; p.aux = nullptr; p.ldaux = 0;
-  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1;
+  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1; p.dbg = 0; p.dbgbuf = nullptr;
   p.k_per_split = (g.K + 63) / 64 * 64;
   gemm_body<bf16_t, float, 0, true, true, BM, BN, 2, 2, true, 2, 64>(p, it.tile_m, it.tile_n, 0, 0);
 }
@@ -557,7 +781,7 @@ int launch(const evp_gemm_desc *d, hipStream_t s) {
   p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = d->strideC0; p.sC1 = d->strideC1;
   p.batch1 = d->batch1 > 0 ? d->batch1 : 1;
   p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
-  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate;
+  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = g_gemm_dbg; p.dbgbuf = g_gemm_dbgbuf;
   p.tiles_m = (d->M + BM - 1) / BM;
   const int tiles_n = (d->N + BN - 1) / BN;
   const int nb = (d->batch0 > 0 ? d->batch0 : 1) * p.batch1;
@@ -783,7 +1007,7 @@ __global__ __launch_bounds__(512) void gemm256_grouped_tn_kernel(const GroupedPr
   p.B = g.B; p.ldb = g.ldb; p.sB0 = 0; p.sB1 = 0;
   p.C = g.C; p.c_dtype = EVP_F32; p.ldc = g.ldc; p.sC0 = 0; p.sC1 = 0;
   p.batch1 = 1; p.alpha = 1.0f; p.bias = nullptr; p.act = EVP_ACT_NONE; p.aux = nullptr; p.ldaux = 0;
-  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1;
+  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1; p.dbg = 0; p.dbgbuf = nullptr;
   p.k_per_split = g.K;
   gemm256_body<float, 0, true, true>(p, it.tile_m, it.tile_n, 0);
 }
@@ -796,7 +1020,7 @@ template <typename TC, int EPI, bool TA, bool TB> int launch256(const evp_gemm_d
   p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = d->strideC0; p.sC1 = d->strideC1;
   p.batch1 = d->batch1 > 0 ? d->batch1 : 1;
   p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
-  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate;
+  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = g_gemm_dbg; p.dbgbuf = g_gemm_dbgbuf;
   p.tiles_m = (d->M + 255) / 256;
   p.splitk = 1; p.k_per_split = d->K;
   const int tiles_n = (d->N + 255) / 256;
@@ -814,6 +1038,372 @@ template <typename TC, int EPI, bool TA, bool TB> int launch256(const evp_gemm_d
   return EVP_OK;
 }
 
+
+// ---- persistent form of the 128x128x64 bf16 LDS-DMA body ------------------------------------------------------------
+// At this path's shapes (K = 512..3072, 300-1600 tiles) a third of a GEMM's time was per-tile fixed cost: workgroup
+// launch, the first operand loads' latency, the epilogue's stores draining before the workgroup retires. Here 2 x 256
+// workgroups stay resident and each walks tiles w, w+G, ...; the K loop is ONE pipeline over (tile, k) pairs with two K
+// tiles of LDS-DMA in flight, so the next tile's first operands stream in under the current tile's last MFMAs and its
+// epilogue, and the epilogue's stores drain under the next tile's MFMAs.
+// vmcnt accounting: at the top of iteration j the outstanding vector-memory ops are, oldest first, [loads of j]
+// [loads of j+1] and possibly [epilogue stores of the previous tile] between or after them. vmcnt(8) proves the loads
+// of j have landed whatever the stores do: loads complete in order, so one missing load of j means all 8 of j+1 are
+// missing too -- 9 outstanding.
+template <typename TC, int EPI, bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmParams p, const int ntiles) {
+  constexpr int BM = 128, BN = 128, BK = 64, NT = 256, MI = 4, NI = 4;
+  constexpr int A_BYTES = Img<bf16_t, TA, BM, BK>::BYTES, B_BYTES = Img<bf16_t, TB, BN, BK>::BYTES, STAGE_BYTES = A_BYTES + B_BYTES;
+  using GA = GStage<TA, BM, NT, BK>;
+  using GB = GStage<TB, BN, NT, BK>;
+  static_assert(GA::PER_WAVE + GB::PER_WAVE == 8, "vmcnt(8) below assumes 8 LDS-DMA pieces per wave and K tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const bf16_t *A = reinterpret_cast<const bf16_t *>(p.A);
+  const bf16_t *B = reinterpret_cast<const bf16_t *>(p.B);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(A), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(B), 0, 0x7FFFFFFF, 0x00020000);
+  const int lda = (int)p.lda, ldb = (int)p.ldb;
+  const int nk = (p.K + BK - 1) / BK;
+  const int G = gridDim.x;
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  const int my_tiles = (ntiles - tile + G - 1) / G;
+  const int J = my_tiles * nk;                 // K iterations of this workgroup
+
+  // (tile, k) of the next LDS-DMA issue
+  int ld_tile = tile, ld_k = 0, ld_m0, ld_n0;
+  {
+    int tm, tn;
+    map_tile(ntiles, ld_tile, p.tiles_m, tm, tn);
+    ld_m0 = tm * BM; ld_n0 = tn * BN;
+  }
+  auto issue_next = [&](int stage) {
+    char *img = smem + stage * STAGE_BYTES;
+    GA::issue(rsA, lda, ld_m0, ld_k * BK, p.M, p.K, img, wave, lane);
+    GB::issue(rsB, ldb, ld_n0, ld_k * BK, p.N, p.K, img + A_BYTES, wave, lane);
+    if (++ld_k == nk) {
+      ld_k = 0;
+      ld_tile += G;
+      int tm, tn;
+      map_tile(ntiles, ld_tile < ntiles ? ld_tile : tile, p.tiles_m, tm, tn);
+      ld_m0 = tm * BM; ld_n0 = tn * BN;
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue_next(0);
+  if (J > 1) issue_next(1);
+  int cm0, cn0;                                 // tile being computed
+  {
+    int tm, tn;
+    map_tile(ntiles, tile, p.tiles_m, tm, tn);
+    cm0 = tm * BM; cn0 = tn * BN;
+  }
+  int k_in_tile = 0;
+  int landed = 0;                               // K iterations ahead whose operands are already known to be in LDS
+  const int li = lane & 15, lg = lane >> 4;
+  unsigned long long t_begin = 0, t_epi = 0, t_mark = 0;
+  if (p.dbgbuf) t_begin = __builtin_readcyclecounter();
+  for (int j = 0; j < J; ++j) {
+    if (landed > 0) --landed;
+    else if (j + 1 < J) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const char *ia = smem + (j & 1) * STAGE_BYTES, *ib = ia + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = frag_bf16<TA, BM, BK>(ia, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int jn = 0; jn < NI; ++jn) bf[jn] = frag_bf16<TB, BN, BK>(ib, wn * 64 + jn * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[jn], af[i], acc[i][jn], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (j + 2 < J) issue_next(j & 1);
+    if (++k_in_tile == nk) {
+      // Let both in-flight K tiles land BEFORE the stores are issued: the next two iterations then need no vmcnt wait
+      // at all, and the first counted wait after them (vmcnt(8), two iterations on) finds the stores long retired. A
+      // counted wait right after the stores would have to sit out their whole HBM round trip.
+      if (j + 1 < J) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        landed = 2;
+      }
+      if (p.dbgbuf) t_mark = __builtin_readcyclecounter();
+      epilogue<TC, EPI, MI, NI>(acc, p, 0, cm0 + wm * 64 + li, cn0 + wn * 64 + lg * 4, true);
+      if (p.dbgbuf) t_epi += __builtin_readcyclecounter() - t_mark;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+      k_in_tile = 0;
+      tile += G;
+      if (tile < ntiles) {
+        int tm, tn;
+        map_tile(ntiles, tile, p.tiles_m, tm, tn);
+        cm0 = tm * BM; cn0 = tn * BN;
+      }
+    }
+  }
+  if (p.dbgbuf && tid == 0) {
+    p.dbgbuf[blockIdx.x * 4 + 0] = __builtin_readcyclecounter() - t_begin;
+    p.dbgbuf[blockIdx.x * 4 + 1] = t_epi;
+    p.dbgbuf[blockIdx.x * 4 + 2] = my_tiles;
+    p.dbgbuf[blockIdx.x * 4 + 3] = t_begin;
+  }
+}
+
+template <typename TC, int EPI, bool TA, bool TB> int launch_persist(const evp_gemm_desc *d, hipStream_t s) {
+  GemmParams p;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.A = d->A; p.lda = d->lda; p.sA0 = 0; p.sA1 = 0;
+  p.B = d->B; p.ldb = d->ldb; p.sB0 = 0; p.sB1 = 0;
+  p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = 0; p.sC1 = 0;
+  p.batch1 = 1;
+  p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
+  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = g_gemm_dbg; p.dbgbuf = g_gemm_dbgbuf;
+  p.tiles_m = (d->M + 127) / 128;
+  p.splitk = 1; p.k_per_split = d->K;
+  const int ntiles = p.tiles_m * ((d->N + 127) / 128);
+  constexpr int smem = 2 * (Img<bf16_t, TA, 128, 64>::BYTES + Img<bf16_t, TB, 128, 64>::BYTES);
+  auto k = gemm_persist_kernel<TC, EPI, TA, TB>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { evp_set_error("evp_gemm: hipFuncSetAttribute(%d) failed: %s", smem, hipGetErrorString(e)); return EVP_ELAUNCH; }
+    attr_done = true;
+  }
+  const int grid = ntiles < 512 ? ntiles : 512;       // 2 workgroups per CU; a multiple of 8 keeps tile % 8 == XCD
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), smem, s, p, ntiles);
+  EVP_CHECK_LAUNCH("evp_gemm");
+  return EVP_OK;
+}
+
+
+// ---- persistent 128x128x64 kernel with the epilogue folded into the next tile's K loop -----------------------------------
+// Measured on the plain persistent kernel above (cycle counters, tools/gemm_epi_probe.py): a finished tile's 16 store
+// instructions per lane took ~5.7k cycles against ~29k for the tile's K loop -- and 1.3k when only a quarter of them was
+// issued. All 512 resident workgroups finish a tile at about the same moment, so every round ends in a 16-32 MB write
+// burst and the waves sit in store back-pressure. Here a finished tile's accumulators are parked in a second register
+// set and written out one 16-row group per K iteration during the first four iterations of the NEXT tile; the
+// residual / aux operands of a group are fetched one iteration ahead. Stores and operand loads are issued right after the
+// top-of-iteration barrier, i.e. a whole MFMA phase before the next counted wait has to see them retired:
+//   top:  s_waitcnt vmcnt(8) ; s_barrier             outstanding then = the 8 LDS-DMA pieces of iteration j+1 at most
+//   [A]   math + stores of row group q (operands fetched in the previous iteration)
+//   [B]   operand loads of row group q+1
+//         MFMAs of iteration j ; s_barrier
+//   [C]   LDS-DMA of iteration j+2
+// vmcnt(8) at the next top is safe whatever order stores and loads retire in: the loads of j+1 are older than the 8
+// pieces of j+2 and loads complete in order, so a missing piece of j+1 leaves at least 9 outstanding.
+// Needs M % 128 == N % 128 == K % 64 == 0, K >= 256, no accumulate (the launcher falls back otherwise).
+template <typename TC, int EPI, bool TA, bool TB, bool RES>
+__global__ __launch_bounds__(256, 2) void gemm_persist2_kernel(const GemmParams p, const int ntiles) {
+  constexpr int BM = 128, BN = 128, BK = 64, NT = 256, MI = 4, NI = 4;
+  constexpr int A_BYTES = Img<bf16_t, TA, BM, BK>::BYTES, B_BYTES = Img<bf16_t, TB, BN, BK>::BYTES, STAGE_BYTES = A_BYTES + B_BYTES;
+  using GA = GStage<TA, BM, NT, BK>;
+  using GB = GStage<TB, BN, NT, BK>;
+  static_assert(GA::PER_WAVE + GB::PER_WAVE == 8, "vmcnt(8) below assumes 8 LDS-DMA pieces per wave and K tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 15, lg = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.A), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.B), 0, 0x7FFFFFFF, 0x00020000);
+  const int lda = (int)p.lda, ldb = (int)p.ldb;
+  const int nk = p.K / BK;
+  const int G = gridDim.x;
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  const int my_tiles = (ntiles - tile + G - 1) / G;
+  const int J = my_tiles * nk;
+
+  int ld_tile = tile, ld_k = 0, ld_m0, ld_n0;
+  {
+    int tm, tn;
+    map_tile(ntiles, ld_tile, p.tiles_m, tm, tn);
+    ld_m0 = tm * BM; ld_n0 = tn * BN;
+  }
+  auto issue_next = [&](int stage) {
+    char *img = smem + stage * STAGE_BYTES;
+    GA::issue(rsA, lda, ld_m0, ld_k * BK, p.M, p.K, img, wave, lane);
+    GB::issue(rsB, ldb, ld_n0, ld_k * BK, p.N, p.K, img + A_BYTES, wave, lane);
+    if (++ld_k == nk) {
+      ld_k = 0;
+      ld_tile += G;
+      int tm, tn;
+      map_tile(ntiles, ld_tile < ntiles ? ld_tile : tile, p.tiles_m, tm, tn);
+      ld_m0 = tm * BM; ld_n0 = tn * BN;
+    }
+  };
+
+  f32x4 acc[MI][NI], prev[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int jn = 0; jn < NI; ++jn) acc[i][jn] = prev[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the parked tile: per-lane row-0 pointers, its bias, and the operands of the row group that is written next
+  TC *pC = nullptr, *pAux = nullptr;
+  const float *pRes = nullptr;
+  float4 pbias[NI], oh[NI], orr[NI];
+#pragma unroll
+  for (int jn = 0; jn < NI; ++jn) pbias[jn] = oh[jn] = orr[jn] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  auto fetch_group = [&](auto Qc) {            // [B]: operand loads of row group Q of the parked tile
+    constexpr int Q = decltype(Qc)::value;
+#pragma unroll
+    for (int jn = 0; jn < NI; ++jn) {
+      if constexpr (EPI == 2) oh[jn] = ld4<TC>(pAux + (int64_t)Q * 16 * p.ldaux + jn * 16);
+      if constexpr (RES) orr[jn] = *reinterpret_cast<const float4 *>(pRes + (int64_t)Q * 16 * p.ldres + jn * 16);
+    }
+  };
+  auto write_group = [&](auto Qc) {            // [A]: epilogue math + stores of row group Q of the parked tile
+    constexpr int Q = decltype(Qc)::value;
+#pragma unroll
+    for (int jn = 0; jn < NI; ++jn) {
+      float4 v = make_float4(prev[Q][jn][0], prev[Q][jn][1], prev[Q][jn][2], prev[Q][jn][3]);     // alpha and bias went in at park()
+      if constexpr (EPI == 1) {
+        st4<TC>(pAux + (int64_t)Q * 16 * p.ldaux + jn * 16, v);
+        if (p.act == EVP_ACT_GELU) v = gelu4(v, true);
+        else v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      } else if constexpr (EPI == 2) {
+        if (p.act == EVP_ACT_DGELU) v = dgelu_mul4(v, oh[jn], true);
+        else v = make_float4(oh[jn].x > 0.f ? v.x : 0.f, oh[jn].y > 0.f ? v.y : 0.f, oh[jn].z > 0.f ? v.z : 0.f, oh[jn].w > 0.f ? v.w : 0.f);
+      }
+      if constexpr (RES) v = make_float4(v.x + orr[jn].x, v.y + orr[jn].y, v.z + orr[jn].z, v.w + orr[jn].w);
+      st4<TC>(pC + (int64_t)Q * 16 * p.ldc + jn * 16, v);
+    }
+  };
+  // last iteration of a tile, [B] slot: pointers / bias / group-0 operands of the tile about to be parked (the previous
+  // parked tile has been written out by then, so the operand registers are free)
+  auto prefetch_park = [&](int m0, int n0) {
+    const int m = m0 + wm * 64 + li, n = n0 + wn * 64 + lg * 4;
+    pC = reinterpret_cast<TC *>(p.C) + (int64_t)m * p.ldc + n;
+    pAux = reinterpret_cast<TC *>(p.aux) + (int64_t)m * p.ldaux + n;
+    pRes = p.residual + (int64_t)m * p.ldres + n;
+#pragma unroll
+    for (int jn = 0; jn < NI; ++jn)
+      pbias[jn] = p.bias ? *reinterpret_cast<const float4 *>(p.bias + n + jn * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    fetch_group(std::integral_constant<int, 0>{});
+  };
+  auto park = [&]() {                          // end of a tile: move alpha * acc + bias aside (the bias is only live across one MFMA phase)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int jn = 0; jn < NI; ++jn) {
+        prev[i][jn] = f32x4{acc[i][jn][0] * p.alpha + pbias[jn].x, acc[i][jn][1] * p.alpha + pbias[jn].y,
+                            acc[i][jn][2] * p.alpha + pbias[jn].z, acc[i][jn][3] * p.alpha + pbias[jn].w};
+        acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  };
+
+  auto compute = [&](int j) {
+    const char *ia = smem + (j & 1) * STAGE_BYTES, *ib = ia + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = frag_bf16<TA, BM, BK>(ia, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int jn = 0; jn < NI; ++jn) bf[jn] = frag_bf16<TB, BN, BK>(ib, wn * 64 + jn * 16, ks, lane);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[jn], af[i], acc[i][jn], 0, 0, 0);
+    }
+  };
+  // one K iteration; Q >= 0: also write row group Q of the parked tile (and fetch the operands of group Q+1);
+  // last: this iteration finishes the current tile (m0, n0)
+  auto iteration = [&](int j, auto Qc, bool parked, bool last, int m0, int n0) {
+    constexpr int Q = decltype(Qc)::value;
+    if (j + 1 < J) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (Q >= 0) {
+      if (parked) {
+        write_group(Qc);
+        if constexpr (Q < 3) fetch_group(std::integral_constant<int, (Q < 3 ? Q + 1 : 3)>{});
+      }
+    }
+    if (last) prefetch_park(m0, n0);
+    compute(j);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (last) park();
+    if (j + 2 < J) issue_next(j & 1);
+  };
+
+  issue_next(0);
+  issue_next(1);                                // nk >= 4, so J >= 4
+  int j = 0;
+  bool parked = false;
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    int tm, tn;
+    map_tile(ntiles, tile, p.tiles_m, tm, tn);
+    const int cm0 = tm * BM, cn0 = tn * BN;
+    iteration(j++, std::integral_constant<int, 0>{}, parked, false, cm0, cn0);
+    iteration(j++, std::integral_constant<int, 1>{}, parked, false, cm0, cn0);
+    iteration(j++, std::integral_constant<int, 2>{}, parked, false, cm0, cn0);
+    iteration(j++, std::integral_constant<int, 3>{}, parked, nk == 4, cm0, cn0);
+    for (int t = 4; t < nk; ++t) iteration(j++, std::integral_constant<int, -1>{}, false, t == nk - 1, cm0, cn0);
+    parked = true;
+    tile += G;
+  }
+  // tail: the last tile of this workgroup
+  write_group(std::integral_constant<int, 0>{});
+  fetch_group(std::integral_constant<int, 1>{});
+  write_group(std::integral_constant<int, 1>{});
+  fetch_group(std::integral_constant<int, 2>{});
+  write_group(std::integral_constant<int, 2>{});
+  fetch_group(std::integral_constant<int, 3>{});
+  write_group(std::integral_constant<int, 3>{});
+}
+
+template <typename TC, int EPI, bool TA, bool TB> int launch_persist2(const evp_gemm_desc *d, hipStream_t s) {
+  GemmParams p;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.A = d->A; p.lda = d->lda; p.sA0 = 0; p.sA1 = 0;
+  p.B = d->B; p.ldb = d->ldb; p.sB0 = 0; p.sB1 = 0;
+  p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = 0; p.sC1 = 0;
+  p.batch1 = 1;
+  p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
+  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = 0; p.dbg = 0; p.dbgbuf = nullptr;
+  p.tiles_m = d->M / 128;
+  p.splitk = 1; p.k_per_split = d->K;
+  const int ntiles = p.tiles_m * (d->N / 128);
+  constexpr int smem = 2 * (Img<bf16_t, TA, 128, 64>::BYTES + Img<bf16_t, TB, 128, 64>::BYTES);
+  const int grid = ntiles < 512 ? ntiles : 512;
+  auto go = [&](auto kfn, bool &attr_done) -> int {
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      if (e != hipSuccess) { evp_set_error("evp_gemm: hipFuncSetAttribute(%d) failed: %s", smem, hipGetErrorString(e)); return EVP_ELAUNCH; }
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256), smem, s, p, ntiles);
+    EVP_CHECK_LAUNCH("evp_gemm");
+    return EVP_OK;
+  };
+  static bool done_r = false, done_n = false;
+  if (d->residual) return go(gemm_persist2_kernel<TC, EPI, TA, TB, true>, done_r);
+  return go(gemm_persist2_kernel<TC, EPI, TA, TB, false>, done_n);
+}
+
+// shapes the deferred-epilogue persistent kernel takes
+static inline bool persist2_ok(const evp_gemm_desc *d) {
+  const int64_t nbz = (int64_t)(d->batch0 > 0 ? d->batch0 : 1) * (d->batch1 > 0 ? d->batch1 : 1);
+  const bool act_fwd = d->act == EVP_ACT_GELU || d->act == EVP_ACT_RELU;
+  return nbz == 1 && d->M % 128 == 0 && d->N % 128 == 0 && d->K % 64 == 0 && d->K >= 256 && !d->accumulate && d->splitk <= 1 &&
+         (!act_fwd || d->aux) && (d->ldc % 4 == 0);
+}
+
 template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(const evp_gemm_desc *d, hipStream_t s) {
   int tile = d->tile;
   const int64_t nb = (int64_t)(d->batch0 > 0 ? d->batch0 : 1) * (d->batch1 > 0 ? d->batch1 : 1);
@@ -829,6 +1419,20 @@ template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(cons
   }
   // bf16: LDS-DMA staging (variant 1, default) or register staging (variant 2, kept for A/B runs); f32: registers
   if constexpr (sizeof(T) == 2) {
+    if (tile == 8) {        // persistent 128x128 with the epilogue folded into the next tile's K loop
+      if constexpr (!TA) {
+        if (!persist2_ok(d)) { evp_set_error("evp_gemm: tile 8 needs M,N %% 128 == 0, K %% 64 == 0, K >= 256, no batch / accumulate"); return EVP_ESHAPE; }
+        return launch_persist2<TC, EPI, TA, TB>(d, s);
+      } else {
+        evp_set_error("evp_gemm: tile 8 is not built for transA");
+        return EVP_EUNSUPPORTED;
+      }
+    }
+    if (tile == 7) {        // persistent 128x128 (single problem, no split-K)
+      const int64_t nbz = (int64_t)(d->batch0 > 0 ? d->batch0 : 1) * (d->batch1 > 0 ? d->batch1 : 1);
+      if (nbz != 1) { evp_set_error("evp_gemm: tile 7 (persistent) takes no batch"); return EVP_ESHAPE; }
+      return launch_persist<TC, EPI, TA, TB>(d, s);
+    }
     if (tile == 6) {
       if (d->K % 64 != 0) { evp_set_error("evp_gemm: tile 6 (256x256 ring) needs K %% 64 == 0 (K=%d)", d->K); return EVP_ESHAPE; }
       return launch256<TC, EPI, TA, TB>(d, s);
@@ -905,8 +1509,14 @@ extern "C" int evp_gemm_grouped_tn256_bf16(const void *problems, const void *ite
   return EVP_OK;
 }
 
+extern "C" int evp_gemm_set_debug_buffer(void *buf) {   // measurement aid: uint64 [4 * 512]; NULL switches it off
+  g_gemm_dbgbuf = reinterpret_cast<unsigned long long *>(buf);
+  return EVP_OK;
+}
+
 extern "C" int evp_gemm_set_variant(int v) {
   const int old = g_gemm_variant;
+  if (v >= 100 && v <= 102) g_gemm_dbg = v - 100;
   if (v == 1 || v == 2) g_gemm_variant = v;
   return old;
 }

@@ -108,6 +108,9 @@ int evp_gemm_grouped_tn256_bf16(const void *problems, const void *items, int n_i
 /* Tuning switch for A/B measurements: 1 = LDS-DMA (buffer_load ... lds) staging for bf16 (default), 2 = register
  * staging. Returns the previous value; any other argument only queries. Results are identical. */
 int evp_gemm_set_variant(int v);
+/* Measurement aid: device buffer uint64 [4*512] that the persistent kernel (tile 7) fills per workgroup with
+ * {total cycles, cycles inside epilogues, tiles done, start cycle}; NULL (default) switches it off. */
+int evp_gemm_set_debug_buffer(void *buf);
 
 /* ------------------------------------------------------------------------------------------------ K4/K9 LayerNorm
  * Replaces nn.LayerNorm over the last dim (vit_block.py:247,249; vit.py:126-128 with the 3-tap sum fused:
