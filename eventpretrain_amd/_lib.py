@@ -40,6 +40,7 @@ SIGNATURES = {
     "evp_gemm_grouped_tn256_bf16": [_vp, _vp, _i, _vp],
     "evp_gemm_set_variant": [_i],
     "evp_gemm_set_debug_buffer": [_vp],
+    "evp_attention_set_debug_buffer": [_vp],
     "evp_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp, _i, _vp, _vp, _vp],
     "evp_layernorm_bwd_nblk": [_i64],
     "evp_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp],

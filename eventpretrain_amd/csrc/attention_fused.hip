@@ -18,6 +18,8 @@ typedef __attribute__((ext_vector_type(8))) short i16x8;
 typedef __attribute__((ext_vector_type(4))) short i16x4;
 typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
 
+static unsigned long long *g_attn_dbg = nullptr;   // measurement aid, see evp_attention_set_debug_buffer
+
 namespace {
 
 // ---- LDS image of a [rows][DH] bf16 array: 16-byte chunks, XOR-swizzled for 128-byte rows ---------------------------
@@ -71,22 +73,68 @@ __device__ __forceinline__ void stage_head(const bf16_t *src, int64_t tok, int N
   }
 }
 
+// Batched form: every thread first ISSUES all its 16-byte loads of all NA arrays (NA * PER independent loads in
+// flight), then parks them in LDS. The loop form above costs one exposed HBM round trip per iteration and array --
+// about 12 (forward) / 25 (backward) serial round trips per workgroup before the first MFMA.
+template <int DH, int NP, int NA> struct HeadStage {
+  static constexpr int CPR = DH / 8, TOTAL = NP * CPR, PER = (TOTAL + 255) / 256;
+  uint4 r[NA][PER];
+  __device__ __forceinline__ void load(const bf16_t *const (&src)[NA], const int64_t (&tok)[NA], int N, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + i * 256, row = c / CPR, ch = c % CPR;
+      const bool ok = (TOTAL % 256 == 0 || c < TOTAL) && row < N;
+#pragma unroll
+      for (int a = 0; a < NA; ++a)
+        r[a][i] = ok ? *reinterpret_cast<const uint4 *>(src[a] + (int64_t)row * tok[a] + ch * 8) : make_uint4(0, 0, 0, 0);
+    }
+  }
+  __device__ __forceinline__ void store(int a, char *img, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid + i * 256, row = c / CPR, ch = c % CPR;
+      if (TOTAL % 256 == 0 || c < TOTAL) *reinterpret_cast<uint4 *>(img + img_off<DH>(row, ch)) = r[a][i];
+    }
+  }
+};
+
+// Workgroup -> (batch, head). With d_h = 32 a 128-byte line of qkv / out holds the slices of TWO adjacent heads, and
+// workgroups i and i+8 run on the same XCD (= share an L2): give that pair the two heads of one line, so the line is
+// fetched from HBM once instead of once per XCD. Pure renumbering (bijective when B*heads is a multiple of 16).
+template <int DH> __device__ __forceinline__ void head_of_block(int bid, int nblk, int heads, int &b, int &h) {
+  int L = bid;
+  if (DH == 32 && (nblk & 15) == 0 && (heads & 1) == 0) L = (bid & ~15) + 2 * (bid & 7) + ((bid >> 3) & 1);
+  b = L / heads;
+  h = L - b * heads;
+}
+
 // ---------------------------------------------------------------------------------------------------- forward
 // NT = number of 16-wide score tiles (NP = 16*NT rows in LDS, NT even)
 template <int DH, int NT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t *qkv, bf16_t *out, float *lse, bf16_t *probs, int N, int heads,
-                                                       float scale, int64_t ldp) {
+                                                       float scale, int64_t ldp, unsigned long long *dbg) {
+  unsigned long long t0 = 0, t1 = 0;
+  if (dbg) t0 = __builtin_readcyclecounter();
   constexpr int NP = 16 * NT, IMG = NP * DH * 2, KS = DH / 32, DT = DH / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *Qs = smem, *Ks = smem + IMG, *Vs = smem + 2 * IMG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  int b, h;
+  head_of_block<DH>(blockIdx.x, gridDim.x, heads, b, h);
+  const int bh = b * heads + h;
   const int64_t C = (int64_t)heads * DH, tok = 3 * C;
   const bf16_t *base = qkv + (int64_t)b * N * tok + (int64_t)h * DH;
-  stage_head<DH>(base, tok, N, NP, Qs, tid, 256);
-  stage_head<DH>(base + C, tok, N, NP, Ks, tid, 256);
-  stage_head<DH>(base + 2 * C, tok, N, NP, Vs, tid, 256);
+  {
+    HeadStage<DH, NP, 3> st;
+    const bf16_t *const src[3] = {base, base + C, base + 2 * C};
+    const int64_t toks[3] = {tok, tok, tok};
+    st.load(src, toks, N, tid);
+    st.store(0, Qs, tid);
+    st.store(1, Ks, tid);
+    st.store(2, Vs, tid);
+  }
   __syncthreads();
+  if (dbg) t1 = __builtin_readcyclecounter();
   const float c2 = scale * 1.44269504088896340736f;   // exp(x*scale) = exp2(x*c2)
 
   for (int strip = wave; strip * 16 < N; strip += 4) {
@@ -101,34 +149,42 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t *qkv, bf16_t
       for (int ks = 0; ks < KS; ++ks)
         S[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Ks, t * 16, ks, lane), qf[ks], S[t], 0, 0, 0);
     }
-    // lane: query strip*16 + li; registers: keys 16t + 4g + r
-    float mx = -INFINITY;
+    // lane: query strip*16 + li; registers: keys 16t + 4g + r. The softmax is the VALU-bound part of this kernel
+    // (56 scores per lane and strip at N = 196), so it is written on whole f32x4 tiles (v_pk_* packed math), with the
+    // raw v_exp_f32 (arguments are <= 0: no overflow, underflow to 0 is the wanted result) and with the key mask applied
+    // only to the tiles that reach past N.
+    f32x4 mx4 = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      if (16 * t + 15 >= N) {               // wave-uniform: only the last one or two tiles
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (16 * t + 4 * g + r >= N) S[t][r] = -INFINITY;
-        mx = fmaxf(mx, S[t][r]);
+        for (int r = 0; r < 4; ++r)
+          if (16 * t + 4 * g + r >= N) S[t][r] = -INFINITY;
       }
+      mx4 = __builtin_elementwise_max(mx4, S[t]);
+    }
+    float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
+    const float nm = -mx * c2;
+    const f32x4 c2v = f32x4{c2, c2, c2, c2}, nmv = f32x4{nm, nm, nm, nm};
+    f32x4 sum4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        S[t][r] = exp2f((S[t][r] - mx) * c2);
-        sum += S[t][r];
-      }
+    for (int t = 0; t < NT; ++t) {
+      const f32x4 e = __builtin_elementwise_fma(S[t], c2v, nmv);
+      S[t] = f32x4{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1]), __builtin_amdgcn_exp2f(e[2]), __builtin_amdgcn_exp2f(e[3])};
+      sum4 += S[t];
+    }
+    float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     const int q = strip * 16 + li;
-    if (g == 0 && q < N && lse) lse[(int64_t)blockIdx.x * N + q] = mx * scale + logf(sum);
+    if (g == 0 && q < N && lse) lse[(int64_t)bh * N + q] = mx * scale + logf(sum);
 #pragma unroll
     for (int t = 0; t < NT; ++t) S[t] = S[t] * inv;
     if (probs && q < N) {
-      bf16_t *pr = probs + ((int64_t)blockIdx.x * N + q) * ldp;
+      bf16_t *pr = probs + ((int64_t)bh * N + q) * ldp;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
         if (16 * t + 4 * g < ldp) *reinterpret_cast<uint2 *>(pr + 16 * t + 4 * g) = pack4(S[t]);
@@ -143,6 +199,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t *qkv, bf16_t
       if (q < N) *reinterpret_cast<uint2 *>(out + ((int64_t)b * N + q) * C + h * DH + dt * 16 + 4 * g) = pack4(O);
     }
   }
+  if (dbg && (threadIdx.x & 63) == 0) {
+    const unsigned long long t2 = __builtin_readcyclecounter();
+    dbg[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + 0] = t1 - t0;     // staging
+    dbg[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + 1] = t2 - t1;     // strips of this wave
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------- backward
@@ -154,34 +215,49 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *qkv, const 
   char *Qs = smem, *Ks = smem + IMG, *Vs = smem + 2 * IMG, *Gs = smem + 3 * IMG;   // Gs = dO
   float *Ls = reinterpret_cast<float *>(smem + 4 * IMG), *Ds = Ls + NP;          // log-sum-exp, delta = rowsum(dO * O)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  int b, h;
+  head_of_block<DH>(blockIdx.x, gridDim.x, heads, b, h);
+  const int bh = b * heads + h;
   const int64_t C = (int64_t)heads * DH, tok = 3 * C;
   const bf16_t *base = qkv + (int64_t)b * N * tok + (int64_t)h * DH;
-  stage_head<DH>(base, tok, N, NP, Qs, tid, 256);
-  stage_head<DH>(base + C, tok, N, NP, Ks, tid, 256);
-  stage_head<DH>(base + 2 * C, tok, N, NP, Vs, tid, 256);
   const bf16_t *go = dout + (int64_t)b * N * C + (int64_t)h * DH, *oo = out + (int64_t)b * N * C + (int64_t)h * DH;
-  stage_head<DH>(go, C, N, NP, Gs, tid, 256);
-  // delta[q] = sum_d dO[q,d] * O[q,d]: DH/8 consecutive threads share a row
   {
-    constexpr int CPR = DH / 8;
-    for (int c = tid; c < NP * CPR; c += 256) {   // NP*CPR is a multiple of CPR, rows never straddle the loop bound
-      const int row = c / CPR, ch = c % CPR;
-      float d = 0.f;
-      if (row < N) {
-        const uint4 a = *reinterpret_cast<const uint4 *>(go + (int64_t)row * C + ch * 8);
-        const uint4 o = *reinterpret_cast<const uint4 *>(oo + (int64_t)row * C + ch * 8);
-        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, ow[4] = {o.x, o.y, o.z, o.w};
+    // Q, K, V, dO and O in one batch of loads; O is only needed for delta[q] = sum_d dO[q,d] * O[q,d], formed from the
+    // staged registers (the DH/8 consecutive threads that share a row meet with shuffles)
+    using ST = HeadStage<DH, NP, 5>;
+    ST st;
+    const bf16_t *const src[5] = {base, base + C, base + 2 * C, go, oo};
+    const int64_t toks[5] = {tok, tok, tok, C, C};
+    st.load(src, toks, N, tid);
+    float lv[(NP + 255) / 256];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          d += __uint_as_float(aw[e] << 16) * __uint_as_float(ow[e] << 16) +
-               __uint_as_float(aw[e] & 0xFFFF0000u) * __uint_as_float(ow[e] & 0xFFFF0000u);
-      }
-#pragma unroll
-      for (int o = 1; o < CPR; o <<= 1) d += __shfl_xor(d, o, 64);
-      if (ch == 0) Ds[row] = d;
+    for (int i = 0; i < (NP + 255) / 256; ++i) {
+      const int r = tid + i * 256;
+      lv[i] = (r < N) ? lse[(int64_t)bh * N + r] : INFINITY;      // exp(-inf) = 0 on the padded queries
     }
-    for (int r = tid; r < NP; r += 256) Ls[r] = r < N ? lse[(int64_t)blockIdx.x * N + r] : INFINITY;   // exp(-inf) = 0 pads
+    st.store(0, Qs, tid);
+    st.store(1, Ks, tid);
+    st.store(2, Vs, tid);
+    st.store(3, Gs, tid);
+#pragma unroll
+    for (int i = 0; i < ST::PER; ++i) {
+      const int c = tid + i * 256, row = c / ST::CPR, ch = c % ST::CPR;
+      const uint32_t aw[4] = {st.r[3][i].x, st.r[3][i].y, st.r[3][i].z, st.r[3][i].w};
+      const uint32_t ow[4] = {st.r[4][i].x, st.r[4][i].y, st.r[4][i].z, st.r[4][i].w};
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        d += __uint_as_float(aw[e] << 16) * __uint_as_float(ow[e] << 16) +
+             __uint_as_float(aw[e] & 0xFFFF0000u) * __uint_as_float(ow[e] & 0xFFFF0000u);
+#pragma unroll
+      for (int o = 1; o < ST::CPR; o <<= 1) d += __shfl_xor(d, o, 64);
+      if (ch == 0 && (ST::TOTAL % 256 == 0 || c < ST::TOTAL)) Ds[row] = d;
+    }
+#pragma unroll
+    for (int i = 0; i < (NP + 255) / 256; ++i) {
+      const int r = tid + i * 256;
+      if (r < NP) Ls[r] = lv[i];
+    }
   }
   __syncthreads();
   const float c2 = scale * 1.44269504088896340736f, l2e = 1.44269504088896340736f;
@@ -196,6 +272,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *qkv, const 
     }
     const float lq = Ls[strip * 16 + li] * l2e, dq_ = Ds[strip * 16 + li];
     const int q = strip * 16 + li;
+    const f32x4 c2q = f32x4{c2, c2, c2, c2}, nlq = f32x4{-lq, -lq, -lq, -lq}, dqv = f32x4{dq_, dq_, dq_, dq_}, scv = f32x4{scale, scale, scale, scale};
     f32x4 accq[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) accq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -213,11 +290,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *qkv, const 
             s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Ks, t * 16, ks, lane), qf[ks], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<DH>(Vs, t * 16, ks, lane), gf[ks], dp, 0, 0, 0);
           }
+          // dS = P * (dP - delta) * scale on the whole tile (packed f32 math, raw v_exp_f32); keys past N only exist in
+          // the last one or two tiles
+          f32x4 pv = __builtin_elementwise_fma(s, c2q, nlq);
+          pv = f32x4{__builtin_amdgcn_exp2f(pv[0]), __builtin_amdgcn_exp2f(pv[1]), __builtin_amdgcn_exp2f(pv[2]), __builtin_amdgcn_exp2f(pv[3])};
+          if (16 * t + 15 >= N) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = (16 * t + 4 * g + r < N) ? exp2f(s[r] * c2 - lq) : 0.f;
-            P[tt][r] = p * (dp[r] - dq_) * scale;   // dS
+            for (int r = 0; r < 4; ++r)
+              if (16 * t + 4 * g + r >= N) pv[r] = 0.f;
           }
+          P[tt] = pv * ((dp - dqv) * scv);
         }
       }
 #pragma unroll
@@ -261,13 +343,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *qkv, const 
           }
           const float4 lq = *reinterpret_cast<const float4 *>(Ls + 16 * t + 4 * g);
           const float4 dl = *reinterpret_cast<const float4 *>(Ds + 16 * t + 4 * g);
-          const float lqa[4] = {lq.x, lq.y, lq.z, lq.w}, dla[4] = {dl.x, dl.y, dl.z, dl.w};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = exp2f(s[r] * c2 - lqa[r] * l2e);   // padded queries carry lse = +inf -> p = 0
-            P[tt][r] = p;
-            dS[tt][r] = p * (dp[r] - dla[r]) * scale;
-          }
+          const f32x4 nl = f32x4{-lq.x * l2e, -lq.y * l2e, -lq.z * l2e, -lq.w * l2e}, dlv = f32x4{dl.x, dl.y, dl.z, dl.w};
+          const f32x4 c2k = f32x4{c2, c2, c2, c2}, sck = f32x4{scale, scale, scale, scale};
+          f32x4 pv = __builtin_elementwise_fma(s, c2k, nl);        // padded queries carry lse = +inf -> p = 0
+          pv = f32x4{__builtin_amdgcn_exp2f(pv[0]), __builtin_amdgcn_exp2f(pv[1]), __builtin_amdgcn_exp2f(pv[2]), __builtin_amdgcn_exp2f(pv[3])};
+          P[tt] = pv;
+          dS[tt] = pv * ((dp - dlv) * sck);
         }
       }
 #pragma unroll
@@ -298,7 +379,7 @@ int launch_fwd(const bf16_t *qkv, bf16_t *out, float *lse, bf16_t *probs, int B,
   constexpr int smem = 3 * 16 * NT * DH * 2;
   auto k = attn_fwd_kernel<DH, NT>;
   if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  hipLaunchKernelGGL(k, dim3(B * heads), dim3(256), smem, s, qkv, out, lse, probs, N, heads, scale, ldp);
+  hipLaunchKernelGGL(k, dim3(B * heads), dim3(256), smem, s, qkv, out, lse, probs, N, heads, scale, ldp, g_attn_dbg);
   EVP_CHECK_LAUNCH("evp_attention_fused_fwd");
   return EVP_OK;
 }
@@ -320,6 +401,11 @@ int launch_bwd(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const f
   else { constexpr int NTV = 14; constexpr int DHC = DHV; CALL; }
 
 }  // namespace
+
+extern "C" int evp_attention_set_debug_buffer(void *buf) {   // measurement aid: uint64 [B*heads*4*2] {staging, compute} cycles per wave
+  g_attn_dbg = reinterpret_cast<unsigned long long *>(buf);
+  return EVP_OK;
+}
 
 extern "C" int evp_attention_fused_supported(int dtype, int N, int dh) {
   return dtype == EVP_BF16 && N >= 1 && N <= 224 && (dh == 32 || dh == 64);

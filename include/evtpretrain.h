@@ -155,6 +155,9 @@ int evp_attention_bwd(const void *qkv, const void *probs, const void *dout, int 
  * when the caller needs the attention map (dense branch, vit.py:144). The backward recomputes the probabilities from
  * qkv and lse; out is the forward output (needed for rowsum(dout*out)). */
 int evp_attention_fused_supported(int dtype, int N, int dh);
+/* Measurement aid: device buffer uint64 [B*heads*4*2] that evp_attention_fused_fwd fills per wave with {staging, compute}
+ * cycles; NULL (default) switches it off. */
+int evp_attention_set_debug_buffer(void *buf);
 int evp_attention_fused_fwd(const void *qkv, int B, int N, int heads, int dh, float scale, void *out, float *lse,
                             void *probs, int64_t ldp, void *stream);
 int evp_attention_fused_bwd(const void *qkv, const void *out, const void *dout, const float *lse, int B, int N,

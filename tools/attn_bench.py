@@ -36,3 +36,17 @@ for name, B, N, h, dh in [("enc", 64, 98, 12, 64), ("dec", 64, 196, 16, 32)]:
     print(f"{name} unfused fwd {t*1e6:8.1f} us")
     t = bench(lambda: ops.attention_bwd(qkv, probs, dout, B, N, h, dh))
     print(f"{name} unfused bwd {t*1e6:8.1f} us")
+
+# per-wave cycle split of the fused forward (staging vs strips)
+from eventpretrain_amd._lib import call  # noqa: E402
+for name, B, N, h, dh in [("enc", 64, 98, 12, 64), ("dec", 64, 196, 16, 32)]:
+    C = h * dh
+    qkv = (torch.randn(B * N, 3 * C, device="cuda") * 0.8).bfloat16()
+    dbg = torch.zeros(B * h * 4 * 2, dtype=torch.int64, device="cuda")
+    call("evp_attention_set_debug_buffer", dbg.data_ptr())
+    for _ in range(3):
+        ops.attention_fused_fwd(qkv, B, N, h, dh)
+    torch.cuda.synchronize()
+    call("evp_attention_set_debug_buffer", None)
+    d = dbg.cpu().numpy().reshape(-1, 2).astype(float)
+    print(f"{name} fwd: staging cycles mean {d[:, 0].mean():.0f} max {d[:, 0].max():.0f}; strips cycles per wave mean {d[:, 1].mean():.0f} max {d[:, 1].max():.0f}")
