@@ -284,7 +284,7 @@ def main():
         loss = None
         try:
             g_ = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_, stream=side):
+            with torch.cuda.graph(g_, stream=side, capture_error_mode="thread_local"):   # RCCL's watchdog thread polls events meanwhile
                 out = model(vox, tgt, is_rec=True, noise=noise_buf)
                 out[0].backward()
                 if not multi:
@@ -297,7 +297,7 @@ def main():
                 plan = reducer.make_static_plan()       # freezes the (now static) gradient buffers
                 plan.run()
                 g2_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2_, stream=side):
+                with torch.cuda.graph(g2_, stream=side, capture_error_mode="thread_local"):
                     opt.refresh()
                     opt.launch()
                 graph2, graph_note = g2_, "hip-graph (fwd+bwd) + RCCL all-reduce + hip-graph (AdamW)"
@@ -368,9 +368,13 @@ def main():
         def timed_call(name, *a_):
             if name not in GROUPED:
                 return orig_call(name, *a_)
+            # like every other GEMM: the same launch 10x between two events (its tables are still alive here; the step's
+            # gradients are not used after this instrumented pass, so re-accumulating into them is harmless)
+            r = orig_call(name, *a_)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            r = orig_call(name, *a_)
+            for _ in range(10):
+                orig_call(name, *a_)
             e1.record()
             grouped.setdefault(name, {})["ev"] = (e0, e1)
             return r
@@ -398,7 +402,7 @@ def main():
         for name, g_ in grouped.items():
             if "ev" not in g_:
                 continue
-            sec = g_["ev"][0].elapsed_time(g_["ev"][1]) * 1e-3
+            sec = g_["ev"][0].elapsed_time(g_["ev"][1]) * 1e-3 / 10
             ks.append(dict(kernel="%s (weight gradients of the step, %d tiles)" % (GROUPED[name][0], g_["tiles"]),
                            launches_per_step=1, avg_us=sec * 1e6, tflops=g_["flops"] / sec / 1e12, ms_per_step=sec * 1e3,
                            flops_per_step=g_["flops"]))
