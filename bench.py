@@ -246,80 +246,26 @@ def main():
         reducer = BucketedGradReducer([p for p in model.parameters() if p.requires_grad], bucket_mb=args.bucket_mb)
     gen = torch.Generator(device=device).manual_seed(100 + rank)     # seed + rank, as main_pretrain.py:174
     L = model.backbone.num_patches
-    noise_buf = torch.empty(args.batch, L, device=device)
-
-    def eager_step():
-        nonlocal gen
-        noise_buf.copy_(torch.rand(args.batch, L, device=device, generator=gen))
-        out = model(vox, tgt, is_rec=True, noise=noise_buf)
-        out[0].backward()
-        if reducer is not None:
-            reducer.finish()
-        opt.step()
-        opt.zero_grad(set_to_none=True)
-        return out[0]
 
     def barrier():
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- HIP graphs of the step: the ~900 kernel launches of forward + backward (+ AdamW) are captured once and
-    # replayed; per-step scalars (lr, Adam bias corrections) travel through pinned host tables that the graph's own
-    # H2D copy nodes re-read, the mask noise is drawn into a static buffer before each replay. With N > 1 the
-    # collectives stay outside the graphs: [forward+backward graph] -> in-place RCCL all-reduce of the flat gradient
-    # buffers -> [AdamW graph].
-    graph, graph2, plan, graph_note, static_loss = None, None, None, "eager", None
+    # ---- the step executor (eventpretrain_amd/engine.py): the ~600 kernel launches of forward + backward (+ AdamW) are
+    # captured once in HIP graphs and replayed; per-step scalars (lr, Adam bias corrections) travel through pinned host
+    # tables that the graph's own H2D copy nodes re-read, the mask noise is drawn into a static buffer before each
+    # replay. With N > 1 the collectives stay outside the graphs: [forward+backward graph] -> in-place RCCL all-reduce of
+    # the flat gradient buffers -> [AdamW graph].
+    from eventpretrain_amd.engine import GraphedStep
     use_graph = not args.no_graph
-    n_warm_eager = min(args.warmup, 3) if use_graph else args.warmup
+    n_warm_eager = min(args.warmup, 3) if use_graph else 0
+    executor = GraphedStep(model, opt, lambda m, x, y, noise: m(x, y, is_rec=True, noise=noise), [vox, tgt],
+                           noise_shape=(args.batch, L), generator=gen, reducer=reducer, use_graph=use_graph,
+                           warmup=max(n_warm_eager, 2))
+    graph_note = executor.note
+    step, eager_step = executor.step, executor.eager_step
     loss = None
-    if use_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):     # warm up on the capture stream so every AccumulateGrad node is born there
-            for _ in range(max(n_warm_eager, 2)):
-                loss = eager_step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        loss = None
-        try:
-            g_ = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_, stream=side, capture_error_mode="thread_local"):   # RCCL's watchdog thread polls events meanwhile
-                out = model(vox, tgt, is_rec=True, noise=noise_buf)
-                out[0].backward()
-                if not multi:
-                    opt.refresh()
-                    opt.launch()
-                static_loss = out[0].detach()
-                del out
-            graph, graph_note = g_, "hip-graph"
-            if multi:
-                plan = reducer.make_static_plan()       # freezes the (now static) gradient buffers
-                plan.run()
-                g2_ = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2_, stream=side, capture_error_mode="thread_local"):
-                    opt.refresh()
-                    opt.launch()
-                graph2, graph_note = g2_, "hip-graph (fwd+bwd) + RCCL all-reduce + hip-graph (AdamW)"
-        except Exception as e:      # keep the benchmark alive; say what happened
-            graph, graph2, plan = None, None, None
-            graph_note = "eager (graph capture failed: %r)" % (e,)
-            opt.zero_grad(set_to_none=True)
-            gen = torch.Generator(device=device).manual_seed(100 + rank)   # a failed capture can poison the old one
-    else:
-        for _ in range(n_warm_eager):
-            loss = eager_step()
-
-    def step():
-        if graph is None:
-            return eager_step()
-        noise_buf.copy_(torch.rand(args.batch, L, device=device, generator=gen))
-        opt.stage_scalars()
-        graph.replay()
-        if plan is not None:
-            plan.run()
-            graph2.replay()
-        return static_loss
 
     for _ in range(args.warmup - n_warm_eager):
         loss = step()

@@ -1,0 +1,112 @@
+"""Step executor: the pre-training step (forward + backward + FusedAdamW) captured once in HIP graphs and replayed.
+
+An eager step of this path is ~600 kernel launches from Python -- launch-bound at about twice the device time. The
+executor runs a few eager steps (allocator and autograd warm-up, on the capture stream), captures
+
+    1 rank : [forward + backward + AdamW]                                               one graph
+    N ranks: [forward + backward] -> in-place RCCL all-reduce of the flat gradient buffers -> [AdamW]
+
+and from then on a step is: copy the batch into the static input buffers, draw the mask noise into its static buffer,
+stage the optimizer's per-step scalars (lr, bias corrections) into the pinned table the graph's own H2D node re-reads,
+replay. Collectives stay outside the graphs. If capture fails the executor says so and keeps stepping eagerly.
+
+Replaces nothing in the reference (its loop is eager PyTorch, trainer/pretrain/pr_trainer.py:20-76); it is the
+MI355X-side answer to "launch-bound inner loop -> HIP graph". `trainer.pretrain.pr_trainer.pr_rec_one_epoch(...,
+step_executor=...)` uses it when given one."""
+import torch
+
+from . import ops
+
+
+class GraphedStep:
+    def __init__(self, model, optimizer, forward, static_inputs, noise_shape=None, generator=None, reducer=None,
+                 use_graph=True, warmup=2):
+        """forward(model, *static_inputs, noise) -> tuple whose first item is the loss. `static_inputs`: device tensors
+        with the batch's shapes (overwritten by `step(...)` when new data is passed). `noise_shape`: (B, L) of the
+        masking noise, or None when the model draws none (density masking, contrastive stage)."""
+        self.model, self.opt, self.forward, self.reducer = model, optimizer, forward, reducer
+        self.inputs = [t for t in static_inputs]
+        dev = self.inputs[0].device
+        self.gen = generator if generator is not None else torch.Generator(device=dev)
+        self.noise = torch.empty(*noise_shape, device=dev) if noise_shape is not None else None
+        self.graph = self.graph2 = self.plan = None
+        self.loss = None
+        self.note = "eager"
+        self.multi = reducer is not None
+        if use_graph:
+            self._capture(max(2, warmup))
+
+    # ------------------------------------------------------------------------------------------------ eager form
+    def _draw_noise(self):
+        if self.noise is not None:
+            self.noise.copy_(torch.rand(self.noise.shape, device=self.noise.device, generator=self.gen))
+
+    def eager_step(self):
+        self._draw_noise()
+        out = self.forward(self.model, *self.inputs, self.noise)
+        out[0].backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        return out[0]
+
+    # ------------------------------------------------------------------------------------------------ capture
+    def _capture(self, warmup):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):       # warm up on the capture stream so every AccumulateGrad node is born there
+            for _ in range(warmup):
+                self.eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        try:
+            g1 = torch.cuda.CUDAGraph()
+            # thread_local: RCCL's watchdog thread polls its events while this thread captures
+            with torch.cuda.graph(g1, stream=side, capture_error_mode="thread_local"):
+                out = self.forward(self.model, *self.inputs, self.noise)
+                out[0].backward()
+                if not self.multi:
+                    self.opt.refresh()
+                    self.opt.launch()
+                self.loss = out[0].detach()
+                del out
+            self.graph, self.note = g1, "hip-graph"
+            if self.multi:
+                self.plan = self.reducer.make_static_plan()        # freezes the (now static) gradient buffers
+                self.plan.run()
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, stream=side, capture_error_mode="thread_local"):
+                    self.opt.refresh()
+                    self.opt.launch()
+                self.graph2, self.note = g2, "hip-graph (fwd+bwd) + RCCL all-reduce + hip-graph (AdamW)"
+        except Exception as e:               # keep training; say what happened
+            self.graph = self.graph2 = self.plan = None
+            self.note = "eager (graph capture failed: %r)" % (e,)
+            self.opt.zero_grad(set_to_none=True)
+            ops.flush_deferred_grads()
+            dev = self.inputs[0].device
+            seed = self.gen.initial_seed()
+            self.gen = torch.Generator(device=dev).manual_seed(seed)      # a failed capture can poison the old generator
+
+    def resync_weights(self):
+        """Call after the weights were changed behind the optimizer's back (load_state_dict, manual edits): refreshes the
+        bf16 weight shadows in place so the captured graphs see the new values."""
+        ops.refresh_lp_shadows(self.model.parameters())
+
+    # ------------------------------------------------------------------------------------------------ stepping
+    def step(self, *new_inputs):
+        """One optimizer step. With arguments, the batch is first copied into the static buffers (same shapes).
+        Returns the loss as a 0-dim device tensor (the graph's static output: read it before the next step)."""
+        for dst, src in zip(self.inputs, new_inputs):
+            if src is not dst:
+                dst.copy_(src, non_blocking=True)
+        if self.graph is None:
+            return self.eager_step()
+        self._draw_noise()
+        self.opt.stage_scalars()
+        self.graph.replay()
+        if self.plan is not None:
+            self.plan.run()
+            self.graph2.replay()
+        return self.loss

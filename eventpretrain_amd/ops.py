@@ -110,6 +110,16 @@ def lp_weight(w):
     return sh
 
 
+def refresh_lp_shadows(params):
+    """Re-cast the f32 master weights into their EXISTING bf16 shadow buffers (same addresses: captured HIP graphs keep
+    reading them). Needed after weights were changed outside FusedAdamW, e.g. by load_state_dict."""
+    for w in params:
+        sh = getattr(w, "_evp_lp", None)
+        if sh is not None and sh.device == w.device:
+            call("evp_cast", ptr(_chk(w.detach())), EVP_F32, ptr(sh), EVP_BF16, w.numel(), stream_ptr())
+            w._evp_lp_version = w._version
+
+
 def colsum(x2d, out=None):
     M, N = x2d.shape
     out = torch.empty(N, dtype=torch.float32, device=x2d.device) if out is None else out

@@ -124,6 +124,15 @@ class FusedAdamW(torch.optim.Optimizer):
         step = max(self._step, 1)
         T["n_hyper"][:] = (1.0 - b1 ** step, math.sqrt(1.0 - b2 ** step), self.grad_scale, 1.0)
 
+    @torch.no_grad()
+    def reset_state(self):
+        """Zero the moments IN PLACE and restart the step counter (the captured graphs keep pointing at these buffers)."""
+        for st in self.state.values():
+            if "exp_avg" in st:
+                st["exp_avg"].zero_()
+                st["exp_avg_sq"].zero_()
+        self._step = 0
+
     def launch(self):
         """Device side of a step (graph-capturable): one evp_adamw_multi over all chunks."""
         T = self._tabs

@@ -8,7 +8,7 @@ from ...utils import misc
 from ...utils.lr_sched import adjust_learning_rate
 
 
-def _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, loss_name, forward, vis_hook):
+def _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, loss_name, forward, vis_hook, step_executor=None):
     model.train(True)
     logger = misc.MetricLogger(delimiter="  ")
     logger.add_meter("lr", misc.SmoothedValue(window_size=1, fmt="{value:.6f}"))
@@ -23,18 +23,27 @@ def _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, l
             adjust_learning_rate(optimizer, it / n_iter + epoch, args)
         events_voxel_grid = batch[0].to(args.device, non_blocking=True)
         supp = batch[1].to(args.device, non_blocking=True)
-        outputs = forward(events_voxel_grid, supp)
-        loss = outputs[0]
-        last = (events_voxel_grid, supp, outputs, batch[-1])
-        if vis_hook is not None and args.test_experiment and args.visualize:
-            vis_hook(args, *last, epoch)
-        logger.update(**{loss_name: loss.item()})
-        loss = loss / args.accum_iter
-        step_now = (it + 1) % args.accum_iter == 0
-        if args.backward:
-            loss_scaler(loss, optimizer, parameters=model.parameters(), update_grad=step_now)
-            if step_now:
-                optimizer.zero_grad()
+        if step_executor is not None:
+            # HIP-graph replay of forward + backward + optimizer step (eventpretrain_amd/engine.py); the lr set above
+            # reaches the graph through the optimizer's staged scalars
+            if args.accum_iter != 1 or not args.backward:
+                raise ValueError("step_executor runs one optimizer step per batch (accum_iter=1, backward=True)")
+            loss = step_executor.step(events_voxel_grid, supp)
+            logger.update(**{loss_name: loss.item()})
+            step_now = True
+        else:
+            outputs = forward(events_voxel_grid, supp)
+            loss = outputs[0]
+            last = (events_voxel_grid, supp, outputs, batch[-1])
+            if vis_hook is not None and args.test_experiment and args.visualize:
+                vis_hook(args, *last, epoch)
+            logger.update(**{loss_name: loss.item()})
+            loss = loss / args.accum_iter
+            step_now = (it + 1) % args.accum_iter == 0
+            if args.backward:
+                loss_scaler(loss, optimizer, parameters=model.parameters(), update_grad=step_now)
+                if step_now:
+                    optimizer.zero_grad()
         if str(args.device).startswith("cuda"):
             torch.cuda.synchronize()
         lr = optimizer.param_groups[0]["lr"]
@@ -51,16 +60,20 @@ def _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, l
     return {k: m.global_avg for k, m in logger.meters.items()}
 
 
-def pr_rec_one_epoch(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer=None, vis_hook=None):
-    """Masked-modeling epoch: model(events_voxel_grid, sub_frame, is_rec=True)."""
+def pr_rec_one_epoch(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer=None, vis_hook=None,
+                     step_executor=None):
+    """Masked-modeling epoch: model(events_voxel_grid, sub_frame, is_rec=True). `step_executor` (an
+    eventpretrain_amd.engine.GraphedStep built on this model / optimizer) replaces the eager forward / backward /
+    optimizer calls by a HIP-graph replay."""
     return _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, "reconstruct_loss",
-                 lambda x, y: model(x, y, is_rec=True), vis_hook)
+                 lambda x, y: model(x, y, is_rec=True), vis_hook, step_executor)
 
 
-def pr_con_one_epoch(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer=None, vis_hook=None):
+def pr_con_one_epoch(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer=None, vis_hook=None,
+                     step_executor=None):
     """Contrastive / transfer epoch: model(events_voxel_grid, clip_emb)."""
     return _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, "contrastive_loss",
-                 lambda x, y: model(x, y), vis_hook)
+                 lambda x, y: model(x, y), vis_hook, step_executor)
 
 
 def pr_rec_and_con_one_epoch(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer=None, vis_hook=None):

@@ -332,3 +332,61 @@ def test_no_cpu_fallback():
     from eventpretrain_amd._lib import EvpError
     with pytest.raises(EvpError):
         ops.layernorm_fwd(torch.zeros(4, 8), torch.ones(8), torch.zeros(8), 1e-6, torch.float32)
+
+
+def test_trainer_with_graph_executor_matches_eager():
+    """The epoch loop driven by engine.GraphedStep (HIP-graph replay of forward + backward + FusedAdamW) follows the same
+    trajectory as the eager loop: same lr schedule, same per-step losses (same generator seed for the mask noise)."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.engine import GraphedStep
+    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
+    from eventpretrain_amd.optim import FusedAdamW
+    from eventpretrain_amd.testing import det_fill_module_, det_normalish, make_args
+    from eventpretrain_amd.trainer.pretrain.pr_trainer import pr_rec_one_epoch
+    from eventpretrain_amd.utils import lr_decay as lrd
+    from eventpretrain_amd.utils.misc import NativeScalerWithGradNormCount
+    batches = [dict(events_voxel_grid=det_normalish(f"train.voxels.{s}", (2, 5, 64, 64)) * 0.5,
+                    sub_frame=det_normalish(f"train.sub_frame.{s}", (2, 1, 64, 64)), image_name=["a", "b"]) for s in range(4)]
+    runs = []
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        for graphed in (False, True):
+            a = make_args(model_size="tiny", pr_phase="rec", patch_size=16, device="cuda", input_size=64)
+            a.lr, a.min_lr, a.warmup_epochs, a.epochs, a.batch_size = 1e-3, 1e-6, 1, 4, 2
+            m = hub.pretrain_hub_model_tiny_patch16_64(a, emb_frames_dim=512, queue_length=1024, T=0.07)
+            det_fill_module_(m)
+            m = m.cuda().train()
+            opt = FusedAdamW(lrd.param_groups_lrd(a, m, a.weight_decay, layer_decay=1), lr=a.lr, betas=(0.9, 0.95))
+            ex = None
+            losses = []
+            if graphed:
+                gen = torch.Generator(device="cuda").manual_seed(7)
+                x0, y0 = batches[0]["events_voxel_grid"].cuda(), batches[0]["sub_frame"].cuda()
+                sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+                ex = GraphedStep(m, opt, lambda mm, x, y, noise: mm(x, y, is_rec=True, noise=noise), [x0.clone(), y0.clone()],
+                                 noise_shape=(2, 16), generator=gen, warmup=2)
+                assert ex.note == "hip-graph", ex.note
+                # the warm-up steps moved the weights and the optimizer state: start both runs from the same point
+                m.load_state_dict(sd0)
+                ex.resync_weights()
+                opt.reset_state()
+                gen.manual_seed(7)
+            else:
+                torch.manual_seed(0)
+                gen = torch.Generator(device="cuda").manual_seed(7)
+                real_rand = torch.rand
+                torch.rand = lambda *s, **k: real_rand(*s, **{**k, "generator": gen}) if k.get("device") is not None else real_rand(*s, **k)
+            try:
+                for ep in range(4):
+                    st = pr_rec_one_epoch(a, m, batches[ep:ep + 1], opt, ep, NativeScalerWithGradNormCount(), step_executor=ex)
+                    losses.append((st["reconstruct_loss"], st["lr"]))
+            finally:
+                if not graphed:
+                    torch.rand = real_rand
+            runs.append(losses)
+    finally:
+        ops.set_compute_dtype(torch.float32)
+    for (l0, lr0), (l1, lr1) in zip(*runs):
+        assert lr0 == pytest.approx(lr1, rel=1e-6)
+        assert l0 == pytest.approx(l1, rel=2e-3), (runs)
+    assert runs[1][-1][0] < runs[1][0][0]
