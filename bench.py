@@ -328,7 +328,7 @@ def main():
         orig_flush = _ops._deferred.flush
 
         def counting_flush():
-            for (_, _, _, n_out, k_in, rows) in _ops._deferred.w:
+            for (_, _, _, n_out, k_in, rows, _bp) in _ops._deferred.w:
                 big = _ops._use_wgrad256 and rows % 64 == 0 and n_out >= 256 and k_in >= 256      # the routing rule of flush()
                 name = "evp_gemm_grouped_tn256_bf16" if big else "evp_gemm_grouped_tn_bf16"
                 T_ = GROUPED[name][1]

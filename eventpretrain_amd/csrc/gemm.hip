@@ -41,6 +41,8 @@ struct GemmParams {
   int splitk, k_per_split;   // blockIdx.y = K slice
   int dbg;                   // measurement aid (evp_gemm_set_variant(101): skip the epilogue; results are then garbage)
   unsigned long long *dbgbuf; // measurement aid: per-workgroup cycle counters of the persistent kernel
+  float *colsum;             // 256x256 TN body only: colsum[m] (+)= sum_k A[k][m] (bias gradient), written by the tile_n == 0 workgroups
+  int colsum_acc;
 };
 
 template <typename T> struct Cfg;
@@ -752,7 +754,8 @@ struct GroupedProblem {
   void *C;
   int M, N, K;
   int lda, ldb, ldc;
-  int accumulate, pad;
+  int accumulate, colsum_accumulate;
+  float *colsum;             // 256x256 kernel only: colsum[m] (+)= sum_k A[k][m]; NULL = none
 };
 struct GroupedItem { int prob, tile_m, tile_n, pad; };
 
@@ -766,7 +769,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_tn_kernel(const GroupedProbl
   p.B = g.B; p.ldb = g.ldb; p.sB0 = 0; p.sB1 = 0;
   p.C = g.C; p.c_dtype = EVP_F32; p.ldc = g.ldc; p.sC0 = 0; p.sC1 = 0;
   p.batch1 = 1; p.alpha = 1.0f; p.bias = nullptr; p.act = EVP_ACT_NONE; p.aux = nullptr; p.ldaux = 0;
-  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1; p.dbg = 0; p.dbgbuf = nullptr;
+  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1; p.dbg = 0; p.dbgbuf = nullptr; p.colsum = nullptr; p.colsum_acc = 0;
   p.k_per_split = (g.K + 63) / 64 * 64;
   gemm_body<bf16_t, float, 0, true, true, BM, BN, 2, 2, true, 2, 64>(p, it.tile_m, it.tile_n, 0, 0);
 }
@@ -781,7 +784,7 @@ int launch(const evp_gemm_desc *d, hipStream_t s) {
   p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = d->strideC0; p.sC1 = d->strideC1;
   p.batch1 = d->batch1 > 0 ? d->batch1 : 1;
   p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
-  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = g_gemm_dbg; p.dbgbuf = g_gemm_dbgbuf;
+  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = g_gemm_dbg; p.dbgbuf = g_gemm_dbgbuf; p.colsum = nullptr; p.colsum_acc = 0;
   p.tiles_m = (d->M + BM - 1) / BM;
   const int tiles_n = (d->N + BN - 1) / BN;
   const int nb = (d->batch0 > 0 ? d->batch0 : 1) * p.batch1;
@@ -918,6 +921,11 @@ __device__ __forceinline__ void gemm256_body(const GemmParams &p, const int tile
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8 af[4][2], bq0[2][2], bq1[2][2];
+  // bias gradient riding on the weight-gradient GEMM: colsum[m] = sum_k A[k][m]. The A fragments of the wc == 0 waves of
+  // the tile_n == 0 workgroups already hold every A value once; v_dot2c_f32_bf16 against (1, 1) adds a fragment's 8 k values
+  // in 4 VALU instructions that issue in the shadow of the MFMAs.
+  const bool do_colsum = p.colsum != nullptr && tile_n == 0 && wc == 0;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   const int last = 4 * nk - 1;              // index of the last half-tile
   constexpr int AHEAD = 5;                  // half-tile s is issued in global phase s - AHEAD
@@ -973,6 +981,26 @@ __device__ __forceinline__ void gemm256_body(const GemmParams &p, const int tile
         for (int jj = 0; jj < 2; ++jj)
           acc[mh * 4 + ii][nh * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nh ? bq1[jj][ks] : bq0[jj][ks], af[ii][ks],
                                                                                   acc[mh * 4 + ii][nh * 2 + jj], 0, 0, 0);
+    if constexpr (P == 0 || P == 2) {         // the phases that loaded a new A half
+      if (do_colsum) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        const bf16x2 ones = __builtin_bit_cast(bf16x2, 0x3F803F80u);
+        // (pairs taken with shufflevector: bit-casting the fragment to 4 dwords and indexing them made hipcc 7.2 feed
+        // dword 0 to all four dot instructions)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 f = af[ii][ks];
+            float c = csum[mh * 4 + ii];
+            c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), ones, c, false);
+            c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), ones, c, false);
+            c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), ones, c, false);
+            c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), ones, c, false);
+            csum[mh * 4 + ii] = c;
+          }
+      }
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -988,6 +1016,16 @@ __device__ __forceinline__ void gemm256_body(const GemmParams &p, const int tile
 
   const int64_t coff = b0 * p.sC0 + b1 * p.sC1;
   epilogue<TC, EPI, 8, 4>(acc, p, coff, m0 + wr * 128 + (lane & 15), n0 + wc * 64 + (lane >> 4) * 4, true);
+  if (do_colsum) {                              // lane (li, g) holds the k-group-g part of row li: fold the four groups
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) {
+      float v = csum[rt];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int m = m0 + wr * 128 + rt * 16 + (lane & 15);
+      if ((lane >> 4) == 0 && m < p.M) p.colsum[m] = p.colsum_acc ? p.colsum[m] + v : v;
+    }
+  }
 }
 
 template <typename TC, int EPI, bool TA, bool TB>
@@ -1007,8 +1045,9 @@ __global__ __launch_bounds__(512) void gemm256_grouped_tn_kernel(const GroupedPr
   p.B = g.B; p.ldb = g.ldb; p.sB0 = 0; p.sB1 = 0;
   p.C = g.C; p.c_dtype = EVP_F32; p.ldc = g.ldc; p.sC0 = 0; p.sC1 = 0;
   p.batch1 = 1; p.alpha = 1.0f; p.bias = nullptr; p.act = EVP_ACT_NONE; p.aux = nullptr; p.ldaux = 0;
-  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1; p.dbg = 0; p.dbgbuf = nullptr;
+  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1; p.dbg = 0; p.dbgbuf = nullptr; p.colsum = nullptr; p.colsum_acc = 0;
   p.k_per_split = g.K;
+  p.colsum = g.colsum; p.colsum_acc = g.colsum_accumulate;
   gemm256_body<float, 0, true, true>(p, it.tile_m, it.tile_n, 0);
 }
 
@@ -1020,7 +1059,7 @@ template <typename TC, int EPI, bool TA, bool TB> int launch256(const evp_gemm_d
   p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = d->strideC0; p.sC1 = d->strideC1;
   p.batch1 = d->batch1 > 0 ? d->batch1 : 1;
   p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
-  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = g_gemm_dbg; p.dbgbuf = g_gemm_dbgbuf;
+  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = g_gemm_dbg; p.dbgbuf = g_gemm_dbgbuf; p.colsum = nullptr; p.colsum_acc = 0;
   p.tiles_m = (d->M + 255) / 256;
   p.splitk = 1; p.k_per_split = d->K;
   const int tiles_n = (d->N + 255) / 256;
@@ -1171,7 +1210,7 @@ template <typename TC, int EPI, bool TA, bool TB> int launch_persist(const evp_g
   p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = 0; p.sC1 = 0;
   p.batch1 = 1;
   p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
-  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = g_gemm_dbg; p.dbgbuf = g_gemm_dbgbuf;
+  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = g_gemm_dbg; p.dbgbuf = g_gemm_dbgbuf; p.colsum = nullptr; p.colsum_acc = 0;
   p.tiles_m = (d->M + 127) / 128;
   p.splitk = 1; p.k_per_split = d->K;
   const int ntiles = p.tiles_m * ((d->N + 127) / 128);
@@ -1375,7 +1414,7 @@ template <typename TC, int EPI, bool TA, bool TB> int launch_persist2(const evp_
   p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = 0; p.sC1 = 0;
   p.batch1 = 1;
   p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
-  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = 0; p.dbg = 0; p.dbgbuf = nullptr;
+  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = 0; p.dbg = 0; p.dbgbuf = nullptr; p.colsum = nullptr; p.colsum_acc = 0;
   p.tiles_m = d->M / 128;
   p.splitk = 1; p.k_per_split = d->K;
   const int ntiles = p.tiles_m * (d->N / 128);

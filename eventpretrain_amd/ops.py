@@ -269,8 +269,8 @@ class _DeferredGrads:
         return (self.enabled and _compute_dtype == torch.bfloat16 and isinstance(param, torch.Tensor) and param.is_leaf
                 and param.requires_grad and param.dtype == torch.float32 and param.is_contiguous())
 
-    def wgrad(self, param, dy, x, n_out, k_in, rows):
-        self.w.append((param, dy, x, n_out, k_in, rows))
+    def wgrad(self, param, dy, x, n_out, k_in, rows, bias_param=None):
+        self.w.append((param, dy, x, n_out, k_in, rows, bias_param))
         self.arm()
 
     def colsum(self, param, x2d):
@@ -314,7 +314,16 @@ class _DeferredGrads:
         w, b, self.w, self.b = self.w, self.b, [], []
         if w:
             dev = w[0][1].device
-            fresh = [p_ for p_ in dict.fromkeys(t_[0] for t_ in w) if p_.grad is None]
+
+            def big_(it):       # long-K problems with >= 256-wide outputs go to the 256x256 ring kernel
+                return _use_wgrad256 and it[5] % 64 == 0 and it[3] >= 256 and it[4] >= 256
+            # a bias gradient rides on its Linear's weight-gradient problem only in the 256x256 kernel; otherwise it joins
+            # the grouped column sums below
+            for it in w:
+                if it[6] is not None and not big_(it):
+                    b.append((it[6], it[1]))
+            fused_bias = [it[6] for it in w if it[6] is not None and big_(it)]
+            fresh = [p_ for p_ in dict.fromkeys([t_[0] for t_ in w] + fused_bias) if p_.grad is None]
             if fresh:
                 sizes = [(p_.numel() + 63) // 64 * 64 for p_ in fresh]
                 flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
@@ -335,23 +344,29 @@ class _DeferredGrads:
                 rounds[r].append(item)
             fresh_ids = {id(p_) for p_ in fresh}
             pdt = np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("lda", "<i4"),
-                            ("ldb", "<i4"), ("ldc", "<i4"), ("acc", "<i4"), ("pad", "<i4")])
+                            ("ldb", "<i4"), ("ldc", "<i4"), ("acc", "<i4"), ("cacc", "<i4"), ("colsum", "<u8")])
             for r, batch in enumerate(rounds):
-                # long-K problems with >= 256-wide outputs go to the 256x256 ring kernel (one launch), the rest to the
-                # 128x128 kernel (one launch); inside a launch the longest-K tiles are listed first
-                big = [it for it in batch if _use_wgrad256 and it[5] % 64 == 0 and it[3] >= 256 and it[4] >= 256]
-                small = [it for it in batch if not (_use_wgrad256 and it[5] % 64 == 0 and it[3] >= 256 and it[4] >= 256)]
+                # one launch of the 256x256 ring kernel and one of the 128x128 kernel per round; inside a launch the
+                # longest-K tiles are listed first
+                big = [it for it in batch if big_(it)]
+                small = [it for it in batch if not big_(it)]
                 for tag, part, T_, entry in (("w256", big, 256, "evp_gemm_grouped_tn256_bf16"), ("w128", small, 128, "evp_gemm_grouped_tn_bf16")):
                     if not part:
                         continue
                     part = sorted(part, key=lambda it: -it[5])
                     probs = np.zeros(len(part), dtype=pdt)
                     items = []
-                    for i, (param, dy, x, n_out, k_in, rows) in enumerate(part):
+                    for i, (param, dy, x, n_out, k_in, rows, bias_param) in enumerate(part):
                         gt, acc = self._target(param)
                         if r == 0 and id(param) in fresh_ids:
                             acc = 0                  # first write into the freshly allocated flat slice
-                        probs[i] = (dy.data_ptr(), x.data_ptr(), gt.data_ptr(), n_out, k_in, rows, n_out, k_in, k_in, acc, 0)
+                        cs_ptr, cs_acc = 0, 0
+                        if bias_param is not None and T_ == 256:
+                            bt, cs_acc = self._target(bias_param)
+                            if r == 0 and id(bias_param) in fresh_ids:
+                                cs_acc = 0
+                            cs_ptr = bt.data_ptr()
+                        probs[i] = (dy.data_ptr(), x.data_ptr(), gt.data_ptr(), n_out, k_in, rows, n_out, k_in, k_in, acc, cs_acc, cs_ptr)
                         tm, tn = (n_out + T_ - 1) // T_, (k_in + T_ - 1) // T_
                         t = np.zeros((tn, tm, 4), dtype=np.int32)
                         t[..., 0] = i
@@ -420,15 +435,33 @@ def take_deferred_flat_buffers():
     return out
 
 
-def _wgrad(dy, x, n_out, k_in, rows, param=None, shape=None):
+def _wgrad(dy, x, n_out, k_in, rows, param=None, shape=None, bias_param=None):
     """dW[n_out,k_in] = dy^T x (f32). Returns the gradient, or None when it was queued for the grouped launch
-    (then flush() delivers it into param.grad)."""
+    (then flush() delivers it into param.grad). `bias_param`: the same Linear's bias, whose gradient sum_rows(dy) is
+    then produced by the same grouped kernel (or the grouped column sums) -- only pass it when this call is queued
+    (see _wgrad_bias)."""
     if param is not None and dy.dtype == torch.bfloat16 and n_out % 8 == 0 and k_in % 8 == 0 and _deferred.can_defer(param):
-        _deferred.wgrad(param, dy, x, n_out, k_in, rows)
+        _deferred.wgrad(param, dy, x, n_out, k_in, rows, bias_param)
         return None
     dw = torch.empty(n_out, k_in, dtype=torch.float32, device=dy.device)
     gemm(dy, x, dw, M=n_out, N=k_in, K=rows, trans_a=True, trans_b=True, lda=n_out, ldb=k_in)
     return dw if shape is None else dw.view(shape)
+
+
+def _wgrad_bias(dy, x, n_out, k_in, rows, wparam, bparam, need_w, need_b, dy_f32=None, shape=None):
+    """(dW, db) of one Linear. When both can be deferred (bf16 mode, leaf parameters) the bias gradient is attached to the
+    weight-gradient problem: the 256x256 grouped kernel sums dy's columns from the A fragments it holds anyway, so dy is
+    not read a second time. Otherwise falls back to the separate paths (`dy_f32`: f32 version of dy for the exact sum)."""
+    # only where dy exists in bf16 alone (qkv, fc1): proj / fc2 have the f32 residual-stream gradient, whose exact column
+    # sum is kept (summing its bf16 copy moved those bias gradients by ~5e-3 of their max)
+    fuse = (need_w and need_b and dy_f32 is None and dy.dtype == torch.bfloat16 and n_out % 8 == 0 and k_in % 8 == 0 and
+            _deferred.can_defer(wparam) and _deferred.can_defer(bparam))
+    if fuse:
+        _deferred.wgrad(wparam, dy, x, n_out, k_in, rows, bparam)
+        return None, None
+    dw = _wgrad(dy, x, n_out, k_in, rows, wparam, shape) if need_w else None
+    db = _bgrad(dy_f32 if dy_f32 is not None else dy, bparam) if need_b else None
+    return dw, db
 
 
 def _bgrad(x2d, param=None):
@@ -497,28 +530,24 @@ class ViTBlockFn(torch.autograd.Function):
         qkvw_, qkvb_, pw_, pb_, f1w_, f1b_, f2w_, f2b_ = ctx.prm
         need = ctx.needs_input_grad
         # MLP
-        db2 = _bgrad(g2, f2b_) if need[12] else None
-        dw2 = _wgrad(g2_lp, h_act, D, Hd, M, f2w_) if need[11] else None
+        dw2, db2 = _wgrad_bias(g2_lp, h_act, D, Hd, M, f2w_, f2b_, need[11], need[12], dy_f32=g2)
         dh_pre = torch.empty(M, Hd, dtype=T, device=dev)
         gemm(g2_lp, w2, dh_pre, M=M, N=Hd, K=D, trans_b=True, ldb=Hd, act=ACT_DGELU, aux=h_pre)
-        db1 = _bgrad(dh_pre, f1b_) if need[10] else None
-        dw1 = _wgrad(dh_pre, ln2, Hd, D, M, f1w_) if need[9] else None
+        dw1, db1 = _wgrad_bias(dh_pre, ln2, Hd, D, M, f1w_, f1b_, need[9], need[10])
         dln2 = torch.empty(M, D, dtype=T, device=dev)
         gemm(dh_pre, w1, dln2, M=M, N=D, K=Hd, trans_b=True, ldb=D)
         g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf, params=ctx.nprm[2:])
         if not bf:
             g1_lp = g1
         # attention
-        dbp = _bgrad(g1, pb_) if need[6] else None
-        dwp = _wgrad(g1_lp, att, D, D, M, pw_) if need[5] else None
+        dwp, dbp = _wgrad_bias(g1_lp, att, D, D, M, pw_, pb_, need[5], need[6], dy_f32=g1)
         datt = torch.empty(M, D, dtype=T, device=dev)
         gemm(g1_lp, wp, datt, M=M, N=D, K=D, trans_b=True, ldb=D)
         if ctx.fused:
             dqkv = attention_fused_bwd(qkv, att, datt, stat, B, N, heads, dh)
         else:
             dqkv = attention_bwd(qkv, stat, datt, B, N, heads, dh)
-        dbq = _bgrad(dqkv, qkvb_) if need[4] else None
-        dwq = _wgrad(dqkv, ln1, 3 * D, D, M, qkvw_) if need[3] else None
+        dwq, dbq = _wgrad_bias(dqkv, ln1, 3 * D, D, M, qkvw_, qkvb_, need[3], need[4])
         dln1 = torch.empty(M, D, dtype=T, device=dev)
         gemm(dqkv, wq, dln1, M=M, N=D, K=3 * D, trans_b=True, ldb=D)
         g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1, params=ctx.nprm[:2])

@@ -98,12 +98,14 @@ int evp_gemm(const evp_gemm_desc *d, void *stream);
 /* Grouped weight-gradient GEMM: n problems C_g[M_g,N_g] (f32) = A_g^T . B_g, A_g stored [K_g][M_g] and B_g stored
  * [K_g][N_g] (bf16), in ONE launch -- the deferred dW = dY^T . X of every Linear of the step (autograd backward of
  * vit_block.py:133,141,226,230 etc.). `problems` is a device array of
- *   struct { const void *A, *B; void *C; int M, N, K; int lda, ldb, ldc; int accumulate, pad; }   (56 bytes each;
- *   accumulate != 0: C_g += ...)
+ *   struct { const void *A, *B; void *C; int M, N, K; int lda, ldb, ldc; int accumulate, colsum_accumulate;
+ *            float *colsum; }   (64 bytes each; accumulate != 0: C_g += ...; colsum: see the 256x256 entry, NULL here)
  * and `items` a device array of  struct { int prob, tile_m, tile_n, pad; }  listing every 128x128 output tile. */
 int evp_gemm_grouped_tn_bf16(const void *problems, const void *items, int n_items, void *stream);
 /* Same problem table, but `items` lists 256x256 output tiles and every K_g must be a multiple of 64: the 8-wave
- * half-tile-ring kernel (one workgroup per CU), the faster form when K_g is long (K_g = batch x tokens here). */
+ * half-tile-ring kernel (one workgroup per CU), the faster form when K_g is long (K_g = batch x tokens here).
+ * A non-NULL `colsum` (float32 [M_g]) also receives colsum[m] (+)= sum_k A_g[k][m] -- the bias gradient db = sum over
+ * rows of dY of the same Linear -- computed from the A fragments already in registers (no second pass over dY). */
 int evp_gemm_grouped_tn256_bf16(const void *problems, const void *items, int n_items, void *stream);
 /* Tuning switch for A/B measurements: 1 = LDS-DMA (buffer_load ... lds) staging for bf16 (default), 2 = register
  * staging. Returns the previous value; any other argument only queries. Results are identical. */

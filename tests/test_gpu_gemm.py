@@ -182,3 +182,38 @@ def test_argument_errors_raise():
         ops.gemm(a, a, torch.zeros(8, 8).cuda(), M=8, N=8, K=12, trans_a=True)     # (1,0) layout not built
     with pytest.raises(EvpError):
         ops.gemm(a.cpu(), a.cpu(), torch.zeros(8, 8), M=8, N=8, K=12)              # no CPU path
+
+
+def test_grouped_tn256_with_fused_column_sums_exact():
+    """evp_gemm_grouped_tn256_bf16: several dW = dY^T X problems in one launch of the 256x256 ring kernel, with the bias
+    gradient (column sums of dY) produced by the same kernel; small-integer data, so every result is exact. Covers ragged
+    M / N (not multiples of 256), accumulate into an existing dW / db, and a problem without column sums."""
+    import numpy as np
+    from eventpretrain_amd._lib import call, stream_ptr
+    g = torch.Generator(device="cuda").manual_seed(11)
+    specs = [(768, 512, 1280, True, False), (304, 264, 192, True, True), (256, 256, 64, False, False), (2304, 768, 6272, True, False)]
+    pdt = np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("lda", "<i4"),
+                    ("ldb", "<i4"), ("ldc", "<i4"), ("acc", "<i4"), ("cacc", "<i4"), ("colsum", "<u8")])
+    probs = np.zeros(len(specs), dtype=pdt)
+    keep, items = [], []
+    for i, (M, N, K, want_cs, acc) in enumerate(specs):
+        dy = torch.randint(-2, 3, (K, M), generator=g, device="cuda").bfloat16()
+        x = torch.randint(-2, 3, (K, N), generator=g, device="cuda").bfloat16()
+        dw = torch.full((M, N), 3.0, device="cuda")
+        db = torch.full((M,), 5.0, device="cuda")
+        keep.append((dy, x, dw, db, want_cs, acc))
+        probs[i] = (dy.data_ptr(), x.data_ptr(), dw.data_ptr(), M, N, K, M, N, N, int(acc), int(acc), db.data_ptr() if want_cs else 0)
+        for tn in range((N + 255) // 256):
+            for tm in range((M + 255) // 256):
+                items.append((i, tm, tn, 0))
+    pt = torch.from_numpy(probs.view(np.uint8)).cuda()
+    it = torch.tensor(items, dtype=torch.int32, device="cuda")
+    call("evp_gemm_grouped_tn256_bf16", pt.data_ptr(), it.data_ptr(), len(items), stream_ptr())
+    torch.cuda.synchronize()
+    for dy, x, dw, db, want_cs, acc in keep:
+        ref_w = dy.float().t() @ x.float() + (3.0 if acc else 0.0)
+        assert torch.equal(dw, ref_w)
+        if want_cs:
+            assert torch.equal(db, dy.float().sum(0) + (5.0 if acc else 0.0))
+        else:
+            assert torch.equal(db, torch.full_like(db, 5.0))
