@@ -171,11 +171,11 @@ extern "C" int evp_window_attention_fwd(const void *qkv, const float *table, con
   const dim3 grid((unsigned)(Bg * H));
   if (dtype == EVP_F32) {
     auto kfn = win_attn_fwd_kernel<float>;
-    if (smem > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(kfn, grid, dim3(WA_THREADS), smem, st, (const float *)qkv, table, rel, (float *)out, probs, nG, N, H, scale);
   } else {
     auto kfn = win_attn_fwd_kernel<bf16_t>;
-    if (smem > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(kfn, grid, dim3(WA_THREADS), smem, st, (const bf16_t *)qkv, table, rel, (bf16_t *)out, probs, nG, N, H, scale);
   }
   EVP_CHECK_LAUNCH("evp_window_attention_fwd");
@@ -195,12 +195,12 @@ extern "C" int evp_window_attention_bwd(const void *qkv, const float *table, con
   const dim3 grid((unsigned)(Bg * H));
   if (dtype == EVP_F32) {
     auto kfn = win_attn_bwd_kernel<float>;
-    if (smem > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(kfn, grid, dim3(WA_THREADS), smem, st, (const float *)qkv, table, rel, (const float *)out, (const float *)dout,
                        (float *)dqkv, dtable, nG, N, H, R, scale);
   } else {
     auto kfn = win_attn_bwd_kernel<bf16_t>;
-    if (smem > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(kfn, grid, dim3(WA_THREADS), smem, st, (const bf16_t *)qkv, table, rel, (const bf16_t *)out, (const bf16_t *)dout,
                        (bf16_t *)dqkv, dtable, nG, N, H, R, scale);
   }

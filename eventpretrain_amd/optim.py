@@ -124,6 +124,26 @@ class FusedAdamW(torch.optim.Optimizer):
         step = max(self._step, 1)
         T["n_hyper"][:] = (1.0 - b1 ** step, math.sqrt(1.0 - b2 ** step), self.grad_scale, 1.0)
 
+    # ------------------------------------------------------------------------------------------------ checkpoints
+    def state_dict(self):
+        """torch.optim.AdamW layout (step / exp_avg / exp_avg_sq per parameter), so checkpoints interchange with the
+        reference's optimizer (utils/misc.py:353-359). The kernel keeps ONE step counter; it is written into every
+        parameter's `step` entry here."""
+        for st in self.state.values():
+            if "exp_avg" in st:
+                st["step"] = torch.tensor(float(self._step))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        steps = [float(st["step"]) for st in self.state.values() if "step" in st]
+        self._step = int(max(steps)) if steps else 0
+        for st in self.state.values():           # the kernel wants contiguous f32 moments
+            for k in ("exp_avg", "exp_avg_sq"):
+                if k in st and (st[k].dtype != torch.float32 or not st[k].is_contiguous()):
+                    st[k] = st[k].float().contiguous()
+        self._tabs, self._sig = None, None       # the moments are new tensors: rebuild the pointer tables
+
     @torch.no_grad()
     def reset_state(self):
         """Zero the moments IN PLACE and restart the step counter (the captured graphs keep pointing at these buffers)."""

@@ -390,3 +390,55 @@ def test_trainer_with_graph_executor_matches_eager():
         assert lr0 == pytest.approx(lr1, rel=1e-6)
         assert l0 == pytest.approx(l1, rel=2e-3), (runs)
     assert runs[1][-1][0] < runs[1][0][0]
+
+
+def test_checkpoint_resume_continues_the_trajectory(tmp_path):
+    """save_model / load_model (reference dict layout, utils/misc.py:318-403) with FusedAdamW: 2 steps, save, fresh
+    objects, load, 2 more steps == 4 uninterrupted steps (weights, moments, step counter and bf16 shadows all resume)."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
+    from eventpretrain_amd.optim import FusedAdamW
+    from eventpretrain_amd.testing import det_fill_module_, det_normalish, det_uniform, make_args
+    from eventpretrain_amd.utils import lr_decay as lrd, misc
+    from eventpretrain_amd.utils.misc import NativeScalerWithGradNormCount
+
+    def fresh():
+        a = make_args(model_size="tiny", pr_phase="rec", patch_size=16, device="cuda", input_size=64, output_dir=str(tmp_path), rec_dir="rec")
+        a.lr = 2e-3
+        m = hub.pretrain_hub_model_tiny_patch16_64(a, emb_frames_dim=512, queue_length=1024, T=0.07)
+        det_fill_module_(m)
+        m = m.cuda().train()
+        opt = FusedAdamW(lrd.param_groups_lrd(a, m, a.weight_decay, layer_decay=1), lr=a.lr, betas=(0.9, 0.95))
+        return a, m, opt
+
+    def run(m, opt, steps):
+        out = []
+        for s in steps:
+            x = (det_normalish(f"train.voxels.{s}", (2, 5, 64, 64)) * 0.5).cuda()
+            y = det_normalish(f"train.sub_frame.{s}", (2, 1, 64, 64)).cuda()
+            noise = det_uniform(f"train.noise.{s}", (2, 16), 0.0, 1.0).cuda()
+            loss = m(x, y, is_rec=True, noise=noise)[0]
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            out.append(loss.item())
+        return out
+
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        a, m, opt = fresh()
+        ref = run(m, opt, range(4))
+        ref_sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        a, m, opt = fresh()
+        first = run(m, opt, range(2))
+        path = misc.save_model(a, 0, m, m, opt, NativeScalerWithGradNormCount())
+        a2, m2, opt2 = fresh()
+        a2.resume = str(path)
+        misc.load_model(a2, m2, opt2, NativeScalerWithGradNormCount())
+        assert a2.start_epoch == 1 and opt2._step == 2
+        second = run(m2, opt2, range(2, 4))
+    finally:
+        ops.set_compute_dtype(torch.float32)
+    assert first + second == pytest.approx(ref, rel=1e-6)
+    for k, v in m2.state_dict().items():
+        assert torch.allclose(v.float(), ref_sd[k].float(), rtol=1e-5, atol=1e-7), k
