@@ -1,0 +1,41 @@
+// GPU side of the loader's view augmentation: once K1 builds voxel grids in HBM, the crop /
+// nearest-resize / horizontal-flip / time-flip chain of dataset/augmentation/view_augment.py:84-95 is one gather per
+// output pixel. The random decisions (crop box, the two coins) are inputs -- the host draws them (reference-compatible
+// legacy stream or a counter-based Philox stream, eventpretrain_amd/dataset/augmentation/view_augment.py).
+// HBM-bound: 4 B read + 4 B written per output element; reads of a row are contiguous up to the resize stride.
+#include "evp_common.h"
+
+// params[b] = {x0, y0, w, h, hflip, tflip}
+__global__ __launch_bounds__(256) void view_augment_kernel(const float *__restrict__ in, const int32_t *__restrict__ params,
+                                                           float *__restrict__ out, int C, int Hin, int Win, int Hout, int Wout,
+                                                           int negate) {
+  const int b = blockIdx.z, y = blockIdx.y;
+  const int32_t *pr = params + (int64_t)b * 6;
+  const int x0 = pr[0], y0 = pr[1], w = pr[2], h = pr[3], hflip = pr[4], tflip = pr[5];
+  // F.interpolate(mode="nearest"): src = min(floorf(dst * (float)in / (float)out), in - 1), all in float32
+  const float sy = (float)h / (float)Hout, sx = (float)w / (float)Wout;
+  int ys = (int)floorf((float)y * sy);
+  ys = y0 + (ys < h - 1 ? ys : h - 1);
+  const float sgn = (tflip && negate) ? -1.0f : 1.0f;
+  for (int x = blockIdx.x * 256 + threadIdx.x; x < Wout; x += gridDim.x * 256) {
+    const int xr = hflip ? Wout - 1 - x : x;          // the flip acts on the resized view
+    int xs = (int)floorf((float)xr * sx);
+    xs = x0 + (xs < w - 1 ? xs : w - 1);
+    for (int c = 0; c < C; ++c) {
+      const int cs = tflip ? C - 1 - c : c;
+      out[(((int64_t)b * C + c) * Hout + y) * Wout + x] = sgn * in[(((int64_t)b * C + cs) * Hin + ys) * Win + xs];
+    }
+  }
+}
+
+extern "C" int evp_view_augment_f32(const float *in, const int32_t *params, float *out, int B, int C, int Hin, int Win, int Hout,
+                                    int Wout, int negate_on_time_flip, void *stream) {
+  EVP_CHECK_ARG(in && params && out, EVP_EINVAL, "evp_view_augment_f32: null pointer");
+  EVP_CHECK_ARG(B > 0 && C > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && B <= 65535 && Hout <= 65535, EVP_ESHAPE,
+                "evp_view_augment_f32: bad shape (B=%d C=%d %dx%d -> %dx%d)", B, C, Hin, Win, Hout, Wout);
+  const dim3 grid((unsigned)((Wout + 255) / 256), (unsigned)Hout, (unsigned)B);
+  hipLaunchKernelGGL(view_augment_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, params, out, C, Hin, Win, Hout, Wout,
+                     negate_on_time_flip);
+  EVP_CHECK_LAUNCH("evp_view_augment_f32");
+  return EVP_OK;
+}

@@ -1,0 +1,74 @@
+"""Voxel-grid view augmentation on the GPU (reference dataset/augmentation/view_augment.py:9-95: `view_crop` ->
+`view_resize(mode='nearest')` -> `view_horizontal_flip` -> `evg_time_flip`), batched: one kernel launch
+(evp_view_augment_f32) for B grids that K1 left in HBM.
+
+The reference draws its random decisions from the process-global legacy numpy stream inside each DataLoader worker.
+Here they are explicit, host-drawn int32 rows {x0, y0, w, h, hflip, tflip}:
+  * `draw_evg_params(rs, ...)`  -- the reference's exact call order on a `numpy.random.RandomState`, so
+    `RandomState(seed)` reproduces `evg_augment(..., seed=seed)` bit for bit (pinned by tests/golden/evg_augment.npz);
+  * `draw_evg_params_batch(seed, step, B, ...)` -- a counter-based stream (Philox keyed by (seed, step, sample)): the
+    decisions of a sample do not depend on worker scheduling or on how many draws other samples consumed.
+Event-level augmentations (erase / add correlated events, events_augment.py:29-57) stay on the host for now."""
+import math
+
+import numpy as np
+import torch
+
+from ... import _lib
+from ..._lib import call, ptr, stream_ptr
+
+
+def draw_evg_params(rs, H, W, crop_min=0.8, ratio=(3 / 4, 4 / 3)):
+    """Decisions of one evg_augment call, in the reference's draw order (view_augment.py:14-31,41,49)."""
+    x0, y0, w, h = 0, 0, W, H
+    area = W * H
+    for _ in range(10):
+        target_area = rs.uniform(crop_min, 1.0) * area
+        aspect = rs.uniform(W / H * ratio[0], W / H * ratio[1])
+        cw, ch = int(round(math.sqrt(target_area * aspect))), int(round(math.sqrt(target_area / aspect)))
+        if rs.randint(0, 10) < 5:
+            cw, ch = ch, cw
+        if cw < W and ch < H:
+            x0, y0, w, h = rs.randint(0, W - cw), rs.randint(0, H - ch), cw, ch
+            break
+    hflip = int(rs.random_sample() < 0.5)
+    tflip = int(rs.random_sample() < 0.5)
+    return x0, y0, w, h, hflip, tflip
+
+
+def draw_evg_params_batch(seed, step, B, H, W, crop_min=0.8, first_sample=0):
+    """int32 [B,6] rows for samples first_sample .. first_sample+B-1 of optimizer step `step`: sample i uses the Philox
+    stream keyed by (seed, step, i). Same distribution as the reference's (same accept / reject rule)."""
+    out = np.zeros((B, 6), dtype=np.int32)
+    for i in range(B):
+        g = np.random.Generator(np.random.Philox(key=[int(seed) & (2 ** 64 - 1), ((int(step) << 24) ^ (first_sample + i)) & (2 ** 64 - 1)]))
+
+        class _RS:            # the four draw kinds of the reference, on a Generator
+            uniform = staticmethod(lambda a, b: g.uniform(a, b))
+            randint = staticmethod(lambda a, b: int(g.integers(a, b)))
+            random_sample = staticmethod(lambda: g.random())
+        out[i] = draw_evg_params(_RS, H, W, crop_min)
+    return out
+
+
+def evg_augment_batch(voxels, params, size, negate=None, out=None):
+    """voxels float32 [B,C,H,W] on the GPU, params int32 [B,6] (host array or device tensor) -> float32
+    [B,C,size[0],size[1]]; negate=None applies the reference's rule (5- or 6-bin grids are negated on a time flip)."""
+    _lib.require_device()
+    if not voxels.is_cuda or voxels.dtype != torch.float32 or not voxels.is_contiguous():
+        raise _lib.EvpError("evg_augment_batch: voxels must be a contiguous float32 tensor in device memory")
+    B, C, H, W = voxels.shape
+    if not torch.is_tensor(params):
+        p = np.ascontiguousarray(params, dtype=np.int32).reshape(B, 6)
+        if ((p[:, 0] < 0) | (p[:, 1] < 0) | (p[:, 2] < 1) | (p[:, 3] < 1) | (p[:, 0] + p[:, 2] > W) | (p[:, 1] + p[:, 3] > H)).any():
+            raise ValueError("evg_augment_batch: crop box outside the view")
+        params = torch.from_numpy(p).to(voxels.device, non_blocking=True)
+    if params.dtype != torch.int32 or tuple(params.shape) != (B, 6) or not params.is_contiguous():
+        raise ValueError("evg_augment_batch: params must be int32 [B,6]")
+    Ho, Wo = int(size[0]), int(size[1])
+    if out is None:
+        out = torch.empty(B, C, Ho, Wo, dtype=torch.float32, device=voxels.device)
+    if negate is None:
+        negate = C in (5, 6)
+    call("evp_view_augment_f32", ptr(voxels), ptr(params), ptr(out), B, C, H, W, Ho, Wo, int(bool(negate)), stream_ptr())
+    return out

@@ -329,6 +329,15 @@ int evp_swin_fuse_gather_bwd_f32(const float *dA, const int32_t *coords, const i
 int evp_swin_group_windows(const int32_t *counts, int n_windows, int cap, int32_t *group_of_window,
                            int32_t *group_sizes, int32_t *n_groups);
 
+/* ------------------------------------------------------------------------------------------------ K22 view augmentation
+ * evg_augment of the loader (dataset/augmentation/view_augment.py:84-95) on voxel grids already in HBM: per sample a
+ * crop box, F.interpolate(mode="nearest") to Hout x Wout (source index min(floorf(dst * float(in)/float(out)), in-1)),
+ * horizontal flip of the resized view, time flip = reversed bin order and, when negate_on_time_flip (5/6-bin polarity
+ * grids, :51-52), negation. in float32 [B,C,Hin,Win]; params int32 [B,6] = {x0, y0, w, h, hflip, tflip} (the random
+ * decisions are the caller's: a box with 0 <= x0, x0 + w <= Win, 0 <= y0, y0 + h <= Hin); out float32 [B,C,Hout,Wout]. */
+int evp_view_augment_f32(const float *in, const int32_t *params, float *out, int B, int C, int Hin, int Win, int Hout,
+                         int Wout, int negate_on_time_flip, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,59 @@
+"""CPU restatement (numpy) of the voxel-grid view augmentation of the pre-training loader.
+
+TEST INFRASTRUCTURE ONLY (see oracle/model_oracle.py). Restates dataset/augmentation/view_augment.py:9-77
+(`view_crop` -> `view_resize(mode='nearest')` -> `view_horizontal_flip` -> `evg_time_flip`) split into
+  (1) the random DECISIONS, drawn from a legacy numpy stream in exactly the reference's call order, and
+  (2) the deterministic pixel transform given those decisions.
+Pinned by tests/golden/evg_augment.npz (outputs of the reference's own evg_augment under np.random.seed)."""
+import math
+
+import numpy as np
+
+
+def draw_evg_params(rs, H, W, crop_min=0.8, ratio=(3 / 4, 4 / 3)):
+    """The decisions of evg_augment (view_augment.py:84-95) from a numpy RandomState `rs`:
+    up to 10 crop attempts (uniform area scale, uniform aspect ratio, a coin that swaps width/height, then the two
+    start offsets; view_augment.py:14-31), a horizontal-flip coin (:41) and a time-flip coin (:49).
+    Returns (x0, y0, w, h, hflip, tflip); no accepted attempt = the full view."""
+    x0, y0, w, h = 0, 0, W, H
+    area = W * H
+    for _ in range(10):
+        target = rs.uniform(crop_min, 1.0) * area
+        aspect = rs.uniform(W / H * ratio[0], W / H * ratio[1])
+        cw = int(round(math.sqrt(target * aspect)))
+        ch = int(round(math.sqrt(target / aspect)))
+        if rs.randint(0, 10) < 5:
+            cw, ch = ch, cw
+        if cw < W and ch < H:
+            x0 = rs.randint(0, W - cw)
+            y0 = rs.randint(0, H - ch)
+            w, h = cw, ch
+            break
+    hflip = int(rs.random_sample() < 0.5)
+    tflip = int(rs.random_sample() < 0.5)
+    return x0, y0, w, h, hflip, tflip
+
+
+def nearest_index(n_out, n_in):
+    """Source index of F.interpolate(mode='nearest'): min(floor(dst * float32(n_in / n_out)), n_in - 1), the scale and the
+    product in float32 as ATen computes them."""
+    scale = np.float32(n_in) / np.float32(n_out)
+    idx = np.floor(np.arange(n_out, dtype=np.float32) * scale).astype(np.int64)
+    return np.minimum(idx, n_in - 1)
+
+
+def evg_transform(view, params, out_hw, negate=True):
+    """view float32 [C,H,W] -> [C,Ho,Wo]: crop box, nearest resize, horizontal flip, time flip (reversed bin order and,
+    for 5/6-bin polarity grids, negated; view_augment.py:47-53)."""
+    x0, y0, w, h, hflip, tflip = params
+    Ho, Wo = out_hw
+    ys = y0 + nearest_index(Ho, h)
+    xs = x0 + nearest_index(Wo, w)
+    if hflip:
+        xs = xs[::-1]
+    out = view[:, ys][:, :, xs]
+    if tflip:
+        out = out[::-1]
+        if negate:
+            out = -out
+    return np.ascontiguousarray(out, dtype=np.float32)

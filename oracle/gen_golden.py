@@ -14,7 +14,7 @@ module object supplying `to_2tuple`, `trunc_normal_` and a `DropPath` that is
 never executed (all drop rates are 0 -> nn.Identity, vit_block.py:241) is put
 in sys.modules for the duration of this script.
 
-Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin,swincon]
+Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin,swincon,augment]
 """
 import argparse
 import json
@@ -522,8 +522,33 @@ def gen_swincon():
     save("con_swin_tiny_queue", **out)
 
 
+def gen_augment():
+    """evg_augment of the reference itself (dataset/augmentation/view_augment.py:84-95) under np.random.seed(seed), for
+    sensor-shaped and input-shaped grids; the fixture keeps inputs' generator seeds, outputs and time-flip flags."""
+    _ref()
+    from dataset.augmentation.view_augment import evg_augment
+    a = make_args(crop_min=0.8)
+    out = {}
+    cases = [("a", 11, (5, 224, 224), (224, 224)), ("b", 12, (5, 224, 224), (224, 224)), ("c", 13, (5, 120, 160), (224, 224)),
+             ("d", 14, (5, 64, 64), (64, 64)), ("e", 15, (5, 224, 224), (224, 224)), ("f", 16, (3, 96, 128), (64, 64))]
+    for tag, seed, shp, size in cases:
+        a.num_bins = shp[0]
+        v = det_normalish(f"aug.view.{tag}", shp)
+        res, tflag = evg_augment(a, v.clone(), size=size, seed=seed)
+        out[f"{tag}_seed"], out[f"{tag}_shape"], out[f"{tag}_size"] = np.array(seed), np.array(shp), np.array(size)
+        out[f"{tag}_tflip"] = np.array(int(tflag))
+        res = res.contiguous()
+        if res.numel() <= 30000:
+            out[f"{tag}_out"] = res                              # small cases in full
+        else:
+            out[f"{tag}_checksums"] = checksums(res)             # large ones: checksums + every 7th pixel
+            out[f"{tag}_sample"] = res.flatten()[::7].clone()
+    out["tags"] = np.array(json.dumps([c[0] for c in cases]))
+    save("evg_augment", **out)
+
+
 GENS = dict(voxel=gen_voxel, pos=gen_pos, mask=gen_mask, tiny=lambda: gen_composed("tiny"), small=gen_small,
-            base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall, swin=gen_swin, swincon=gen_swincon)
+            base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall, swin=gen_swin, swincon=gen_swincon, augment=gen_augment)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -309,3 +309,22 @@ def test_con_swin_matches_reference():
         assert sd[n].grad.double().norm().item() == pytest.approx(gn, rel=3e-3, abs=1e-6), n
     assert_checksums(side["queue"], d["queue_after_checksums"], 1e-6)
     assert int(side["queue_ptr"]) == int(d["queue_ptr_after"][0])
+
+
+def test_evg_augment_matches_reference():
+    """View augmentation of the voxel grid (crop box, nearest resize, h-flip, time flip + negate): the oracle's decision
+    stream and pixel transform against the reference's own evg_augment under np.random.seed (bit-exact)."""
+    from oracle import augment_oracle as ao
+    from eventpretrain_amd.testing import det_normalish
+    d = load_golden("evg_augment")
+    for tag in jl(d["tags"]):
+        shp, size, seed = tuple(int(v) for v in d[f"{tag}_shape"]), tuple(int(v) for v in d[f"{tag}_size"]), int(d[f"{tag}_seed"])
+        v = det_normalish(f"aug.view.{tag}", shp).numpy()
+        prm = ao.draw_evg_params(np.random.RandomState(seed), shp[1], shp[2], 0.8)
+        assert prm[5] == int(d[f"{tag}_tflip"])
+        out = ao.evg_transform(v, prm, size, negate=shp[0] in (5, 6))
+        if f"{tag}_out" in d.files:
+            assert np.array_equal(out, d[f"{tag}_out"]), tag
+        else:
+            assert np.array_equal(out.reshape(-1)[::7], d[f"{tag}_sample"]), tag
+            assert_checksums(torch.from_numpy(out), d[f"{tag}_checksums"], 1e-12, tag)
