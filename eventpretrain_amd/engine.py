@@ -4,7 +4,8 @@ An eager step of this path is ~600 kernel launches from Python -- launch-bound a
 executor runs a few eager steps (allocator and autograd warm-up, on the capture stream), captures
 
     1 rank : [forward + backward + AdamW]                                               one graph
-    N ranks: [forward + backward] -> in-place RCCL all-reduce of the flat gradient buffers -> [AdamW]
+    N ranks: [forward + backward] -> weight-gradient GEMMs in chunks, each chunk's flat buffer all-reduced (RCCL, in
+             place) while the next chunk computes -> [AdamW]
 
 and from then on a step is: copy the batch into the static input buffers, draw the mask noise into its static buffer,
 stage the optimizer's per-step scalars (lr, bias corrections) into the pinned table the graph's own H2D node re-reads,
@@ -20,7 +21,7 @@ from . import ops
 
 class GraphedStep:
     def __init__(self, model, optimizer, forward, static_inputs, noise_shape=None, generator=None, reducer=None,
-                 use_graph=True, warmup=2):
+                 use_graph=True, warmup=2, wgrad_chunks=4):
         """forward(model, *static_inputs, noise) -> tuple whose first item is the loss. `static_inputs`: device tensors
         with the batch's shapes (overwritten by `step(...)` when new data is passed). `noise_shape`: (B, L) of the
         masking noise, or None when the model draws none (density masking, contrastive stage)."""
@@ -33,6 +34,7 @@ class GraphedStep:
         self.loss = None
         self.note = "eager"
         self.multi = reducer is not None
+        self.wgrad_chunks = int(wgrad_chunks)
         if use_graph:
             self._capture(max(2, warmup))
 
@@ -63,23 +65,28 @@ class GraphedStep:
         try:
             g1 = torch.cuda.CUDAGraph()
             # thread_local: RCCL's watchdog thread polls its events while this thread captures
-            with torch.cuda.graph(g1, stream=side, capture_error_mode="thread_local"):
-                out = self.forward(self.model, *self.inputs, self.noise)
-                out[0].backward()
-                if not self.multi:
-                    self.opt.refresh()
-                    self.opt.launch()
-                self.loss = out[0].detach()
-                del out
+            ops.hold_deferred_grads(self.multi)      # N ranks: the grouped weight-gradient launches stay out of the graph
+            try:
+                with torch.cuda.graph(g1, stream=side, capture_error_mode="thread_local"):
+                    out = self.forward(self.model, *self.inputs, self.noise)
+                    out[0].backward()
+                    if not self.multi:
+                        self.opt.refresh()
+                        self.opt.launch()
+                    self.loss = out[0].detach()
+                    del out
+            finally:
+                ops.hold_deferred_grads(False)
             self.graph, self.note = g1, "hip-graph"
             if self.multi:
-                self.plan = self.reducer.make_static_plan()        # freezes the (now static) gradient buffers
-                self.plan.run()
+                # chunked weight-gradient launches interleaved with their all-reduces (parallel.OverlappedPlan)
+                with torch.cuda.stream(side):
+                    self.plan = self.reducer.make_overlapped_plan(self.wgrad_chunks)
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, stream=side, capture_error_mode="thread_local"):
                     self.opt.refresh()
                     self.opt.launch()
-                self.graph2, self.note = g2, "hip-graph (fwd+bwd) + RCCL all-reduce + hip-graph (AdamW)"
+                self.graph2, self.note = g2, "hip-graph (fwd+bwd) + %d weight-gradient chunks overlapped with RCCL all-reduce + hip-graph (AdamW)" % self.wgrad_chunks
         except Exception as e:               # keep training; say what happened
             self.graph = self.graph2 = self.plan = None
             self.note = "eager (graph capture failed: %r)" % (e,)

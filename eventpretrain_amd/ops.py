@@ -252,6 +252,7 @@ class _DeferredGrads:
 
     def __init__(self):
         self.enabled = True
+        self.hold = False               # keep the queue at the end of backward (see build_plan)
         self.w, self.b = [], []
         self.armed = False
         self._pin = {}
@@ -309,9 +310,58 @@ class _DeferredGrads:
         return param.grad, 1
 
     def flush(self):
-        import numpy as np
+        """End-of-backward callback: launch everything that was queued (normal mode). While `hold` is set (the step
+        executor capturing the forward+backward graph of the data-parallel path) the queue is kept for build_plan()."""
         self.armed = False
+        if self.hold:
+            return
+        for st in self._build(n_chunks=1, static=False):
+            st.run()
+
+    def build_plan(self, n_chunks=4):
+        """Data-parallel graph mode: turn the queue left by a captured backward into a list of re-runnable launch steps
+        with STATIC device tables (the operands live in the graph's private pool, so their addresses repeat at every
+        replay). Weight-gradient problems are cut into `n_chunks` launches, each writing its own flat gradient buffer, so
+        the all-reduce of one chunk overlaps the next chunk's GEMMs (parallel.OverlappedPlan)."""
+        self.armed = False
+        return self._build(n_chunks=n_chunks, static=True)
+
+    class _Step:
+        def __init__(self, entry, pt, it, n_items, flats, zero, keep):
+            self.entry, self.pt, self.it, self.n_items = entry, pt, it, n_items
+            self.flats = flats          # flat gradient buffers complete once this step has run
+            self.zero = zero            # buffers that accumulate with atomics: cleared before every run
+            self.keep = keep            # operand tensors referenced by the tables
+
+        def run(self):
+            for z in self.zero:
+                z.zero_()
+            call(self.entry, self.pt.data_ptr(), self.it.data_ptr(), self.n_items, stream_ptr())
+
+    def _build(self, n_chunks, static):
+        import numpy as np
         w, b, self.w, self.b = self.w, self.b, [], []
+        steps = []
+
+        def table(key, arr, dev):
+            if static:
+                return torch.from_numpy(arr.copy()).to(dev)
+            return self._stage(key, arr, dev)
+
+        def alloc_fresh(params, dev, zeroed):
+            """one flat buffer for the parameters of this launch that have no gradient yet; returns (flat | None, ids)"""
+            fresh = [p_ for p_ in dict.fromkeys(params) if p_.grad is None]
+            if not fresh:
+                return None, set()
+            sizes = [(p_.numel() + 63) // 64 * 64 for p_ in fresh]
+            flat = (torch.zeros if zeroed else torch.empty)(sum(sizes), dtype=torch.float32, device=dev)
+            o = 0
+            for p_, n_ in zip(fresh, sizes):
+                p_.grad = flat[o:o + p_.numel()].view_as(p_)
+                o += n_
+            self.flat_buffers.append(flat)
+            return flat, {id(p_) for p_ in fresh}
+
         if w:
             dev = w[0][1].device
 
@@ -322,16 +372,6 @@ class _DeferredGrads:
             for it in w:
                 if it[6] is not None and not big_(it):
                     b.append((it[6], it[1]))
-            fused_bias = [it[6] for it in w if it[6] is not None and big_(it)]
-            fresh = [p_ for p_ in dict.fromkeys([t_[0] for t_ in w] + fused_bias) if p_.grad is None]
-            if fresh:
-                sizes = [(p_.numel() + 63) // 64 * 64 for p_ in fresh]
-                flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-                o = 0
-                for p_, n_ in zip(fresh, sizes):
-                    p_.grad = flat[o:o + p_.numel()].view_as(p_)
-                    o += n_
-                self.flat_buffers.append(flat)
             # A parameter used by several autograd nodes of one backward (rec+con: masked AND dense forward) has several
             # queued contributions. Tiles of different problems run concurrently, so contributions to the SAME gradient
             # go to successive launches (round r holds every parameter's r-th contribution; normally one round).
@@ -342,28 +382,37 @@ class _DeferredGrads:
                 while len(rounds) <= r:
                     rounds.append([])
                 rounds[r].append(item)
-            fresh_ids = {id(p_) for p_ in fresh}
             pdt = np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("lda", "<i4"),
                             ("ldb", "<i4"), ("ldc", "<i4"), ("acc", "<i4"), ("cacc", "<i4"), ("colsum", "<u8")])
             for r, batch in enumerate(rounds):
-                # one launch of the 256x256 ring kernel and one of the 128x128 kernel per round; inside a launch the
-                # longest-K tiles are listed first
-                big = [it for it in batch if big_(it)]
-                small = [it for it in batch if not big_(it)]
-                for tag, part, T_, entry in (("w256", big, 256, "evp_gemm_grouped_tn256_bf16"), ("w128", small, 128, "evp_gemm_grouped_tn_bf16")):
-                    if not part:
-                        continue
-                    part = sorted(part, key=lambda it: -it[5])
+                # per round: the 256x256 ring kernel (in n_chunks launches when a plan is built) and the 128x128 kernel;
+                # inside a launch the longest-K tiles are listed first
+                big = sorted([it for it in batch if big_(it)], key=lambda it: -it[5])
+                small = sorted([it for it in batch if not big_(it)], key=lambda it: -it[5])
+                groups = []
+                if big:
+                    k = max(1, min(n_chunks if r == 0 else 1, len(big)))
+                    work = np.cumsum([float(it[3]) * it[4] * it[5] for it in big])
+                    cuts = [0] + [int(np.searchsorted(work, work[-1] * (c + 1) / k, side="left")) + 1 for c in range(k - 1)] + [len(big)]
+                    cuts = sorted(set(min(max(c, 0), len(big)) for c in cuts))
+                    for c in range(len(cuts) - 1):
+                        if cuts[c + 1] > cuts[c]:
+                            groups.append(("w256r%dc%d" % (r, c), big[cuts[c]:cuts[c + 1]], 256, "evp_gemm_grouped_tn256_bf16"))
+                if small:
+                    groups.append(("w128r%d" % r, small, 128, "evp_gemm_grouped_tn_bf16"))
+                for tag, part, T_, entry in groups:
+                    flat, fresh_ids = alloc_fresh([it[0] for it in part] + [it[6] for it in part if it[6] is not None and T_ == 256],
+                                                  dev, zeroed=False)
                     probs = np.zeros(len(part), dtype=pdt)
                     items = []
                     for i, (param, dy, x, n_out, k_in, rows, bias_param) in enumerate(part):
                         gt, acc = self._target(param)
-                        if r == 0 and id(param) in fresh_ids:
+                        if id(param) in fresh_ids:
                             acc = 0                  # first write into the freshly allocated flat slice
                         cs_ptr, cs_acc = 0, 0
                         if bias_param is not None and T_ == 256:
                             bt, cs_acc = self._target(bias_param)
-                            if r == 0 and id(bias_param) in fresh_ids:
+                            if id(bias_param) in fresh_ids:
                                 cs_acc = 0
                             cs_ptr = bt.data_ptr()
                         probs[i] = (dy.data_ptr(), x.data_ptr(), gt.data_ptr(), n_out, k_in, rows, n_out, k_in, k_in, acc, cs_acc, cs_ptr)
@@ -374,24 +423,17 @@ class _DeferredGrads:
                         t[..., 2] = np.arange(tn, dtype=np.int32)[:, None]
                         items.append(t.reshape(-1, 4))
                     items = np.concatenate(items, 0)
-                    pt = self._stage("%sp%d" % (tag, r), probs.view(np.uint8), dev)
-                    it_ = self._stage("%si%d" % (tag, r), items.view(np.uint8).reshape(-1), dev)
-                    call(entry, pt.data_ptr(), it_.data_ptr(), int(items.shape[0]), stream_ptr())
+                    pt = table(tag + "p", probs.view(np.uint8), dev)
+                    it_ = table(tag + "i", items.view(np.uint8).reshape(-1), dev)
+                    steps.append(self._Step(entry, pt, it_, int(items.shape[0]), [flat] if flat is not None else [], [],
+                                            [(it[1], it[2]) for it in part]))
         if b:
             dev = b[0][1].device
             probs = np.zeros(len(b), dtype=np.dtype([("x", "<u8"), ("out", "<u8"), ("M", "<i8"), ("N", "<i4"), ("ld", "<i4"),
                                                       ("dtype", "<i4"), ("pad", "<i4")]))
             items = []
             # fresh bias gradients are slices of ONE flat buffer zeroed by one memset (they accumulate with atomics)
-            fresh = [p_ for p_ in dict.fromkeys(t_[0] for t_ in b) if p_.grad is None]
-            if fresh:
-                sizes = [(p_.numel() + 63) // 64 * 64 for p_ in fresh]
-                flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
-                o = 0
-                for p_, n_ in zip(fresh, sizes):
-                    p_.grad = flat[o:o + p_.numel()].view_as(p_)
-                    o += n_
-                self.flat_buffers.append(flat)
+            flat, _ = alloc_fresh([t_[0] for t_ in b], dev, zeroed=True)
             for i, (param, x2d) in enumerate(b):
                 M, N = x2d.shape
                 gt, acc = self._target(param)
@@ -403,9 +445,16 @@ class _DeferredGrads:
                 t[..., 2] = np.arange(rs, dtype=np.int32)[:, None]
                 items.append(t.reshape(-1, 4))
             items = np.concatenate(items, 0)
-            pt = self._stage("bp", probs.view(np.uint8), dev)
-            it = self._stage("bi", items.view(np.uint8).reshape(-1), dev)
-            call("evp_colsum_grouped", pt.data_ptr(), it.data_ptr(), int(items.shape[0]), stream_ptr())
+            pt = table("bp", probs.view(np.uint8), dev)
+            it = table("bi", items.view(np.uint8).reshape(-1), dev)
+            st = self._Step("evp_colsum_grouped", pt, it, int(items.shape[0]), [flat] if flat is not None else [],
+                            [flat] if (static and flat is not None) else [], [t_[1] for t_ in b])
+            # in a plan the short column-sum launch goes first: its all-reduce then hides under the first GEMM chunk
+            if static:
+                steps.insert(0, st)
+            else:
+                steps.append(st)
+        return steps
 
 
 _deferred = _DeferredGrads()
@@ -426,6 +475,15 @@ def set_deferred_grads(flag):
 def flush_deferred_grads():
     if _deferred.w or _deferred.b:
         _deferred.flush()
+
+
+def hold_deferred_grads(flag):
+    """While set, the end-of-backward callback leaves the queued gradient work in place (for build_deferred_plan)."""
+    _deferred.hold = bool(flag)
+
+
+def build_deferred_plan(n_chunks=4):
+    return _deferred.build_plan(n_chunks)
 
 
 def take_deferred_flat_buffers():

@@ -31,6 +31,33 @@ class _Plan:
             w.wait()                                  # stream wait, no host sync
 
 
+class OverlappedPlan:
+    """HIP-graph data-parallel step, gradient part: the deferred weight-gradient work was kept OUT of the captured
+    forward+backward graph and cut into chunks (ops.build_deferred_plan); run() launches chunk c and immediately issues the
+    asynchronous all-reduce of the flat buffer chunk c-... wrote, so RCCL (on its own stream, ordered after the chunk by
+    the event torch.distributed records at the call) moves chunk c over xGMI while chunk c+1's GEMMs run. Only the last
+    chunk's all-reduce is exposed. The small gradients autograd produced inside the graph go through the packed bucket
+    first."""
+
+    def __init__(self, steps, others, bucket, views, group):
+        self.steps, self.others, self.bucket, self.views, self.group = steps, others, bucket, views, group
+        self.srcs = [p.grad for p in others]
+        for p, v in zip(others, views):
+            p.grad = v
+
+    def run(self):
+        works = []
+        if self.others:
+            torch._foreach_copy_(self.views, self.srcs)
+            works.append(dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for st in self.steps:
+            st.run()
+            for f in st.flats:
+                works.append(dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in works:
+            w.wait()                                  # stream wait, no host sync
+
+
 class BucketedGradReducer:
     def __init__(self, params, bucket_mb=64.0, process_group=None):
         self.group = process_group
@@ -64,6 +91,21 @@ class BucketedGradReducer:
     def finish(self):
         """Eager mode: call after every backward. All-reduces (SUM) every gradient, waits on the current stream."""
         _Plan(*self._collect(), self.group).run()
+
+    def make_overlapped_plan(self, n_chunks=4):
+        """HIP-graph mode with overlap: call once after a forward+backward captured under ops.hold_deferred_grads(True)."""
+        from . import ops
+        steps = ops.build_deferred_plan(n_chunks)
+        flats = ops.take_deferred_flat_buffers()
+        spans = [(f.data_ptr(), f.data_ptr() + f.numel() * f.element_size()) for f in flats]
+        others = [p for p in self.params if p.grad is not None and not any(lo <= p.grad.data_ptr() < hi for lo, hi in spans)]
+        bucket = views = None
+        if others:
+            sizes = [(p.numel() + 63) // 64 * 64 for p in others]
+            bucket = torch.zeros(sum(sizes), dtype=torch.float32, device=others[0].device)
+            offs = [sum(sizes[:i]) for i in range(len(sizes))]
+            views = [bucket[o:o + p.numel()].view_as(p) for o, p in zip(offs, others)]
+        return OverlappedPlan(steps, others, bucket, views, self.group)
 
     def make_static_plan(self):
         """HIP-graph mode: call once after the captured backward; the returned plan's run() reduces the same buffers
