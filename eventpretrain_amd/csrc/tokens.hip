@@ -318,3 +318,47 @@ extern "C" int evp_transpose(const void *src, void *dst, int dtype, int64_t rows
   EVP_CHECK_LAUNCH("evp_transpose");
   return EVP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ token mean pool
+// Fine-tune classification head (model/finetune_cls/ft_cls_hub_model.py:136): emb_h.mean(dim=1) of f32 tokens
+// [B, N, D] -> [B, D], and its backward dx[b,n,:] = g[b,:] / N. One thread per (b, 4 columns); the N-loop reads
+// consecutive rows, so a wave reads 1 KiB-contiguous row segments. HBM-bound, 4 B per input element.
+__global__ __launch_bounds__(256) void token_mean_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ out, int N, int D4) {
+  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (c >= D4) return;
+  const float4 *p = x + (int64_t)b * N * D4 + c;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int n = 0; n < N; ++n) {
+    const float4 v = p[(int64_t)n * D4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const float inv = 1.0f / (float)N;
+  out[(int64_t)b * D4 + c] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+}
+__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float4 *__restrict__ g, float4 *__restrict__ dx, int64_t total, int N, int D4) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)(e % D4);
+  const int64_t b = e / ((int64_t)N * D4);
+  const float4 v = g[b * D4 + c];
+  const float inv = 1.0f / (float)N;
+  dx[e] = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+}
+
+extern "C" int evp_token_mean_fwd(const float *x, int B, int N, int D, float *out, void *stream) {
+  EVP_CHECK_ARG(x && out, EVP_EINVAL, "evp_token_mean_fwd: null pointer");
+  EVP_CHECK_ARG(B > 0 && B <= 65535 && N > 0 && D > 0 && D % 4 == 0, EVP_ESHAPE, "evp_token_mean_fwd: B=%d N=%d D=%d (D%%4==0)", B, N, D);
+  hipLaunchKernelGGL(token_mean_fwd_kernel, dim3((unsigned)((D / 4 + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                     (const float4 *)x, (float4 *)out, N, D / 4);
+  EVP_CHECK_LAUNCH("evp_token_mean_fwd");
+  return EVP_OK;
+}
+extern "C" int evp_token_mean_bwd(const float *g, int B, int N, int D, float *dx, void *stream) {
+  EVP_CHECK_ARG(g && dx, EVP_EINVAL, "evp_token_mean_bwd: null pointer");
+  EVP_CHECK_ARG(B > 0 && N > 0 && D > 0 && D % 4 == 0, EVP_ESHAPE, "evp_token_mean_bwd: B=%d N=%d D=%d (D%%4==0)", B, N, D);
+  const int64_t total = (int64_t)B * N * (D / 4);
+  hipLaunchKernelGGL(token_mean_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)g,
+                     (float4 *)dx, total, N, D / 4);
+  EVP_CHECK_LAUNCH("evp_token_mean_bwd");
+  return EVP_OK;
+}

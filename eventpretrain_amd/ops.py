@@ -692,38 +692,63 @@ class LayerNormFn(torch.autograd.Function):
 
 
 class LinearFn(torch.autograd.Function):
-    """nn.Linear on f32 tokens (f32 in / f32 out; operands rounded to the compute dtype for the MFMA)."""
+    """nn.Linear on f32 tokens (f32 in / f32 out; operands rounded to the compute dtype for the MFMA). An output width
+    that is not a multiple of 8 (a classification head with 10 or 101 classes) runs zero-padded to the next multiple --
+    the kernels' vector accesses want 16-byte-aligned rows -- and is sliced back."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         shp = x.shape
         K = shp[-1]
         N = w.shape[0]
+        Np = _pad8(N)
         x2d = _chk(x.detach().contiguous(), torch.float32).view(-1, K)
         M = x2d.shape[0]
         xl = cast(x2d, _compute_dtype)
         wl = lp_weight(w)
-        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-        gemm(xl, wl, y, M=M, N=N, K=K, bias=b)
+        bias = b
+        if Np != N:
+            wp = torch.zeros(Np, K, dtype=wl.dtype, device=wl.device)
+            wp[:N].copy_(wl)
+            wl = wp
+            if b is not None:
+                bias = torch.zeros(Np, dtype=torch.float32, device=wl.device)
+                bias[:N].copy_(b.detach())
+        y = torch.empty(M, Np, dtype=torch.float32, device=x.device)
+        gemm(xl, wl, y, M=M, N=Np, K=K, bias=bias)
         ctx.save_for_backward(xl, wl)
         ctx.has_bias = b is not None
         ctx.needs_dx = x.requires_grad
         ctx.prm = (w, b)
-        return y.view(*shp[:-1], N)
+        ctx.n_out = N
+        if Np != N:
+            y = y[:, :N]
+        return y.reshape(*shp[:-1], N)
 
     @staticmethod
     def backward(ctx, g):
         xl, wl = ctx.saved_tensors
         M, K = xl.shape
-        N = wl.shape[0]
+        N, Np = ctx.n_out, wl.shape[0]
         g2d = _chk(g.contiguous(), torch.float32).view(M, N)
+        if Np != N:
+            gp = torch.zeros(M, Np, dtype=torch.float32, device=g.device)
+            gp[:, :N].copy_(g2d)
+            g2d = gp
         gl = cast(g2d, xl.dtype)
-        dw = _wgrad(gl, xl, N, K, M, ctx.prm[0]) if ctx.needs_input_grad[1] else None
-        db = _bgrad(g2d, ctx.prm[1]) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dw = db = None
+        if Np == N:
+            dw = _wgrad(gl, xl, N, K, M, ctx.prm[0]) if ctx.needs_input_grad[1] else None
+            db = _bgrad(g2d, ctx.prm[1]) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        else:
+            if ctx.needs_input_grad[1]:
+                dw = _wgrad(gl, xl, Np, K, M)[:N].contiguous()
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = colsum(g2d)[:N].contiguous()
         dx = None
         if ctx.needs_dx:
             dx = torch.empty(M, K, dtype=torch.float32, device=g.device)
-            gemm(gl, wl, dx, M=M, N=K, K=N, trans_b=True, ldb=K)
+            gemm(gl, wl, dx, M=M, N=K, K=Np, trans_b=True, ldb=K)
             dx = dx.view(*g.shape[:-1], K)
         return dx, dw, db
 
@@ -1409,3 +1434,45 @@ class AddFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g, g
+
+
+# ----------------------------------------------------------------------------------------------------- fine-tune (cls) head
+class TokenMeanFn(torch.autograd.Function):
+    """emb_h.mean(dim=1) over the tokens (ft_cls_hub_model.py:136) on f32 [B,N,D]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, N, D = x.shape
+        out = torch.empty(B, D, dtype=torch.float32, device=x.device)
+        call("evp_token_mean_fwd", ptr(_chk(x.detach().contiguous(), torch.float32)), B, N, D, ptr(out), stream_ptr())
+        ctx.dims = (B, N, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, D = ctx.dims
+        dx = torch.empty(B, N, D, dtype=torch.float32, device=g.device)
+        call("evp_token_mean_bwd", ptr(_chk(g.contiguous(), torch.float32)), B, N, D, ptr(dx), stream_ptr())
+        return dx
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss()(pred, label) (mean reduction; ft_cls_trainer.py:66) on f32 logits [B, n_cls]."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        B, Cn = logits.shape
+        lg = _chk(logits.detach().contiguous(), torch.float32)
+        loss = torch.empty(1, dtype=torch.float32, device=lg.device)
+        dlog = torch.empty(B, Cn, dtype=torch.float32, device=lg.device)
+        ws = torch.empty(B, dtype=torch.float32, device=lg.device)
+        call("evp_cross_entropy", ptr(lg), ptr(_chk(labels.contiguous(), torch.int64)), B, Cn, Cn, ptr(loss), ptr(dlog), ptr(ws), stream_ptr())
+        ctx.save_for_backward(dlog)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlog,) = ctx.saved_tensors
+        out = dlog.clone()
+        call("evp_scale_f32", ptr(out), ptr(_chk(g.contiguous().view(1), torch.float32)), out.numel(), stream_ptr())
+        return out, None

@@ -101,9 +101,12 @@ class MetricLogger:
     def log_every(self, args, iterable, print_freq, header=None):
         """Yields each batch dict as the tuple the phase's trainer unpacks (reference utils/misc.py:144-167) and
         prints progress every print_freq iterations."""
-        if args.phase != "pretrain" or args.pr_phase not in _BATCH_KEYS:
+        if args.phase == "finetune_cls":
+            keys = ("events_voxel_grid", "label", "image_name")
+        elif args.phase == "pretrain" and args.pr_phase in _BATCH_KEYS:
+            keys = _BATCH_KEYS[args.pr_phase]
+        else:
             raise ValueError((args.phase, getattr(args, "pr_phase", None)))
-        keys = _BATCH_KEYS[args.pr_phase]
         header = header or ""
         n = len(iterable)
         start = end = time.time()

@@ -338,6 +338,13 @@ int evp_swin_group_windows(const int32_t *counts, int n_windows, int cap, int32_
 int evp_view_augment_f32(const float *in, const int32_t *params, float *out, int B, int C, int Hin, int Win, int Hout,
                          int Wout, int negate_on_time_flip, void *stream);
 
+/* ------------------------------------------------------------------------------------------------ K23 token mean pool
+ * Classification fine-tuning head (model/finetune_cls/ft_cls_hub_model.py:136): out[b,:] = mean_n x[b,n,:] for float32
+ * tokens [B,N,D] (D % 4 == 0), and dx[b,n,:] = g[b,:] / N. The head's Linear and cross-entropy are evp_gemm and
+ * evp_cross_entropy. */
+int evp_token_mean_fwd(const float *x, int B, int N, int D, float *out, void *stream);
+int evp_token_mean_bwd(const float *g, int B, int N, int D, float *dx, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ module object supplying `to_2tuple`, `trunc_normal_` and a `DropPath` that is
 never executed (all drop rates are 0 -> nn.Identity, vit_block.py:241) is put
 in sys.modules for the duration of this script.
 
-Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin,swincon,augment]
+Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin,swincon,augment,ftcls]
 """
 import argparse
 import json
@@ -547,8 +547,38 @@ def gen_augment():
     save("evg_augment", **out)
 
 
+def gen_ftcls():
+    """Classification fine-tuning step (model/finetune_cls/ft_cls_hub_model.py:118-139 + nn.CrossEntropyLoss,
+    trainer/finetune_cls/ft_cls_trainer.py:66) on the ViT-Small and Swin-T hubs, B=2, 10 classes."""
+    _ref()
+    from model.finetune_cls.ft_cls_hub_model import finetune_cls_hub_model_small_patch16, finetune_cls_hub_model_swin_tiny_window7
+    for tag, fac, bt in (("vit_small", finetune_cls_hub_model_small_patch16, "vit"), ("swin_tiny", finetune_cls_hub_model_swin_tiny_window7, "swin")):
+        a = make_args(phase="finetune_cls", model_size="small" if bt == "vit" else "tiny", backbone_type=bt, num_classes=10, mask_ratio=0.0)
+        hub = fac(a)
+        det_fill_module_(hub)
+        hub.train(True)
+        x = det_normalish("ft.voxels", (2, 5, 224, 224)) * 0.5
+        label = torch.tensor([3, 7])
+        res = hub(x)
+        pred, emb_h = res[-2], res[-3]
+        loss = torch.nn.CrossEntropyLoss()(pred, label)
+        loss.backward()
+        out = dict(loss=loss.detach().double(), pred=pred.detach(), emb_h_checksums=checksums(emb_h), attn_checksums=checksums(res[-1]),
+                   label=label)
+        names, gn = [], []
+        for n, p in hub.named_parameters():
+            if p.grad is not None:
+                names.append(n)
+                gn.append(p.grad.double().norm().item())
+        out["grad_names"], out["grad_norms"] = np.array(json.dumps(names)), np.array(gn)
+        out["grad::classify_head.weight"] = hub.classify_head.weight.grad
+        out["grad::classify_head.bias"] = hub.classify_head.bias.grad
+        out["state_keys"] = np.array(json.dumps({k: list(v.shape) for k, v in hub.state_dict().items()}))
+        save("ft_cls_" + tag, **out)
+
+
 GENS = dict(voxel=gen_voxel, pos=gen_pos, mask=gen_mask, tiny=lambda: gen_composed("tiny"), small=gen_small,
-            base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall, swin=gen_swin, swincon=gen_swincon, augment=gen_augment)
+            base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall, swin=gen_swin, swincon=gen_swincon, augment=gen_augment, ftcls=gen_ftcls)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

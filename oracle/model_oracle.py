@@ -542,6 +542,18 @@ def swin_con_step(sd, x, clip_emb, cfg, training=True):
     return loss, emb_h_org, h, clip_org, clip_proj, attn, side
 
 
+# ----------------------------------------------------------------------------- model/finetune_cls/ft_cls_hub_model.py:118-139
+def ft_cls_step(sd, x, label, cfg):
+    """Dense backbone (vit.py:132-156 / swin.py:248-290) -> mean over tokens -> Linear head -> mean cross-entropy
+    (trainer/finetune_cls/ft_cls_trainer.py:66). Returns (loss, pred, emb_h, attn)."""
+    if cfg["backbone"] == "swin":
+        _, emb_h, attn = swin_dense(sd, x, cfg)
+    else:
+        _, _, emb_h, attn = vit_dense(sd, x, patch=cfg["patch"], heads=cfg["heads"])
+    pred = F.linear(emb_h.mean(dim=1), sd["classify_head.weight"], sd["classify_head.bias"])
+    return F.cross_entropy(pred, label), pred, emb_h, attn
+
+
 # ----------------------------------------------------------------------------- optimiser-side glue
 def cosine_lr(epoch, lr, min_lr, warmup_epochs, epochs):
     """utils/lr_sched.py:3-16."""

@@ -328,3 +328,42 @@ def test_evg_augment_matches_reference():
         else:
             assert np.array_equal(out.reshape(-1)[::7], d[f"{tag}_sample"]), tag
             assert_checksums(torch.from_numpy(out), d[f"{tag}_checksums"], 1e-12, tag)
+
+
+FT_CFG = {"vit_small": dict(backbone="vit", patch=16, heads=12),
+          "swin_tiny": dict(backbone="swin", input=224, window=7, depths=[2, 2, 6, 2], heads=[3, 6, 12, 24])}
+
+
+def ft_state_dict(d, grid=14):
+    from eventpretrain_amd.testing import det_value_for
+    sd = {}
+    for k, shp in jl(d["state_keys"]).items():
+        if k.endswith("relative_position_index"):
+            continue
+        if k.endswith("pos_embed"):
+            sd[k] = torch.from_numpy(mo.sincos_2d(shp[-1], grid)).float().unsqueeze(0)
+        else:
+            sd[k] = det_value_for(k, shp).requires_grad_(True)
+    return sd
+
+
+@pytest.mark.parametrize("tag", ["vit_small", "swin_tiny"])
+def test_ft_cls_matches_reference(tag):
+    """Classification fine-tuning step (dense backbone, token mean, Linear head, cross-entropy) through the oracle
+    against the reference's own FtClsHubModel outputs."""
+    from eventpretrain_amd.testing import det_normalish
+    d = load_golden("ft_cls_" + tag)
+    sd = ft_state_dict(d)
+    x = det_normalish("ft.voxels", (2, 5, 224, 224)) * 0.5
+    loss, pred, emb_h, attn = mo.ft_cls_step(sd, x, torch.from_numpy(d["label"]), FT_CFG[tag])
+    assert loss.item() == pytest.approx(float(d["loss"]), rel=5e-6)
+    assert torch.allclose(pred, torch.from_numpy(d["pred"]), atol=2e-5, rtol=1e-5)
+    assert_checksums(emb_h, d["emb_h_checksums"], 2e-5)
+    assert_checksums(attn, d["attn_checksums"], 2e-5)
+    loss.backward()
+    for n, gn in zip(jl(d["grad_names"]), d["grad_norms"]):
+        assert sd[n].grad is not None, n
+        assert sd[n].grad.double().norm().item() == pytest.approx(gn, rel=1e-3, abs=1e-7), n
+    for k in ("classify_head.weight", "classify_head.bias"):
+        ref = torch.from_numpy(d["grad::" + k])
+        assert torch.allclose(sd[k].grad, ref, atol=1e-6 + 1e-4 * ref.abs().max().item(), rtol=1e-4), k
