@@ -82,6 +82,7 @@ SIGNATURES = {
     "evp_scale_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp, _vp],
     "evp_infonce_queue": [_vp, _vp, _i64, _i, _i64, _f, _vp, _vp, _vp, _vp, _vp],
     "evp_enqueue_keys": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "evp_enqueue_keys_dev": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "evp_window_attention_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "evp_window_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "evp_gather_rows_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -116,6 +116,20 @@ __global__ __launch_bounds__(256) void enqueue_kernel(float *queue, const float 
   }
 }
 
+// the same with the write position read from (and advanced in) device memory: no host round trip, HIP-graph capturable
+__global__ __launch_bounds__(256) void enqueue_dev_kernel(float *queue, const float *keys, const int64_t *qptr, int B, int L, int C, int K) {
+  const int ptr = (int)(*qptr);
+  if (ptr < 0 || ptr + B > K) return;        // K % B == 0 is checked on the host; a corrupt pointer must not write out of range
+  const int64_t total = (int64_t)B * L * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)(i % B);
+    const int64_t t = i / B;
+    const int l = (int)(t % L), c = (int)(t / L);
+    queue[((int64_t)c * L + l) * K + ptr + b] = keys[((int64_t)b * L + l) * C + c];
+  }
+}
+__global__ void advance_ptr_kernel(int64_t *qptr, int B, int K) { *qptr = (*qptr + B) % K; }
+
 static inline int rows_grid(int64_t rows) {
   int64_t g = (rows + 3) / 4;
   if (g > 4096) g = 4096;
@@ -172,6 +186,17 @@ extern "C" int evp_infonce_queue(const float *pos, const float *neg, int64_t R, 
   EVP_CHECK_LAUNCH("evp_infonce_queue(mean)");
   return EVP_OK;
 }
+extern "C" int evp_enqueue_keys_dev(float *queue, const float *keys, int64_t *queue_ptr, int B, int L, int C, int K, void *stream) {
+  EVP_CHECK_ARG(queue && keys && queue_ptr, EVP_EINVAL, "evp_enqueue_keys_dev: null pointer");
+  EVP_CHECK_ARG(B > 0 && L > 0 && C > 0 && K > 0 && K % B == 0, EVP_ESHAPE, "evp_enqueue_keys_dev: queue length %d must be a multiple of the batch %d", K, B);
+  int64_t g = ((int64_t)B * L * C + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(enqueue_dev_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, queue, keys, queue_ptr, B, L, C, K);
+  EVP_CHECK_LAUNCH("evp_enqueue_keys_dev");
+  hipLaunchKernelGGL(advance_ptr_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, queue_ptr, B, K);
+  EVP_CHECK_LAUNCH("evp_enqueue_keys_dev(advance)");
+  return EVP_OK;
+}
+
 extern "C" int evp_enqueue_keys(float *queue, const float *keys, int ptr, int B, int L, int C, int K, void *stream) {
   EVP_CHECK_ARG(queue && keys, EVP_EINVAL, "evp_enqueue_keys: null pointer");
   EVP_CHECK_ARG(B > 0 && L > 0 && C > 0 && ptr >= 0 && ptr + B <= K, EVP_ESHAPE, "evp_enqueue_keys: ptr+B exceeds the queue length");

@@ -77,13 +77,12 @@ class PrHubModel(nn.Module):
     @torch.no_grad()
     def _dequeue_and_enqueue(self, keys):
         """queue[:, :, ptr:ptr+B] = keys^T with all three dims reversed ((B,L,C) -> (C,L,B)), pointer advances
-        modulo the queue length (pr_hub_model.py:112-122)."""
+        modulo the queue length (pr_hub_model.py:112-122). The pointer stays in its device buffer: the kernel reads it
+        and a one-thread kernel advances it, so the step has no host read-back (and can be captured in a HIP graph)."""
         B = keys.shape[0]
-        ptr_ = int(self.queue_ptr)
         if self.queue_length % B:
             raise AssertionError("queue_length must be a multiple of the batch size")
-        ops.enqueue_keys(self.queue, keys, ptr_)
-        self.queue_ptr[0] = (ptr_ + B) % self.queue_length
+        ops.enqueue_keys_dev(self.queue, keys, self.queue_ptr)
 
     def contrastive_loss_queue(self, emb_h, clip_emb):
         loss, k = ops.info_nce_queue(emb_h, clip_emb, self.queue, self.T)

@@ -1029,6 +1029,13 @@ def enqueue_keys(queue, keys, ptr_):
          queue.shape[2], stream_ptr())
 
 
+def enqueue_keys_dev(queue, keys, queue_ptr):
+    """_dequeue_and_enqueue with the pointer kept on the device (queue_ptr: int64 [1] buffer): no host sync."""
+    B, L, C_ = keys.shape
+    call("evp_enqueue_keys_dev", ptr(_chk(queue, torch.float32)), ptr(_chk(keys.contiguous(), torch.float32)),
+         ptr(_chk(queue_ptr, torch.int64)), B, L, C_, queue.shape[2], stream_ptr())
+
+
 # ----------------------------------------------------------------------------------------------------- ConvViT stages
 class PatchEmbedNHWCFn(torch.autograd.Function):
     """PatchEmbed (Conv2d k=s=p -> LayerNorm(eps 1e-5) -> GELU, vit_block.py:60-68) on a channels-last token map

@@ -289,6 +289,9 @@ int evp_infonce_queue(const float *pos, const float *neg, int64_t R, int K, int6
                       float *dpos, float *dneg, float *workspace, void *stream);
 /* _dequeue_and_enqueue (pr_hub_model.py:112-122): queue[c,l,ptr+b] = keys[b,l,c]; queue float32 [C,L,K]. */
 int evp_enqueue_keys(float *queue, const float *keys, int ptr, int B, int L, int C, int K, void *stream);
+/* The same with the pointer in device memory (the reference's `queue_ptr` buffer, int64 [1]): read by the kernel and
+ * advanced to (ptr + B) % K afterwards on the stream -- no host read-back, capturable in a HIP graph. K % B == 0. */
+int evp_enqueue_keys_dev(float *queue, const float *keys, int64_t *queue_ptr, int B, int L, int C, int K, void *stream);
 
 /* ------------------------------------------------------------------------------------------------ K17 Swin windows
  * Grouped window attention with the gathered relative-position bias, replacing WindowAttention.forward's core
