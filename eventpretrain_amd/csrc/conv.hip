@@ -58,118 +58,158 @@ __device__ __forceinline__ float keep_at(const float *mask, int b, int y, int x,
   return mask ? 1.0f - mask[(int64_t)b * L + (y / s) * gw + x / s] : 1.0f;
 }
 
-// y[b,y,x,c] = bias[c] + sum_{i,j} w[c,i,j] * keep(y+i-2,x+j-2) * in[b,y+i-2,x+j-2,c]
-// thread = 4 channels of one position (float4 / 8-byte loads); weights for its channels in registers
-template <typename T>
-__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T *in, const float *mask, const float *w, const float *bias, int B, int H,
-                                                         int W, int C, int ms, int mgw, int mL, T *out) {
-  const int C4 = C / 4;
-  const int64_t total = (int64_t)B * H * W * C4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % C4) * 4;
-    int64_t t = i / C4;
-    const int x = (int)(t % W); t /= W;
-    const int y = (int)(t % H);
-    const int b = (int)(t / H);
-    float acc[4] = {bias[c], bias[c + 1], bias[c + 2], bias[c + 3]};
-#pragma unroll
-    for (int ki = 0; ki < 5; ++ki) {
-      const int yy = y + ki - 2;
-      if (yy < 0 || yy >= H) continue;
-#pragma unroll
-      for (int kj = 0; kj < 5; ++kj) {
-        const int xx = x + kj - 2;
-        if (xx < 0 || xx >= W) continue;
-        const float k = keep_at(mask, b, yy, xx, ms, mgw, mL);
-        if (k == 0.f) continue;
-        const T *p = in + (((int64_t)b * H + yy) * W + xx) * C + c;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] += w[(c + e) * 25 + ki * 5 + kj] * (k * ldf<T>(p + e));
-      }
-    }
-    T *o = out + (((int64_t)b * H + y) * W + x) * C + c;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) ElemIO<T>::st(o + e, acc[e]);
-  }
+// Forward:  y[b,y,x,c]   = bias[c] + sum_{i,j} w[c,i,j] * keep(y+i-2,x+j-2) * in[b,y+i-2,x+j-2,c]
+// Backward: din[b,y,x,c] = keep(y,x) * sum_{i,j} w[c,i,j] * dout[b,y-i+2,x-j+2,c]     (the flipped kernel on dout)
+// One kernel for both: a wave walks an image row left to right with a 5x5 register window per channel (lane = 2
+// adjacent channels, 64 lanes = 128 channels = one contiguous 256-byte / 512-byte row segment), so a position costs
+// 5 loads + 1 store instead of 25 + 1. BWD: window elements are not masked, the result is; the taps are read flipped.
+template <typename T> __device__ __forceinline__ void ld2(const T *p, float &a, float &b);
+template <> __device__ __forceinline__ void ld2<float>(const float *p, float &a, float &b) {
+  const float2 v = *reinterpret_cast<const float2 *>(p);
+  a = v.x; b = v.y;
 }
-
-// din[b,y,x,c] = keep(y,x) * sum_{i,j} w[c,i,j] * dout[b,y-i+2,x-j+2,c]
-template <typename T>
-__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const T *dout, const float *mask, const float *w, int B, int H, int W, int C,
-                                                              int ms, int mgw, int mL, T *din) {
-  const int C4 = C / 4;
-  const int64_t total = (int64_t)B * H * W * C4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % C4) * 4;
-    int64_t t = i / C4;
-    const int x = (int)(t % W); t /= W;
-    const int y = (int)(t % H);
-    const int b = (int)(t / H);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const float k = keep_at(mask, b, y, x, ms, mgw, mL);
-    if (k != 0.f) {
+template <> __device__ __forceinline__ void ld2<bf16_t>(const bf16_t *p, float &a, float &b) {
+  const uint32_t u = *reinterpret_cast<const uint32_t *>(p);
+  a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xFFFF0000u);
+}
+template <typename T> __device__ __forceinline__ void st2(T *p, float a, float b);
+template <> __device__ __forceinline__ void st2<float>(float *p, float a, float b) { *reinterpret_cast<float2 *>(p) = make_float2(a, b); }
+template <> __device__ __forceinline__ void st2<bf16_t>(bf16_t *p, float a, float b) {
+  *reinterpret_cast<uint32_t *>(p) = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+}
+constexpr int DWF_RPW = 2;                    // rows per wave
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void dwconv_rows_kernel(const T *src, const float *mask, const float *w, const float *bias, int B, int H,
+                                                          int W, int C, int ms, int mgw, int mL, T *dst) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 128 + lane * 2;
+  if (c >= C) return;
+  const int nrows = B * H;
+  float k0[5][5], k1[5][5];                   // taps of the two channels (flipped for the backward)
+#pragma unroll
+  for (int ki = 0; ki < 5; ++ki)
+#pragma unroll
+    for (int kj = 0; kj < 5; ++kj) {
+      const int t = BWD ? (4 - ki) * 5 + (4 - kj) : ki * 5 + kj;
+      k0[ki][kj] = w[c * 25 + t];
+      k1[ki][kj] = w[(c + 1) * 25 + t];
+    }
+  const float b0 = BWD ? 0.f : bias[c], b1 = BWD ? 0.f : bias[c + 1];
+  const int r0 = (blockIdx.y * 4 + wave) * DWF_RPW;
+  for (int r = r0; r < r0 + DWF_RPW && r < nrows; ++r) {
+    const int b = r / H, y = r - b * H;
+    float w0[5][5], w1[5][5];
+    auto load_col = [&](int xx, int kj) {
 #pragma unroll
       for (int ki = 0; ki < 5; ++ki) {
-        const int yy = y - ki + 2;
-        if (yy < 0 || yy >= H) continue;
+        const int yy = y + ki - 2;
+        float a_ = 0.f, b_ = 0.f;
+        if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+          const float k = BWD ? 1.0f : keep_at(mask, b, yy, xx, ms, mgw, mL);
+          if (k != 0.f) {
+            ld2<T>(src + (((int64_t)b * H + yy) * W + xx) * C + c, a_, b_);
+            a_ *= k; b_ *= k;
+          }
+        }
+        w0[ki][kj] = a_; w1[ki][kj] = b_;
+      }
+    };
+    load_col(-2, 0); load_col(-1, 1); load_col(0, 2); load_col(1, 3);
+    for (int x = 0; x < W; ++x) {
+      load_col(x + 2, 4);
+      float s0 = b0, s1 = b1;
+#pragma unroll
+      for (int ki = 0; ki < 5; ++ki)
 #pragma unroll
         for (int kj = 0; kj < 5; ++kj) {
-          const int xx = x - kj + 2;
-          if (xx < 0 || xx >= W) continue;
-          const T *p = dout + (((int64_t)b * H + yy) * W + xx) * C + c;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] += w[(c + e) * 25 + ki * 5 + kj] * ldf<T>(p + e);
+          s0 += k0[ki][kj] * w0[ki][kj];
+          s1 += k1[ki][kj] * w1[ki][kj];
         }
+      if (BWD) {
+        const float k = keep_at(mask, b, y, x, ms, mgw, mL);
+        s0 *= k; s1 *= k;
       }
-    }
-    T *o = din + (((int64_t)b * H + y) * W + x) * C + c;
+      st2<T>(dst + ((int64_t)r * W + x) * C + c, s0, s1);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ElemIO<T>::st(o + e, k * acc[e]);
+      for (int ki = 0; ki < 5; ++ki)
+#pragma unroll
+        for (int kj = 0; kj < 4; ++kj) { w0[ki][kj] = w0[ki][kj + 1]; w1[ki][kj] = w1[ki][kj + 1]; }
+    }
   }
 }
 
 // dw[c,i,j] = sum_{b,y,x} dout[b,y,x,c] * keep(y+i-2,x+j-2) * in[b,y+i-2,x+j-2,c];  dbias[c] = sum dout
-// block = 64 channels x 4 position lanes over a slab of positions; partials part[slab][26][C] (25 taps + bias)
-constexpr int DW_SLAB = 512;   // positions per block
+// A wave walks image rows (b, y) left to right with a 5x5 register window of the (masked) input per channel: one new
+// column (5 loads) + one dout load per position instead of 25 + 1, and the keep mask is looked up once per loaded
+// element. Lane = 2 adjacent channels (one 4-byte / 8-byte load: 64 lanes cover 128 channels = 256 contiguous bytes).
+// block = 4 waves x DW_RPW rows each; partials part[slab][26][C] (25 taps + bias), slab = blockIdx.y.
+constexpr int DW_RPW = 4;                     // rows per wave
+constexpr int DW_ROWS = 4 * DW_RPW;           // rows per block (= slab)
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T *dout, const T *in, const float *mask, int B, int H, int W, int C,
                                                                 int ms, int mgw, int mL, float *part) {
-  __shared__ float sh[4][26][64];
-  const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  const int64_t npos = (int64_t)B * H * W;
-  const int64_t p0 = (int64_t)blockIdx.y * DW_SLAB, p1 = p0 + DW_SLAB < npos ? p0 + DW_SLAB : npos;
-  float acc[26];
+  __shared__ float sh[4][26][128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 128 + lane * 2;
+  const int nrows = B * H;
+  float acc0[26], acc1[26];
 #pragma unroll
-  for (int k = 0; k < 26; ++k) acc[k] = 0.f;
+  for (int k = 0; k < 26; ++k) acc0[k] = acc1[k] = 0.f;
   if (c < C) {
-    for (int64_t pos = p0 + pl; pos < p1; pos += 4) {
-      const int x = (int)(pos % W);
-      const int y = (int)((pos / W) % H);
-      const int b = (int)(pos / ((int64_t)W * H));
-      const float g = ldf<T>(dout + pos * C + c);
-      acc[25] += g;
+    const int r0 = blockIdx.y * DW_ROWS + wave * DW_RPW;
+    for (int r = r0; r < r0 + DW_RPW && r < nrows; ++r) {
+      const int b = r / H, y = r - b * H;
+      float w0[5][5], w1[5][5];          // window: w[ki][kj] = keep * in[b, y+ki-2, x+kj-2, c / c+1]
+      auto load_col = [&](int xx, float (&o0)[5], float (&o1)[5]) {
 #pragma unroll
-      for (int ki = 0; ki < 5; ++ki) {
-        const int yy = y + ki - 2;
-        if (yy < 0 || yy >= H) continue;
-#pragma unroll
-        for (int kj = 0; kj < 5; ++kj) {
-          const int xx = x + kj - 2;
-          if (xx < 0 || xx >= W) continue;
-          const float k = keep_at(mask, b, yy, xx, ms, mgw, mL);
-          if (k != 0.f) acc[ki * 5 + kj] += g * k * ldf<T>(in + (((int64_t)b * H + yy) * W + xx) * C + c);
+        for (int ki = 0; ki < 5; ++ki) {
+          const int yy = y + ki - 2;
+          o0[ki] = o1[ki] = 0.f;
+          if (xx >= 0 && xx < W && yy >= 0 && yy < H) {
+            const float k = keep_at(mask, b, yy, xx, ms, mgw, mL);
+            if (k != 0.f) {
+              float a_, b_;
+              ld2<T>(in + (((int64_t)b * H + yy) * W + xx) * C + c, a_, b_);
+              o0[ki] = k * a_; o1[ki] = k * b_;
+            }
+          }
         }
+      };
+      float c0[5], c1[5];
+#pragma unroll
+      for (int kj = 0; kj < 4; ++kj) {     // columns x-2 .. x+1 for x = 0
+        load_col(kj - 2, c0, c1);
+#pragma unroll
+        for (int ki = 0; ki < 5; ++ki) { w0[ki][kj] = c0[ki]; w1[ki][kj] = c1[ki]; }
+      }
+      for (int x = 0; x < W; ++x) {
+        load_col(x + 2, c0, c1);
+#pragma unroll
+        for (int ki = 0; ki < 5; ++ki) { w0[ki][4] = c0[ki]; w1[ki][4] = c1[ki]; }
+        float g0, g1;
+        ld2<T>(dout + ((int64_t)r * W + x) * C + c, g0, g1);
+        acc0[25] += g0; acc1[25] += g1;
+#pragma unroll
+        for (int ki = 0; ki < 5; ++ki)
+#pragma unroll
+          for (int kj = 0; kj < 5; ++kj) {
+            acc0[ki * 5 + kj] += g0 * w0[ki][kj];
+            acc1[ki * 5 + kj] += g1 * w1[ki][kj];
+          }
+#pragma unroll
+        for (int ki = 0; ki < 5; ++ki)
+#pragma unroll
+          for (int kj = 0; kj < 4; ++kj) { w0[ki][kj] = w0[ki][kj + 1]; w1[ki][kj] = w1[ki][kj + 1]; }
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 26; ++k) sh[pl][k][cl] = acc[k];
+  for (int k = 0; k < 26; ++k) { sh[wave][k][lane * 2] = acc0[k]; sh[wave][k][lane * 2 + 1] = acc1[k]; }
   __syncthreads();
-  for (int e = threadIdx.x; e < 26 * 64; e += 256) {
-    const int k = e / 64, cc = e % 64;
-    if (blockIdx.x * 64 + cc < C)
-      part[((int64_t)blockIdx.y * 26 + k) * C + blockIdx.x * 64 + cc] = sh[0][k][cc] + sh[1][k][cc] + sh[2][k][cc] + sh[3][k][cc];
+  for (int e = threadIdx.x; e < 26 * 128; e += 256) {
+    const int k = e / 128, cc = e % 128;
+    if (blockIdx.x * 128 + cc < C)
+      part[((int64_t)blockIdx.y * 26 + k) * C + blockIdx.x * 128 + cc] = sh[0][k][cc] + sh[1][k][cc] + sh[2][k][cc] + sh[3][k][cc];
   }
 }
 // dw[c*25 + k] = sum_slab part[slab][k][c] (k < 25), dbias[c] = sum_slab part[slab][25][c]
@@ -234,13 +274,15 @@ extern "C" int evp_dwconv5x5_fwd(const void *in, int dtype, const float *mask, i
   DW_COMMON_CHECK("evp_dwconv5x5_fwd")
   const int64_t n = (int64_t)B * H * W * (C / 4);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == EVP_F32) hipLaunchKernelGGL(dwconv_fwd_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, (const float *)in, mask, w, bias, B, H, W, C, mask_scale, mgw, mL, (float *)out);
-  else hipLaunchKernelGGL(dwconv_fwd_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, s, (const bf16_t *)in, mask, w, bias, B, H, W, C, mask_scale, mgw, mL, (bf16_t *)out);
+  (void)n;
+  const dim3 rg((unsigned)((C + 127) / 128), (unsigned)(((int64_t)B * H + 4 * DWF_RPW - 1) / (4 * DWF_RPW)));
+  if (dtype == EVP_F32) hipLaunchKernelGGL((dwconv_rows_kernel<float, false>), rg, dim3(256), 0, s, (const float *)in, mask, w, bias, B, H, W, C, mask_scale, mgw, mL, (float *)out);
+  else hipLaunchKernelGGL((dwconv_rows_kernel<bf16_t, false>), rg, dim3(256), 0, s, (const bf16_t *)in, mask, w, bias, B, H, W, C, mask_scale, mgw, mL, (bf16_t *)out);
   EVP_CHECK_LAUNCH("evp_dwconv5x5_fwd");
   return EVP_OK;
 }
 
-extern "C" int evp_dwconv5x5_bwd_nslab(int B, int H, int W) { return (int)(((int64_t)B * H * W + DW_SLAB - 1) / DW_SLAB); }
+extern "C" int evp_dwconv5x5_bwd_nslab(int B, int H, int W) { (void)W; return (int)(((int64_t)B * H + DW_ROWS - 1) / DW_ROWS); }
 
 extern "C" int evp_dwconv5x5_bwd(const void *dout, const void *in, int dtype, const float *mask, int mask_scale, const float *w, int B, int H,
                                  int W, int C, void *din, float *dw, float *dbias, float *workspace, void *stream) {
@@ -249,12 +291,14 @@ extern "C" int evp_dwconv5x5_bwd(const void *dout, const void *in, int dtype, co
   const int64_t n = (int64_t)B * H * W * (C / 4);
   hipStream_t s = (hipStream_t)stream;
   const int nslab = evp_dwconv5x5_bwd_nslab(B, H, W);
-  dim3 wg((C + 63) / 64, nslab);
+  dim3 wg((C + 127) / 128, nslab);
+  (void)n;
+  const dim3 rg((unsigned)((C + 127) / 128), (unsigned)(((int64_t)B * H + 4 * DWF_RPW - 1) / (4 * DWF_RPW)));
   if (dtype == EVP_F32) {
-    hipLaunchKernelGGL(dwconv_bwd_data_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, (const float *)dout, mask, w, B, H, W, C, mask_scale, mgw, mL, (float *)din);
+    hipLaunchKernelGGL((dwconv_rows_kernel<float, true>), rg, dim3(256), 0, s, (const float *)dout, mask, w, (const float *)nullptr, B, H, W, C, mask_scale, mgw, mL, (float *)din);
     hipLaunchKernelGGL(dwconv_bwd_weight_kernel<float>, wg, dim3(256), 0, s, (const float *)dout, (const float *)in, mask, B, H, W, C, mask_scale, mgw, mL, workspace);
   } else {
-    hipLaunchKernelGGL(dwconv_bwd_data_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, s, (const bf16_t *)dout, mask, w, B, H, W, C, mask_scale, mgw, mL, (bf16_t *)din);
+    hipLaunchKernelGGL((dwconv_rows_kernel<bf16_t, true>), rg, dim3(256), 0, s, (const bf16_t *)dout, mask, w, (const float *)nullptr, B, H, W, C, mask_scale, mgw, mL, (bf16_t *)din);
     hipLaunchKernelGGL(dwconv_bwd_weight_kernel<bf16_t>, wg, dim3(256), 0, s, (const bf16_t *)dout, (const bf16_t *)in, mask, B, H, W, C, mask_scale, mgw, mL, workspace);
   }
   EVP_CHECK_LAUNCH("evp_dwconv5x5_bwd");
