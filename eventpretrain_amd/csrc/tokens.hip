@@ -362,3 +362,28 @@ extern "C" int evp_token_mean_bwd(const float *g, int B, int N, int D, float *dx
   EVP_CHECK_LAUNCH("evp_token_mean_bwd");
   return EVP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ slice sum
+// out[i] (+)= sum_s ws[s * numel + i]: the reduction of split-K weight-gradient partials (each K slice of a long-K
+// problem is computed as its own problem of the grouped launch into its own slice of a workspace).
+__global__ __launch_bounds__(256) void sum_slices_kernel(const float4 *__restrict__ ws, float4 *__restrict__ out, int n_slices, int64_t n4,
+                                                         int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = accumulate ? out[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < n_slices; ++k) {
+    const float4 v = ws[(int64_t)k * n4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  out[i] = s;
+}
+extern "C" int evp_sum_slices_f32(const float *ws, float *out, int n_slices, int64_t numel, int accumulate, void *stream) {
+  EVP_CHECK_ARG(ws && out, EVP_EINVAL, "evp_sum_slices_f32: null pointer");
+  EVP_CHECK_ARG(n_slices > 0 && numel > 0 && numel % 4 == 0, EVP_ESHAPE, "evp_sum_slices_f32: n_slices=%d numel=%lld (numel%%4==0)", n_slices,
+                (long long)numel);
+  const int64_t n4 = numel / 4;
+  hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)ws, (float4 *)out,
+                     n_slices, n4, accumulate);
+  EVP_CHECK_LAUNCH("evp_sum_slices_f32");
+  return EVP_OK;
+}

@@ -327,16 +327,19 @@ class _DeferredGrads:
         return self._build(n_chunks=n_chunks, static=True)
 
     class _Step:
-        def __init__(self, entry, pt, it, n_items, flats, zero, keep):
+        def __init__(self, entry, pt, it, n_items, flats, zero, keep, post=()):
             self.entry, self.pt, self.it, self.n_items = entry, pt, it, n_items
             self.flats = flats          # flat gradient buffers complete once this step has run
             self.zero = zero            # buffers that accumulate with atomics: cleared before every run
             self.keep = keep            # operand tensors referenced by the tables
+            self.post = list(post)      # split-K reductions: (workspace, out, n_slices, numel, accumulate)
 
         def run(self):
             for z in self.zero:
                 z.zero_()
             call(self.entry, self.pt.data_ptr(), self.it.data_ptr(), self.n_items, stream_ptr())
+            for ws, out, ns, numel, acc in self.post:
+                call("evp_sum_slices_f32", ws.data_ptr(), out.data_ptr(), ns, numel, acc, stream_ptr())
 
     def _build(self, n_chunks, static):
         import numpy as np
@@ -401,22 +404,49 @@ class _DeferredGrads:
                 if small:
                     groups.append(("w128r%d" % r, small, 128, "evp_gemm_grouped_tn_bf16"))
                 for tag, part, T_, entry in groups:
-                    flat, fresh_ids = alloc_fresh([it[0] for it in part] + [it[6] for it in part if it[6] is not None and T_ == 256],
+                    # A problem with few output tiles and a very long K (ConvViT stage 1: 256x256 outputs, K = B*56*56)
+                    # would keep one workgroup busy for the whole launch: cut its K into slices that run as separate
+                    # problems into a workspace and are summed afterwards. The bias then takes the column-sum launch.
+                    def n_slices_(it):
+                        tiles = ((it[3] + T_ - 1) // T_) * ((it[4] + T_ - 1) // T_)
+                        return int(min(64, it[5] // 8192)) if (tiles <= 32 and it[5] >= 32768 and (it[3] * it[4]) % 4 == 0) else 1
+                    for it in part:
+                        if it[6] is not None and T_ == 256 and n_slices_(it) > 1:
+                            b.append((it[6], it[1]))
+                    flat, fresh_ids = alloc_fresh([it[0] for it in part] +
+                                                  [it[6] for it in part if it[6] is not None and T_ == 256 and n_slices_(it) == 1],
                                                   dev, zeroed=False)
-                    probs = np.zeros(len(part), dtype=pdt)
-                    items = []
-                    for i, (param, dy, x, n_out, k_in, rows, bias_param) in enumerate(part):
+                    rows_, items, post = [], [], []
+                    for (param, dy, x, n_out, k_in, rows, bias_param) in part:
                         gt, acc = self._target(param)
                         if id(param) in fresh_ids:
                             acc = 0                  # first write into the freshly allocated flat slice
+                        ns = n_slices_((param, dy, x, n_out, k_in, rows, bias_param))
+                        tm, tn = (n_out + T_ - 1) // T_, (k_in + T_ - 1) // T_
+                        if ns > 1:
+                            kper = ((rows // 64 + ns - 1) // ns) * 64
+                            ns = (rows + kper - 1) // kper
+                            numel = n_out * k_in
+                            ws = torch.empty(ns * numel, dtype=torch.float32, device=dev)
+                            for sidx in range(ns):
+                                k0 = sidx * kper
+                                kk = min(kper, rows - k0)
+                                rows_.append((dy.data_ptr() + k0 * n_out * 2, x.data_ptr() + k0 * k_in * 2, ws.data_ptr() + sidx * numel * 4,
+                                              n_out, k_in, kk, n_out, k_in, k_in, 0, 0, 0, tm, tn))
+                            post.append((ws, gt, ns, numel, acc))
+                            continue
                         cs_ptr, cs_acc = 0, 0
                         if bias_param is not None and T_ == 256:
                             bt, cs_acc = self._target(bias_param)
                             if id(bias_param) in fresh_ids:
                                 cs_acc = 0
                             cs_ptr = bt.data_ptr()
-                        probs[i] = (dy.data_ptr(), x.data_ptr(), gt.data_ptr(), n_out, k_in, rows, n_out, k_in, k_in, acc, cs_acc, cs_ptr)
-                        tm, tn = (n_out + T_ - 1) // T_, (k_in + T_ - 1) // T_
+                        rows_.append((dy.data_ptr(), x.data_ptr(), gt.data_ptr(), n_out, k_in, rows, n_out, k_in, k_in, acc, cs_acc, cs_ptr, tm, tn))
+                    rows_.sort(key=lambda r_: -r_[5])           # longest K first
+                    probs = np.zeros(len(rows_), dtype=pdt)
+                    for i, r_ in enumerate(rows_):
+                        probs[i] = r_[:12]
+                        tm, tn = r_[12], r_[13]
                         t = np.zeros((tn, tm, 4), dtype=np.int32)
                         t[..., 0] = i
                         t[..., 1] = np.arange(tm, dtype=np.int32)[None, :]
@@ -426,7 +456,7 @@ class _DeferredGrads:
                     pt = table(tag + "p", probs.view(np.uint8), dev)
                     it_ = table(tag + "i", items.view(np.uint8).reshape(-1), dev)
                     steps.append(self._Step(entry, pt, it_, int(items.shape[0]), [flat] if flat is not None else [], [],
-                                            [(it[1], it[2]) for it in part]))
+                                            [(it[1], it[2]) for it in part], post))
         if b:
             dev = b[0][1].device
             probs = np.zeros(len(b), dtype=np.dtype([("x", "<u8"), ("out", "<u8"), ("M", "<i8"), ("N", "<i4"), ("ld", "<i4"),

@@ -107,6 +107,9 @@ int evp_gemm_grouped_tn_bf16(const void *problems, const void *items, int n_item
  * A non-NULL `colsum` (float32 [M_g]) also receives colsum[m] (+)= sum_k A_g[k][m] -- the bias gradient db = sum over
  * rows of dY of the same Linear -- computed from the A fragments already in registers (no second pass over dY). */
 int evp_gemm_grouped_tn256_bf16(const void *problems, const void *items, int n_items, void *stream);
+/* out[i] (+)= sum_s ws[s*numel + i], float32, numel % 4 == 0: reduction of split-K partials when a long-K problem was
+ * entered into the grouped launch as several K-slice problems writing to a workspace (ConvViT stage 1: K = B*56*56). */
+int evp_sum_slices_f32(const float *ws, float *out, int n_slices, int64_t numel, int accumulate, void *stream);
 /* Tuning switch for A/B measurements: 1 = LDS-DMA (buffer_load ... lds) staging for bf16 (default), 2 = register
  * staging. Returns the previous value; any other argument only queries. Results are identical. */
 int evp_gemm_set_variant(int v);
