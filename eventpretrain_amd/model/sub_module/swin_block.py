@@ -250,9 +250,18 @@ class GroupingModule:
         return w[:, 0] * coords.shape[0] + w[:, 1]
 
     def _rel_index(self, c):
+        """relative-position index of every token pair of a group, int32 [..., n, n] (swin_block.py:375-381); rows and
+        columns are handled separately in int32 -- the [..., n, n, 2] int64 form cost 10 ms of host time per step"""
         ws = self.window_size
-        d = c[..., :, None, :] - c[..., None, :, :] + (ws - 1)
-        return d[..., 0] * (2 * ws - 1) + d[..., 1]
+        cy = np.ascontiguousarray(c[..., 0], dtype=np.int32)
+        cx = np.ascontiguousarray(c[..., 1], dtype=np.int32)
+        out = cy[..., :, None] - cy[..., None, :]
+        out += ws - 1
+        out *= 2 * ws - 1
+        out += cx[..., :, None]
+        out -= cx[..., None, :]
+        out += ws - 1
+        return out
 
     def plan(self, coords, num_tokens):
         """coords int64 [n,2] (host). -> dict of host arrays (see prepare)."""
@@ -260,8 +269,9 @@ class GroupingModule:
         wid = self._window_id(coords)
         ws = self.window_size
         if num_tokens <= 2 * ws * ws:
-            same = wid[:, None] == wid[None, :]
-            rel = np.where(same, self._rel_index(coords), -1)[None]
+            rel = self._rel_index(coords)
+            rel[wid[:, None] != wid[None, :]] = -1
+            rel = rel[None]
             return dict(mode="masking", rel=rel, group_size=int(num_tokens), n_groups=1)
         order = np.argsort(wid, kind="stable")
         swid = wid[order]
@@ -284,8 +294,9 @@ class GroupingModule:
         tok_slot = np.empty(coords.shape[0], dtype=np.int64)
         tok_slot[flat[real]] = np.nonzero(real)[0]
         cs = coords[np.where(real, flat, 0)].reshape(ng, gs, 2)
-        ok = (slot_wid[:, :, None] == slot_wid[:, None, :]) & (slot_wid[:, :, None] >= 0)
-        rel = np.where(ok, self._rel_index(cs), -1)
+        sw = slot_wid.astype(np.int32)
+        rel = self._rel_index(cs)
+        rel[(sw[:, :, None] != sw[:, None, :]) | (sw[:, :, None] < 0)] = -1
         return dict(mode="grouping", rel=rel, group_size=gs, n_groups=ng, gather=np.where(real, flat, 0), gather_adj=tok_slot,
                     scatter=tok_slot, scatter_adj=flat)
 
