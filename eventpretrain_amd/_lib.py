@@ -146,8 +146,19 @@ def require_device():
                        "there is no CPU fallback")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_dev_index = None
+
+
 def stream_ptr():
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream on the current device (the raw-stream accessor is ~5x cheaper than building a
+    torch.cuda.Stream object; an eager step calls this ~900 times)."""
+    global _dev_index
+    if _raw_stream is None:
+        return torch.cuda.current_stream().cuda_stream
+    if _dev_index is None:
+        _dev_index = torch.cuda.current_device()
+    return _raw_stream(_dev_index)
 
 
 def call(name, *args):
