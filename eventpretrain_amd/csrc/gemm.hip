@@ -762,6 +762,7 @@ struct GroupedItem { int prob, tile_m, tile_n, pad; };
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_grouped_tn_kernel(const GroupedProblem *__restrict__ probs, const GroupedItem *__restrict__ items) {
   const GroupedItem it = items[blockIdx.x];
+  if (it.prob < 0) return;                       // padding of the per-XCD item lists
   const GroupedProblem g = probs[it.prob];
   GemmParams p;
   p.M = g.M; p.N = g.N; p.K = g.K;
@@ -1038,6 +1039,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 // grouped weight gradients on the 256x256 ring: same problem / item tables as gemm_grouped_tn_kernel, 256x256 items
 __global__ __launch_bounds__(512) void gemm256_grouped_tn_kernel(const GroupedProblem *__restrict__ probs, const GroupedItem *__restrict__ items) {
   const GroupedItem it = items[blockIdx.x];
+  if (it.prob < 0) return;                       // padding of the per-XCD item lists (see the host-side ordering)
   const GroupedProblem g = probs[it.prob];
   GemmParams p;
   p.M = g.M; p.N = g.N; p.K = g.K;

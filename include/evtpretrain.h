@@ -100,7 +100,8 @@ int evp_gemm(const evp_gemm_desc *d, void *stream);
  * vit_block.py:133,141,226,230 etc.). `problems` is a device array of
  *   struct { const void *A, *B; void *C; int M, N, K; int lda, ldb, ldc; int accumulate, colsum_accumulate;
  *            float *colsum; }   (64 bytes each; accumulate != 0: C_g += ...; colsum: see the 256x256 entry, NULL here)
- * and `items` a device array of  struct { int prob, tile_m, tile_n, pad; }  listing every 128x128 output tile. */
+ * and `items` a device array of  struct { int prob, tile_m, tile_n, pad; }  listing every 128x128 output tile
+ * (prob < 0 = padding entry, skipped: lets the caller lay the list out per XCD, workgroups i and i+8 share an L2). */
 int evp_gemm_grouped_tn_bf16(const void *problems, const void *items, int n_items, void *stream);
 /* Same problem table, but `items` lists 256x256 output tiles and every K_g must be a multiple of 64: the 8-wave
  * half-tile-ring kernel (one workgroup per CU), the faster form when K_g is long (K_g = batch x tokens here).
