@@ -193,6 +193,21 @@ def cpu_baseline(cfgs, n_threads):
                        "B=%d, %d steps, %.1f s" % (Bc, n_steps, dt_))
 
 
+def pmc_traffic(kernel_key):
+    """HBM-side bytes per launch of a kernel from the committed PMC summary (profiles/r01_pmc_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the guide's gfx950 correction), or None. bench.py cannot collect
+    PMC counters itself; the figure is from the same command profiled offline."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
+            k = json.load(f)["kernels"]
+        for name, v in k.items():
+            if name in kernel_key:
+                return float(v["traffic_bytes"])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_voxel_baseline():
     from eventpretrain_amd.testing import synthetic_events
     from oracle.voxel_oracle import voxel_grid_batch
@@ -357,7 +372,7 @@ def main():
             top = ks[0]
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
             result["roofline"] = {"bound": "mfma", "achieved": top["tflops"], "peak": peak, "unit": "TFLOP/s",
-                                  "frac": top["tflops"] / peak, "traffic": None, "kernel": top["kernel"],
+                                  "frac": top["tflops"] / peak, "traffic": pmc_traffic(top["kernel"]), "kernel": top["kernel"],
                                   "avg_launch_us": top["avg_us"], "launches_per_step": top["launches_per_step"],
                                   "ms_per_step_in_kernel": top["ms_per_step"],
                                   "note": "achieved = algorithmic 2MNK FLOPs of this kernel's launches in one step / their "
@@ -378,7 +393,9 @@ def main():
         sec = e0.elapsed_time(e1) * 1e-3 / reps
         bytes_ = args.batch * (n_ev * 32 + 5 * S * S * 4)
         result["voxel"] = {"bound": "hbm", "achieved": bytes_ / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": bytes_ / sec / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "voxel_cuts_kernel+voxel_bin_kernel",
+                           "frac": bytes_ / sec / 1e9 / HBM_PEAK_GBS,
+                           "traffic": (pmc_traffic("voxel_bin_kernel") or 0) + (pmc_traffic("voxel_cuts_kernel") or 0) or None,
+                           "kernel": "voxel_cuts_kernel+voxel_bin_kernel",
                            "us_per_batch": sec * 1e6, "clips_per_s": args.batch / sec, "events_per_s": args.batch * n_ev / sec,
                            "algorithmic_bytes_per_clip": n_ev * 32 + 5 * S * S * 4}
     if multi:
