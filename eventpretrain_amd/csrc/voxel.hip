@@ -3,11 +3,11 @@
 // Restates dataset/dataset_utils/events_to_voxel_grid.py:4-61 of the reference (two index_add_ scatters) as
 //   1. voxel_cuts_kernel : per clip, a 64-ary wave search over the (time-sorted) stamps for the first event with
 //                          ts >= k, k = 0..bins  -> the contiguous event slab that can touch bin plane b.
-//   2. voxel_bin_kernel  : one workgroup per (clip, bin, y-tile). The tile of the bin plane lives in LDS
-//                          (ds_add_f32), the workgroup streams its event slab with coalesced 32-byte rows, and the
-//                          tile is flushed ONCE with coalesced 16-byte stores -- no global atomics, no memset,
-//                          every output byte written exactly once.
-//      Blocks of one clip are mapped to one XCD (blockIdx % 8) so the slab re-reads (one per bin / y-tile) are
+//   2. voxel_bin_kernel  : workgroups of equal work per (clip, plane pair / plane, y-tile) -- see the schedule at the
+//                          kernel. The tile of the bin plane lives in LDS (ds_add_f32), the workgroup streams its
+//                          event slab with coalesced 32-byte rows, and the tile is flushed ONCE with coalesced
+//                          16-byte stores -- no global atomics, no memset, every output byte written exactly once.
+//      Blocks of one clip are mapped to one XCD (blockIdx % 8) so the slab re-reads (one per plane / y-tile) are
 //      served by that XCD's L2, not by HBM.
 // algo 1 keeps the plain global-atomic formulation (memset + 2 atomics per event), algo 2 a decode-once two-pass form
 // (12-byte packed records); both measured slower than the default (5.3x and 1.3x) and stay for A/B measurements.
@@ -35,7 +35,7 @@ __device__ __forceinline__ double stamp(const double *ev, int64_t i, int is_txyp
 __device__ __forceinline__ double ts_of(double t, double t0, double dT, int bins) { return (double)(bins - 1) * (t - t0) / dT; }
 
 // cuts[c][k], k = 0..bins: first row i (clip-relative) with ts_i >= k; cuts[c][bins+1] = n (unused sentinel)
-__global__ __launch_bounds__(256) void voxel_cuts_kernel(const double *events, const int64_t *offsets, int bins, int is_txyp,
+__global__ __launch_bounds__(512) void voxel_cuts_kernel(const double *events, const int64_t *offsets, int bins, int is_txyp,
                                                          int64_t *cuts) {
   const int c = blockIdx.x;
   const int64_t beg = offsets[c], n = offsets[c + 1] - beg;
@@ -73,31 +73,46 @@ __global__ __launch_bounds__(256) void voxel_cuts_kernel(const double *events, c
   if (threadIdx.x == 0) out[bins + 1] = n;
 }
 
-// Contribution of one event to bin plane `b`: returns false if none. pix = x + y*W (flat, as the reference).
-__device__ __forceinline__ bool contribution(const Event &e, double t0, double dT, int bins, int b, int W, int64_t &pix,
-                                             float &val) {
-  const double ts = ts_of(e.t, t0, dT, bins);
-  const double tf = floor(ts);
-  if (!(tf >= 0.0)) return false;  // also rejects NaN
-  float p = (float)e.p;
-  if (p == 0.0f) p = -1.0f;
-  const float dt = (float)(ts - tf);
-  if (tf == (double)b) val = p * (1.0f - dt);          // left neighbour, valid since b < bins
-  else if (tf + 1.0 == (double)b) val = p * dt;         // right neighbour
-  else return false;
-  pix = (int64_t)e.x + (int64_t)e.y * (int64_t)W;
-  return true;
-}
-
 constexpr int VB_THREADS = 1024;
 constexpr int VB_UNROLL = 4;
 
+// a / d for the clip-constant divisor d, r = RN(1/d): two Newton corrections of q = a*r with exact FMA residuals, the
+// last one is Markstein's final step (q faithful + r correctly rounded => RN(q + (a - q*d)*r) == RN(a/d)), so the
+// result is the IEEE quotient the reference's float64 division produces -- at 5 full-rate FMAs instead of the ~14
+// instruction v_div_scale/v_rcp_f64/v_div_fmas/v_div_fixup sequence (quarter-rate parts included) per event.
+// Valid while nothing under- or overflows; callers route operands outside [2^-400, 2^400] to the plain division.
+__device__ __forceinline__ double div_by_clip_constant(double a, double d, double r) {
+  double q = a * r;
+  double e = __builtin_fma(-q, d, a);
+  q = __builtin_fma(e, r, q);
+  e = __builtin_fma(-q, d, a);
+  return __builtin_fma(e, r, q);
+}
+__device__ __forceinline__ bool in_safe_range(double v) {
+  const double m = __builtin_fabs(v);
+  return m >= 0x1p-400 && m <= 0x1p400;  // false for 0, NaN, inf, denormals
+}
+
+// Per event visit: (1) x, y -> flat pixel with 32-bit conversions and the y-tile test, which rejects about half of the
+// visits after ~10 instructions; (2) only for events inside the tile the float64 time normalisation, with the division
+// above. Measured: the kernel is bound by the bytes it pulls through L2 (every event row is visited by ~4 workgroups),
+// not by this arithmetic, so the schedule below is what matters.
+//
+// Schedule. With sorted stamps the clip splits into regions R_k = [cuts[k], cuts[k+1]) (floor(ts) == k); plane b takes
+// the left contributions of R_b and the right contributions of R_(b-1). A clip is served by (bins-1) * n_yt workgroups
+// of EQUAL work (two regions each):
+//   j = 0        : plane 0 over R_0, flush, then plane bins-1 over R_(bins-2) (+ the few rows with ts == bins-1)
+//   j = 1..bins-2: plane j over R_(j-1) and R_j -- ascending rows for odd j, descending rows for even j
+// so that, for odd `bins`, the two planes that need a region stream it during the same half of their lifetime and the
+// second reader finds the rows in the XCD's L2 instead of fetching them again (all blocks of a clip share an XCD).
+template <bool TXYP>
 __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *events, const int64_t *offsets, const int64_t *cuts,
-                                                               int n_clips, int bins, int H, int W, int is_txyp,
-                                                               int assume_sorted, int tile_rows, int n_yt, float *out) {
+                                                               int n_clips, int bins, int H, int W, int assume_sorted, int tile_rows,
+                                                               int n_yt, float *out) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float *tile = reinterpret_cast<float *>(smem_raw);
-  const int per_clip = bins * n_yt;
+  const int n_j = bins > 1 ? bins - 1 : 1;
+  const int per_clip = n_j * n_yt;
   int clip, sub;
   if ((n_clips & 7) == 0) {  // keep one clip's blocks on one XCD (blocks b and b+8 share an XCD)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -107,48 +122,78 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *eve
     clip = blockIdx.x / per_clip;
     sub = blockIdx.x % per_clip;
   }
-  const int b = sub / n_yt, yt = sub % n_yt;
+  const int j = sub / n_yt, yt = sub % n_yt;
   const int y0 = yt * tile_rows, y1 = (y0 + tile_rows < H) ? y0 + tile_rows : H;
   const int tile_elems = (y1 - y0) * W;
-  for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) tile[i] = 0.f;
-  __syncthreads();
-
+  const int64_t pix0 = (int64_t)y0 * W, pix1 = (int64_t)y1 * W;
   const int64_t beg = offsets[clip], n = offsets[clip + 1] - beg;
-  float *dst = out + (((int64_t)clip * bins + b) * H + y0) * W;
+  const double *ev = events + beg * 4;
+  const int64_t *cc = cuts + (int64_t)clip * (bins + 2);
+  double t0 = 0.0, dT = 1.0;
   if (n > 0) {
-    const double *ev = events + beg * 4;
-    const double t0 = stamp(ev, 0, is_txyp), t1 = stamp(ev, n - 1, is_txyp);
-    double dT = t1 - t0;
+    t0 = stamp(ev, 0, TXYP);
+    dT = stamp(ev, n - 1, TXYP) - t0;
     if (dT == 0) dT = 1.0;
-    const int64_t *cc = cuts + (int64_t)clip * (bins + 2);
-    // sorted: only rows with floor(ts) in {b-1, b} can touch plane b; unsorted: scan the whole clip
-    const int64_t lo = assume_sorted ? cc[b > 0 ? b - 1 : 0] : 0;
-    const int64_t hi = assume_sorted ? cc[b + 1] : n;
-    const int64_t pix0 = (int64_t)y0 * W, pix1 = (int64_t)y1 * W;
-    for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)VB_THREADS * VB_UNROLL) {
-      Event e[VB_UNROLL];
-      bool live[VB_UNROLL];
+  }
+  const double rT = 1.0 / dT, scale = (double)(bins - 1);
+  const bool clip_fast = in_safe_range(dT);
+
+  const int n_jobs = (j == 0 && bins > 1) ? 2 : 1;
+  for (int job = 0; job < n_jobs; ++job) {
+    const int b = job ? bins - 1 : j;
+    const bool descending = (j > 0) && ((j & 1) == 0);
+    const double bd = (double)b;
+    if (job) __syncthreads();  // the previous plane's flush has read the tile
+    for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) tile[i] = 0.f;
+    __syncthreads();
+    if (n > 0) {
+      // sorted: only rows with floor(ts) in {b-1, b} can touch plane b; unsorted: scan the whole clip
+      const int64_t lo = assume_sorted ? cc[b > 0 ? b - 1 : 0] : 0;
+      const int64_t hi = assume_sorted ? cc[b + 1] : n;
+      for (int64_t k0 = threadIdx.x; k0 < hi - lo; k0 += (int64_t)VB_THREADS * VB_UNROLL) {
+        double2 ra[VB_UNROLL], rb[VB_UNROLL];
+        bool live[VB_UNROLL];
 #pragma unroll
-      for (int u = 0; u < VB_UNROLL; ++u) {
-        const int64_t i = i0 + (int64_t)u * VB_THREADS;
-        live[u] = i < hi;
-        e[u] = load_event(ev, live[u] ? i : lo, is_txyp);
-      }
+        for (int u = 0; u < VB_UNROLL; ++u) {
+          const int64_t k = k0 + (int64_t)u * VB_THREADS;
+          live[u] = k < hi - lo;
+          const double *row = ev + (live[u] ? (descending ? hi - 1 - k : lo + k) : lo) * 4;
+          ra[u] = *reinterpret_cast<const double2 *>(row);
+          rb[u] = *reinterpret_cast<const double2 *>(row + 2);
+        }
 #pragma unroll
-      for (int u = 0; u < VB_UNROLL; ++u) {
-        int64_t pix;
-        float val;
-        if (live[u] && contribution(e[u], t0, dT, bins, b, W, pix, val) && pix >= pix0 && pix < pix1)
+        for (int u = 0; u < VB_UNROLL; ++u) {
+          const double x = TXYP ? ra[u].y : ra[u].x, y = TXYP ? rb[u].x : ra[u].y;
+          const double t = TXYP ? ra[u].x : rb[u].x, pd = rb[u].y;
+          int64_t pix;
+          if (__builtin_fabs(x) < 2147483648.0 && __builtin_fabs(y) < 2147483648.0)
+            pix = (int64_t)(int)x + (int64_t)(int)y * (int64_t)W;  // same truncation as the int64 conversion below
+          else
+            pix = (int64_t)x + (int64_t)y * (int64_t)W;
+          if (!live[u] || pix < pix0 || pix >= pix1) continue;
+          const double a = scale * (t - t0);
+          const double ts = (clip_fast && in_safe_range(a)) ? div_by_clip_constant(a, dT, rT) : a / dT;
+          const double tf = floor(ts);
+          if (!(tf >= 0.0)) continue;                   // also rejects NaN
+          float p = (float)pd;
+          if (p == 0.0f) p = -1.0f;
+          const float dt = (float)(ts - tf);
+          float val;
+          if (tf == bd) val = p * (1.0f - dt);          // left neighbour, valid since b < bins
+          else if (tf + 1.0 == bd) val = p * dt;         // right neighbour
+          else continue;
           atomicAdd(&tile[pix - pix0], val);
+        }
       }
     }
-  }
-  __syncthreads();
-  if ((W & 3) == 0) {
-    for (int i = threadIdx.x; i < tile_elems / 4; i += VB_THREADS)
-      reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(tile)[i];
-  } else {
-    for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) dst[i] = tile[i];
+    __syncthreads();
+    float *dst = out + (((int64_t)clip * bins + b) * H + y0) * W;
+    if ((W & 3) == 0) {
+      for (int i = threadIdx.x; i < tile_elems / 4; i += VB_THREADS)
+        reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(tile)[i];
+    } else {
+      for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) dst[i] = tile[i];
+    }
   }
 }
 
@@ -315,7 +360,7 @@ extern "C" int evp_voxel_scatter_f32(const double *events, const int64_t *clip_o
   const int n_yt = (H + tile_rows - 1) / tile_rows;
   const size_t smem = (size_t)tile_rows * W * sizeof(float);
   if (assume_sorted) {
-    hipLaunchKernelGGL(voxel_cuts_kernel, dim3(n_clips), dim3(256), 0, s, events, clip_offsets, bins, is_txyp, workspace);
+    hipLaunchKernelGGL(voxel_cuts_kernel, dim3(n_clips), dim3(512), 0, s, events, clip_offsets, bins, is_txyp, workspace);
     EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(cuts)");
   }
   if (algo == 2) {
@@ -333,11 +378,17 @@ extern "C" int evp_voxel_scatter_f32(const double *events, const int64_t *clip_o
     return EVP_OK;
   }
   if (smem > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(voxel_bin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(is_txyp ? voxel_bin_kernel<true> : voxel_bin_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_voxel_scatter_f32: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(voxel_bin_kernel, dim3(n_clips * bins * n_yt), dim3(VB_THREADS), smem, s, events, clip_offsets, workspace, n_clips,
-                     bins, H, W, is_txyp, assume_sorted, tile_rows, n_yt, out);
+  const int n_blocks = n_clips * (bins > 1 ? bins - 1 : 1) * n_yt;  // plane 0 and plane bins-1 share a workgroup
+  if (is_txyp)
+    hipLaunchKernelGGL(voxel_bin_kernel<true>, dim3(n_blocks), dim3(VB_THREADS), smem, s, events, clip_offsets, workspace, n_clips, bins, H,
+                       W, assume_sorted, tile_rows, n_yt, out);
+  else
+    hipLaunchKernelGGL(voxel_bin_kernel<false>, dim3(n_blocks), dim3(VB_THREADS), smem, s, events, clip_offsets, workspace, n_clips, bins, H,
+                       W, assume_sorted, tile_rows, n_yt, out);
   EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(bin)");
   return EVP_OK;
 }
