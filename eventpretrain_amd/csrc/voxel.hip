@@ -102,7 +102,7 @@ __device__ __forceinline__ bool in_safe_range(double v) {
 // the left contributions of R_b and the right contributions of R_(b-1). A clip is served by (bins-1) * n_yt workgroups
 // of EQUAL work (two regions each):
 //   j = 0        : plane 0 over R_0, flush, then plane bins-1 over R_(bins-2) (+ the few rows with ts == bins-1)
-//   j = 1..bins-2: plane j over R_(j-1) and R_j -- ascending rows for odd j, descending rows for even j
+//   j = 1..bins-2: plane j over R_(j-1) then R_j for odd j, R_j then R_(j-1) for even j (rows ascending in both)
 // so that, for odd `bins`, the two planes that need a region stream it during the same half of their lifetime and the
 // second reader finds the rows in the XCD's L2 instead of fetching them again (all blocks of a clip share an XCD).
 template <bool TXYP>
@@ -141,48 +141,52 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *eve
   const int n_jobs = (j == 0 && bins > 1) ? 2 : 1;
   for (int job = 0; job < n_jobs; ++job) {
     const int b = job ? bins - 1 : j;
-    const bool descending = (j > 0) && ((j & 1) == 0);
+    const bool swapped = (j > 0) && ((j & 1) == 0);
     const double bd = (double)b;
     if (job) __syncthreads();  // the previous plane's flush has read the tile
     for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) tile[i] = 0.f;
     __syncthreads();
     if (n > 0) {
-      // sorted: only rows with floor(ts) in {b-1, b} can touch plane b; unsorted: scan the whole clip
-      const int64_t lo = assume_sorted ? cc[b > 0 ? b - 1 : 0] : 0;
-      const int64_t hi = assume_sorted ? cc[b + 1] : n;
-      for (int64_t k0 = threadIdx.x; k0 < hi - lo; k0 += (int64_t)VB_THREADS * VB_UNROLL) {
-        double2 ra[VB_UNROLL], rb[VB_UNROLL];
-        bool live[VB_UNROLL];
-#pragma unroll
-        for (int u = 0; u < VB_UNROLL; ++u) {
-          const int64_t k = k0 + (int64_t)u * VB_THREADS;
-          live[u] = k < hi - lo;
-          const double *row = ev + (live[u] ? (descending ? hi - 1 - k : lo + k) : lo) * 4;
-          ra[u] = *reinterpret_cast<const double2 *>(row);
-          rb[u] = *reinterpret_cast<const double2 *>(row + 2);
-        }
-#pragma unroll
-        for (int u = 0; u < VB_UNROLL; ++u) {
-          const double x = TXYP ? ra[u].y : ra[u].x, y = TXYP ? rb[u].x : ra[u].y;
-          const double t = TXYP ? ra[u].x : rb[u].x, pd = rb[u].y;
-          int64_t pix;
-          if (__builtin_fabs(x) < 2147483648.0 && __builtin_fabs(y) < 2147483648.0)
-            pix = (int64_t)(int)x + (int64_t)(int)y * (int64_t)W;  // same truncation as the int64 conversion below
-          else
-            pix = (int64_t)x + (int64_t)y * (int64_t)W;
-          if (!live[u] || pix < pix0 || pix >= pix1) continue;
-          const double a = scale * (t - t0);
-          const double ts = (clip_fast && in_safe_range(a)) ? div_by_clip_constant(a, dT, rT) : a / dT;
-          const double tf = floor(ts);
-          if (!(tf >= 0.0)) continue;                   // also rejects NaN
-          float p = (float)pd;
-          if (p == 0.0f) p = -1.0f;
-          const float dt = (float)(ts - tf);
-          float val;
-          if (tf == bd) val = p * (1.0f - dt);          // left neighbour, valid since b < bins
-          else if (tf + 1.0 == bd) val = p * dt;         // right neighbour
-          else continue;
-          atomicAdd(&tile[pix - pix0], val);
+      // sorted: only rows with floor(ts) in {b-1, b} can touch plane b -- two regions, each walked upward, the upper
+      // one first for even j; unsorted: scan the whole clip
+      for (int part = 0; part < (assume_sorted ? 2 : 1); ++part) {
+        const bool upper = (part == 0) == swapped;
+        const int64_t lo = assume_sorted ? (upper ? cc[b] : cc[b > 0 ? b - 1 : 0]) : 0;
+        const int64_t hi = assume_sorted ? (upper ? cc[b + 1] : cc[b]) : n;
+        for (int64_t k0 = threadIdx.x; k0 < hi - lo; k0 += (int64_t)VB_THREADS * VB_UNROLL) {
+          double2 ra[VB_UNROLL], rb[VB_UNROLL];
+          bool live[VB_UNROLL];
+  #pragma unroll
+          for (int u = 0; u < VB_UNROLL; ++u) {
+            const int64_t k = k0 + (int64_t)u * VB_THREADS;
+            live[u] = k < hi - lo;
+            const double *row = ev + (lo + (live[u] ? k : 0)) * 4;
+            ra[u] = *reinterpret_cast<const double2 *>(row);
+            rb[u] = *reinterpret_cast<const double2 *>(row + 2);
+          }
+  #pragma unroll
+          for (int u = 0; u < VB_UNROLL; ++u) {
+            const double x = TXYP ? ra[u].y : ra[u].x, y = TXYP ? rb[u].x : ra[u].y;
+            const double t = TXYP ? ra[u].x : rb[u].x, pd = rb[u].y;
+            int64_t pix;
+            if (__builtin_fabs(x) < 2147483648.0 && __builtin_fabs(y) < 2147483648.0)
+              pix = (int64_t)(int)x + (int64_t)(int)y * (int64_t)W;  // same truncation as the int64 conversion below
+            else
+              pix = (int64_t)x + (int64_t)y * (int64_t)W;
+            if (!live[u] || pix < pix0 || pix >= pix1) continue;
+            const double a = scale * (t - t0);
+            const double ts = (clip_fast && in_safe_range(a)) ? div_by_clip_constant(a, dT, rT) : a / dT;
+            const double tf = floor(ts);
+            if (!(tf >= 0.0)) continue;                   // also rejects NaN
+            float p = (float)pd;
+            if (p == 0.0f) p = -1.0f;
+            const float dt = (float)(ts - tf);
+            float val;
+            if (tf == bd) val = p * (1.0f - dt);          // left neighbour, valid since b < bins
+            else if (tf + 1.0 == bd) val = p * dt;         // right neighbour
+            else continue;
+            atomicAdd(&tile[pix - pix0], val);
+          }
         }
       }
     }
