@@ -354,7 +354,9 @@ def main():
 
         _ops.call, _ops._deferred.flush = timed_call, counting_flush
         timer.install()
+        saved_reducer, executor.reducer = executor.reducer, None      # rank-0-only pass: no collective may run in it
         eager_step()
+        executor.reducer = saved_reducer
         timer.remove()
         _ops.call, _ops._deferred.flush = orig_call, orig_flush
         ks = timer.summary()

@@ -147,18 +147,15 @@ def require_device():
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-_dev_index = None
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 def stream_ptr():
     """hipStream_t of torch's current stream on the current device (the raw-stream accessor is ~5x cheaper than building a
     torch.cuda.Stream object; an eager step calls this ~900 times)."""
-    global _dev_index
-    if _raw_stream is None:
+    if _raw_stream is None or _get_device is None:
         return torch.cuda.current_stream().cuda_stream
-    if _dev_index is None:
-        _dev_index = torch.cuda.current_device()
-    return _raw_stream(_dev_index)
+    return _raw_stream(_get_device())
 
 
 def call(name, *args):
