@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 EVP_F32, EVP_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_DGELU, ACT_RELU, ACT_DRELU = 0, 1, 2, 3, 4
 
-_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_vp, _i, _i64, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 
 
 class GemmDesc(C.Structure):
@@ -32,7 +32,9 @@ class GemmDesc(C.Structure):
 # name -> argtypes (all return int status unless listed in _OTHER_RESTYPE)
 SIGNATURES = {
     "evp_voxel_scatter_f32": [_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "evp_voxel_scatter_scaled_f32": [_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp],
     "evp_events_sorted_check": [_vp, _vp, _i, _i, _vp, _vp],
+    "evp_events_erase_add_f64": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp],
     "evp_mask_from_noise": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "evp_density_noise": [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "evp_gemm": [C.POINTER(GemmDesc), _vp],

@@ -1,0 +1,166 @@
+// Event-level augmentation on the device: erase rows / add correlated rows, result time-sorted.
+//
+// Restates `erase_and_add_events` of the reference loader (dataset/augmentation/events_augment.py:28-55): drop the rows
+// listed in erase_index, append rows events[add_index] + noise (x and y clipped to the sensor), then sort by the time
+// stamp. The random decisions (how many, which rows, the noise) are drawn by the caller in the reference's order; this
+// file is the data movement. Instead of delete + concatenate + argsort over the whole clip, the kept rows (already
+// time-sorted) and the few added rows (<= 1 % of the clip, sorted here in LDS) are MERGED: every row computes its own
+// output position with two short binary searches and is written once.
+//   position of kept row i      = i - #{erased < i} + #{added with t_add <  t_i}
+//   position of added row j     = j + #{kept rows with t <= t_add_j}
+// (rows with equal stamps: original rows first, in their original order; numpy's argsort leaves that order unspecified).
+// HBM-bound: n*32 B read + n'*32 B written per clip.
+#include "evp_common.h"
+
+namespace {
+
+constexpr int EA_MAX_ADD = 8192;  // added rows per clip the LDS sort holds (1 % of an 819 200-event clip)
+
+struct SortKey {
+  double t;
+  int j;
+};
+__device__ __forceinline__ bool key_less(const SortKey &a, const SortKey &b) { return a.t < b.t || (a.t == b.t && a.j < b.j); }
+
+// one workgroup per clip: gather + perturb + clip the added rows, bitonic-sort them by (t, draw order) in LDS
+__global__ __launch_bounds__(1024) void build_added_kernel(const double *events, const int64_t *clip_offsets, const int64_t *add_idx,
+                                                           const double *add_noise, const int64_t *add_offsets, double sensor_w,
+                                                           double sensor_h, double *add_rows) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  SortKey *keys = reinterpret_cast<SortKey *>(smem_raw);
+  const int c = blockIdx.x;
+  const int64_t a0 = add_offsets[c];
+  const int na = (int)(add_offsets[c + 1] - a0);
+  if (na <= 0) return;
+  const double *ev = events + clip_offsets[c] * 4;
+  int np2 = 1;
+  while (np2 < na) np2 <<= 1;
+  for (int j = threadIdx.x; j < np2; j += blockDim.x) {
+    SortKey k;
+    k.j = j;
+    k.t = j < na ? ev[add_idx[a0 + j] * 4 + 2] + add_noise[(a0 + j) * 3 + 2] : __builtin_inf();
+    keys[j] = k;
+  }
+  __syncthreads();
+  for (int size = 2; size <= np2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+        const int partner = i ^ stride;
+        if (partner > i) {
+          const bool up = (i & size) == 0;
+          const SortKey a = keys[i], b = keys[partner];
+          if (key_less(b, a) == up) {
+            keys[i] = b;
+            keys[partner] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int r = threadIdx.x; r < na; r += blockDim.x) {
+    const int j = keys[r].j;
+    const double *src = ev + add_idx[a0 + j] * 4;
+    const double *nz = add_noise + (a0 + j) * 3;
+    double x = src[0] + nz[0], y = src[1] + nz[1];
+    x = fmin(fmax(x, 0.0), sensor_w - 1.0);  // np.clip(., 0, sensor_w - 1), events_augment.py:46-47
+    y = fmin(fmax(y, 0.0), sensor_h - 1.0);
+    double *dst = add_rows + (a0 + r) * 4;
+    dst[0] = x;
+    dst[1] = y;
+    dst[2] = keys[r].t;
+    dst[3] = src[3];
+  }
+}
+
+// first index in [0, n) with a[idx] >= v (int64 keys)
+__device__ __forceinline__ int lower_bound_i64(const int64_t *a, int n, int64_t v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// grid (chunks, clips): kept rows and added rows scatter themselves to their merged positions
+__global__ __launch_bounds__(256) void merge_kernel(const double *events, const int64_t *clip_offsets, const int64_t *erase_idx,
+                                                    const int64_t *erase_offsets, const int64_t *add_offsets, const double *add_rows,
+                                                    const int64_t *out_offsets, double *out) {
+  const int c = blockIdx.y;
+  const int64_t beg = clip_offsets[c], n = clip_offsets[c + 1] - beg;
+  const int64_t e0 = erase_offsets[c];
+  const int ne = (int)(erase_offsets[c + 1] - e0);
+  const int64_t a0 = add_offsets[c];
+  const int na = (int)(add_offsets[c + 1] - a0);
+  const double *ev = events + beg * 4;
+  const int64_t *er = erase_idx + e0;
+  const double *ad = add_rows + a0 * 4;
+  double *dst = out + out_offsets[c] * 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = tid; i < n; i += stride) {
+    const double2 r0 = *reinterpret_cast<const double2 *>(ev + i * 4);
+    const double2 r1 = *reinterpret_cast<const double2 *>(ev + i * 4 + 2);
+    const int e = lower_bound_i64(er, ne, i);
+    if (e < ne && er[e] == i) continue;  // erased
+    int lo = 0, hi = na;                  // added rows with t_add < t_i
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (ad[mid * 4 + 2] < r1.x) lo = mid + 1;
+      else hi = mid;
+    }
+    double *o = dst + (i - e + lo) * 4;
+    *reinterpret_cast<double2 *>(o) = r0;
+    *reinterpret_cast<double2 *>(o + 2) = r1;
+  }
+  for (int64_t j = tid; j < na; j += stride) {
+    const double t = ad[j * 4 + 2];
+    int64_t lo = 0, hi = n;  // original rows with t_i <= t
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (ev[mid * 4 + 2] <= t) lo = mid + 1;
+      else hi = mid;
+    }
+    const int64_t kept = lo - lower_bound_i64(er, ne, lo);
+    double *o = dst + (j + kept) * 4;
+    o[0] = ad[j * 4 + 0];
+    o[1] = ad[j * 4 + 1];
+    o[2] = t;
+    o[3] = ad[j * 4 + 3];
+  }
+}
+
+}  // namespace
+
+extern "C" int evp_events_erase_add_f64(const double *events, const int64_t *clip_offsets, int n_clips, const int64_t *erase_idx,
+                                        const int64_t *erase_offsets, const int64_t *add_idx, const double *add_noise,
+                                        const int64_t *add_offsets, int max_add_per_clip, double sensor_w, double sensor_h,
+                                        double *add_rows_ws, const int64_t *out_offsets, double *out_events, void *stream) {
+  EVP_CHECK_ARG(events && clip_offsets && erase_offsets && add_offsets && out_offsets && out_events, EVP_EINVAL,
+                "evp_events_erase_add_f64: null pointer");
+  EVP_CHECK_ARG(n_clips > 0, EVP_ESHAPE, "evp_events_erase_add_f64: n_clips must be positive");
+  EVP_CHECK_ARG(max_add_per_clip >= 0 && max_add_per_clip <= EA_MAX_ADD, EVP_ESHAPE,
+                "evp_events_erase_add_f64: at most %d added rows per clip (got %d)", EA_MAX_ADD, max_add_per_clip);
+  EVP_CHECK_ARG(max_add_per_clip == 0 || (add_idx && add_noise && add_rows_ws), EVP_EINVAL,
+                "evp_events_erase_add_f64: add_idx, add_noise and the workspace are required when rows are added");
+  EVP_CHECK_ARG((((uintptr_t)events | (uintptr_t)out_events) & 15) == 0, EVP_EINVAL,
+                "evp_events_erase_add_f64: event buffers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (max_add_per_clip > 0) {
+    int np2 = 1;
+    while (np2 < max_add_per_clip) np2 <<= 1;
+    const size_t smem = (size_t)np2 * sizeof(SortKey);
+    if (smem > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(build_added_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_events_erase_add_f64: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(build_added_kernel, dim3(n_clips), dim3(1024), smem, s, events, clip_offsets, add_idx, add_noise, add_offsets,
+                       sensor_w, sensor_h, add_rows_ws);
+    EVP_CHECK_LAUNCH("evp_events_erase_add_f64(build)");
+  }
+  hipLaunchKernelGGL(merge_kernel, dim3(64, n_clips), dim3(256), 0, s, events, clip_offsets, erase_idx, erase_offsets, add_offsets,
+                     add_rows_ws, out_offsets, out_events);
+  EVP_CHECK_LAUNCH("evp_events_erase_add_f64(merge)");
+  return EVP_OK;
+}

@@ -19,12 +19,14 @@ namespace {
 
 struct Event { double x, y, t, p; };
 // rows are (x,y,t,p), or (t,x,y,p) when is_txyp (events_to_voxel_grid.py:14-34)
-__device__ __forceinline__ Event load_event(const double *ev, int64_t i, int is_txyp) {
+// sx, sy: the sensor -> input rescale of the loader (events_augment.py:22-26), applied to x and y in float64 before the
+// truncation exactly as `events[:, 0] *= input_w / sensor_w` does (1.0 = none; x * 1.0 is x)
+__device__ __forceinline__ Event load_event(const double *ev, int64_t i, int is_txyp, double sx, double sy) {
   const double2 a = *reinterpret_cast<const double2 *>(ev + i * 4);
   const double2 b = *reinterpret_cast<const double2 *>(ev + i * 4 + 2);
   Event e;
-  e.x = is_txyp ? a.y : a.x;
-  e.y = is_txyp ? b.x : a.y;
+  e.x = (is_txyp ? a.y : a.x) * sx;
+  e.y = (is_txyp ? b.x : a.y) * sy;
   e.t = is_txyp ? a.x : b.x;
   e.p = b.y;
   return e;
@@ -108,7 +110,7 @@ __device__ __forceinline__ bool in_safe_range(double v) {
 template <bool TXYP>
 __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *events, const int64_t *offsets, const int64_t *cuts,
                                                                int n_clips, int bins, int H, int W, int assume_sorted, int tile_rows,
-                                                               int n_yt, float *out) {
+                                                               int n_yt, double sx, double sy, float *out) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float *tile = reinterpret_cast<float *>(smem_raw);
   const int n_j = bins > 1 ? bins - 1 : 1;
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *eve
           }
   #pragma unroll
           for (int u = 0; u < VB_UNROLL; ++u) {
-            const double x = TXYP ? ra[u].y : ra[u].x, y = TXYP ? rb[u].x : ra[u].y;
+            const double x = (TXYP ? ra[u].y : ra[u].x) * sx, y = (TXYP ? rb[u].x : ra[u].y) * sy;
             const double t = TXYP ? ra[u].x : rb[u].x, pd = rb[u].y;
             int64_t pix;
             if (__builtin_fabs(x) < 2147483648.0 && __builtin_fabs(y) < 2147483648.0)
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *eve
 // val_left = p*(1-dt), val_right = p*dt. Pass B (one workgroup per clip x bin x y-tile, tile in LDS) then only reads
 // the 4-byte key of every event of its slab and touches a value only when the event lands in its tile.
 constexpr uint32_t KEY_INVALID = 0x80000000u;
-__global__ __launch_bounds__(256) void voxel_pack_kernel(const double *events, const int64_t *offsets, int bins, int H, int W, int is_txyp,
+__global__ __launch_bounds__(256) void voxel_pack_kernel(const double *events, const int64_t *offsets, int bins, int H, int W, int is_txyp, double sx, double sy,
                                                          uint32_t *keys, float *vleft, float *vright) {
   const int clip = blockIdx.y;
   const int64_t beg = offsets[clip], n = offsets[clip + 1] - beg;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256) void voxel_pack_kernel(const double *events, c
   if (dT == 0) dT = 1.0;
   const int64_t plane = (int64_t)H * W;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const Event e = load_event(ev, i, is_txyp);
+    const Event e = load_event(ev, i, is_txyp, sx, sy);
     const double ts = ts_of(e.t, t0, dT, bins);
     const double tf = floor(ts);
     float p = (float)e.p;
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_packed_kernel(const uint
 
 // algo 1: two global float atomics per event into a pre-zeroed grid
 __global__ __launch_bounds__(256) void voxel_atomic_kernel(const double *events, const int64_t *offsets, int bins, int H, int W,
-                                                           int is_txyp, float *out) {
+                                                           int is_txyp, double sx, double sy, float *out) {
   const int clip = blockIdx.y;
   const int64_t beg = offsets[clip], n = offsets[clip + 1] - beg;
   if (n <= 0) return;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(256) void voxel_atomic_kernel(const double *events,
   const int64_t plane = (int64_t)H * W;
   float *grid = out + (int64_t)clip * bins * plane;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const Event e = load_event(ev, i, is_txyp);
+    const Event e = load_event(ev, i, is_txyp, sx, sy);
     const double ts = ts_of(e.t, t0, dT, bins);
     const double tf = floor(ts);
     if (!(tf >= 0.0)) continue;
@@ -335,9 +337,9 @@ __global__ __launch_bounds__(256) void sorted_check_kernel(const double *events,
 
 }  // namespace
 
-extern "C" int evp_voxel_scatter_f32(const double *events, const int64_t *clip_offsets, int n_clips, int64_t n_events_total, int bins,
-                                     int H, int W, int is_txyp, int assume_sorted, int algo, int tile_rows, int64_t *workspace,
-                                     float *out, void *stream) {
+extern "C" int evp_voxel_scatter_scaled_f32(const double *events, const int64_t *clip_offsets, int n_clips, int64_t n_events_total,
+                                            int bins, int H, int W, int is_txyp, int assume_sorted, int algo, int tile_rows,
+                                            double scale_x, double scale_y, int64_t *workspace, float *out, void *stream) {
   EVP_CHECK_ARG(events && clip_offsets && out, EVP_EINVAL, "evp_voxel_scatter_f32: null pointer");
   EVP_CHECK_ARG(n_clips > 0 && bins > 0 && bins <= 64 && H > 0 && W > 0, EVP_ESHAPE,
                 "evp_voxel_scatter_f32: need n_clips>0, 0<bins<=64, H,W>0 (got %d,%d,%d,%d)", n_clips, bins, H, W);
@@ -346,7 +348,8 @@ extern "C" int evp_voxel_scatter_f32(const double *events, const int64_t *clip_o
   if (algo == 1) {
     hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)n_clips * bins * H * W, s);
     EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_voxel_scatter_f32: memset failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(voxel_atomic_kernel, dim3(64, n_clips), dim3(256), 0, s, events, clip_offsets, bins, H, W, is_txyp, out);
+    hipLaunchKernelGGL(voxel_atomic_kernel, dim3(64, n_clips), dim3(256), 0, s, events, clip_offsets, bins, H, W, is_txyp, scale_x,
+                       scale_y, out);
     EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(atomic)");
     return EVP_OK;
   }
@@ -370,7 +373,8 @@ extern "C" int evp_voxel_scatter_f32(const double *events, const int64_t *clip_o
   if (algo == 2) {
     uint32_t *keys = reinterpret_cast<uint32_t *>(workspace + (int64_t)n_clips * (bins + 2));
     float *vl = reinterpret_cast<float *>(keys + n_events_total), *vr = vl + n_events_total;
-    hipLaunchKernelGGL(voxel_pack_kernel, dim3(64, n_clips), dim3(256), 0, s, events, clip_offsets, bins, H, W, is_txyp, keys, vl, vr);
+    hipLaunchKernelGGL(voxel_pack_kernel, dim3(64, n_clips), dim3(256), 0, s, events, clip_offsets, bins, H, W, is_txyp, scale_x,
+                       scale_y, keys, vl, vr);
     EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(pack)");
     if (smem > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(voxel_bin_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -389,12 +393,19 @@ extern "C" int evp_voxel_scatter_f32(const double *events, const int64_t *clip_o
   const int n_blocks = n_clips * (bins > 1 ? bins - 1 : 1) * n_yt;  // plane 0 and plane bins-1 share a workgroup
   if (is_txyp)
     hipLaunchKernelGGL(voxel_bin_kernel<true>, dim3(n_blocks), dim3(VB_THREADS), smem, s, events, clip_offsets, workspace, n_clips, bins, H,
-                       W, assume_sorted, tile_rows, n_yt, out);
+                       W, assume_sorted, tile_rows, n_yt, scale_x, scale_y, out);
   else
     hipLaunchKernelGGL(voxel_bin_kernel<false>, dim3(n_blocks), dim3(VB_THREADS), smem, s, events, clip_offsets, workspace, n_clips, bins, H,
-                       W, assume_sorted, tile_rows, n_yt, out);
+                       W, assume_sorted, tile_rows, n_yt, scale_x, scale_y, out);
   EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(bin)");
   return EVP_OK;
+}
+
+extern "C" int evp_voxel_scatter_f32(const double *events, const int64_t *clip_offsets, int n_clips, int64_t n_events_total, int bins,
+                                     int H, int W, int is_txyp, int assume_sorted, int algo, int tile_rows, int64_t *workspace,
+                                     float *out, void *stream) {
+  return evp_voxel_scatter_scaled_f32(events, clip_offsets, n_clips, n_events_total, bins, H, W, is_txyp, assume_sorted, algo, tile_rows,
+                                      1.0, 1.0, workspace, out, stream);
 }
 
 extern "C" int evp_events_sorted_check(const double *events, const int64_t *clip_offsets, int n_clips, int is_txyp,

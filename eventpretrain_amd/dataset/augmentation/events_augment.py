@@ -1,0 +1,131 @@
+"""Event-level augmentation on the GPU behind the reference's function names (reference
+dataset/augmentation/events_augment.py): window pick `get_random_index` (:5-20), sensor -> input rescale `events_reshape`
+(:22-26), erase / add-correlated-events `erase_and_add_events` (:28-55) and `events_augment` (:80-86).
+
+Split as in view_augment.py: the random DECISIONS are drawn on the host from the legacy numpy stream in the reference's
+exact call order (so `np.random.seed(seed)` reproduces the reference's augmented clip bit for bit -- pinned by
+tests/golden/events_augment.npz), the DATA MOVEMENT runs on the device (csrc/events.hip: the few added rows are sorted in
+LDS and merged into the already time-sorted kept rows; no delete / concatenate / argsort of the whole clip).
+
+`events_augment_batch` handles a batch of clips resident in HBM in two launches; together with
+`voxel_grid_batch(..., scale=(sx, sy))` (the rescale fused into K1) and `view_augment.evg_augment_batch` this is the
+loader's chain events -> events_augment -> events_reshape -> events_to_voxel_grid -> evg_augment
+(pr_n_imagenet_dataset.py:82-89) without leaving the GPU."""
+import numpy as np
+import torch
+
+from ... import _lib
+from ..._lib import call, ptr, stream_ptr
+
+MAX_ADD_PER_CLIP = 8192     # csrc/events.hip: the added rows of one clip are sorted in LDS
+
+
+def get_random_index(args, events, is_train, seed=None):
+    """Window of at most args.fix_events_num (train) / args.val_fix_events_num rows, start drawn from np.random
+    (events_augment.py:5-20). Returns [start, end). Host-only: slicing a device tensor with it is free."""
+    if seed is not None:
+        np.random.seed(seed)
+    fix_events_num = args.fix_events_num if is_train else args.val_fix_events_num
+    n = int(events.shape[0])
+    if n > fix_events_num:
+        start_index = np.random.randint(0, n - fix_events_num)
+        return start_index, start_index + fix_events_num
+    return 0, n
+
+
+def events_reshape(events, sensor_w, sensor_h, input_w, input_h):
+    """x *= input_w / sensor_w, y *= input_h / sensor_h in place (float64; events_augment.py:22-26). Works on numpy
+    arrays and on device tensors; in the batched pipeline pass scale=(input_w / sensor_w, input_h / sensor_h) to
+    voxel_grid_batch instead -- K1 applies it while it reads the rows."""
+    events[:, 0] *= (input_w / sensor_w)
+    events[:, 1] *= (input_h / sensor_h)
+    return events
+
+
+def draw_erase_add(n, rs=None):
+    """Decisions of erase_and_add_events for a clip of n rows, in the reference's draw order (events_augment.py:31-44):
+    erase count, erased rows, add count, the three normal noise columns for ALL n rows, added rows. `rs`: a
+    numpy.random.RandomState, default the process-global legacy stream (what the reference uses).
+    Returns None for n < 100 (`int(0.01 n) == 0`: the reference leaves such clips alone), else
+    (erase_index int64 [E] ascending, add_index int64 [A], add_noise float64 [A,3])."""
+    rs = np.random if rs is None else rs
+    if int(0.01 * n) <= 0:
+        return None
+    lo, hi = int(0.001 * n), int(0.01 * n)
+    erase_num = rs.randint(lo, hi)
+    erase_index = np.sort(rs.choice(np.arange(n), size=erase_num, replace=False))
+    add_num = rs.randint(lo, hi)
+    nx = rs.normal(0, 1.5, size=(n, 1))
+    ny = rs.normal(0, 1.5, size=(n, 1))
+    nt = rs.normal(0, 0.001, size=(n, 1))
+    add_index = rs.choice(np.arange(n), size=add_num, replace=False)
+    noise = np.concatenate((nx[add_index], ny[add_index], nt[add_index]), 1)
+    return erase_index.astype(np.int64), add_index.astype(np.int64), np.ascontiguousarray(noise, dtype=np.float64)
+
+
+def events_augment_batch(events, clip_offsets, decisions, size):
+    """events: float64 CUDA tensor [n_total,4] (x,y,t,p), every clip time-sorted; clip_offsets: int64 host sequence /
+    array [n_clips+1]; decisions: one `draw_erase_add` result (or None) per clip; size = (sensor_h, sensor_w).
+    Returns (augmented events float64 CUDA [n_total',4], new clip_offsets int64 CUDA [n_clips+1])."""
+    _lib.require_device()
+    if not events.is_cuda or events.dtype != torch.float64 or events.dim() != 2 or events.shape[1] != 4 or not events.is_contiguous():
+        raise _lib.EvpError("events_augment_batch: events must be a contiguous float64 [N,4] tensor in device memory")
+    offs = np.asarray(clip_offsets.cpu() if torch.is_tensor(clip_offsets) else clip_offsets, dtype=np.int64)
+    n_clips = offs.shape[0] - 1
+    if len(decisions) != n_clips:
+        raise _lib.EvpError("events_augment_batch: one decision entry per clip")
+    dev = events.device
+    er_l, ai_l, nz_l = [], [], []
+    er_off, ad_off, out_off = np.zeros(n_clips + 1, np.int64), np.zeros(n_clips + 1, np.int64), np.zeros(n_clips + 1, np.int64)
+    max_add = 0
+    for c, d in enumerate(decisions):
+        n = int(offs[c + 1] - offs[c])
+        e = a = 0
+        if d is not None:
+            er, ai, nz = d
+            if er.size and (er[0] < 0 or er[-1] >= n or np.any(np.diff(er) <= 0)):
+                raise _lib.EvpError("events_augment_batch: erase_index of clip %d must be strictly ascending inside [0, %d)" % (c, n))
+            if ai.size and (ai.min() < 0 or ai.max() >= n):
+                raise _lib.EvpError("events_augment_batch: add_index of clip %d out of range" % c)
+            e, a = int(er.size), int(ai.size)
+            er_l.append(er), ai_l.append(ai), nz_l.append(nz.reshape(-1, 3))
+        max_add = max(max_add, a)
+        er_off[c + 1], ad_off[c + 1], out_off[c + 1] = er_off[c] + e, ad_off[c] + a, out_off[c] + n - e + a
+    if max_add > MAX_ADD_PER_CLIP:
+        raise _lib.EvpError("events_augment_batch: at most %d added rows per clip (got %d)" % (MAX_ADD_PER_CLIP, max_add))
+
+    def up(parts, dtype, shape):
+        arr = np.concatenate(parts) if parts else np.zeros(shape, dtype)
+        return torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype)).to(dev)
+
+    # one packed upload for the index tables
+    er_d, ai_d, nz_d = up(er_l, np.int64, (0,)), up(ai_l, np.int64, (0,)), up(nz_l, np.float64, (0, 3))
+    tabs = torch.from_numpy(np.stack([offs, er_off, ad_off, out_off])).to(dev)
+    n_add, n_out = int(ad_off[-1]), int(out_off[-1])
+    ws = torch.empty(max(n_add, 1), 4, dtype=torch.float64, device=dev)
+    out = torch.empty(n_out, 4, dtype=torch.float64, device=dev)
+    call("evp_events_erase_add_f64", ptr(events), ptr(tabs[0]), n_clips, ptr(er_d), ptr(tabs[1]), ptr(ai_d), ptr(nz_d), ptr(tabs[2]),
+         max_add, float(size[1]), float(size[0]), ptr(ws), ptr(tabs[3]), ptr(out), stream_ptr())
+    return out, tabs[3]
+
+
+def erase_and_add_events(args, events, size=None):
+    """Drop-in for the reference function (events_augment.py:28-55): events is a numpy float64 [N,4] (x,y,t,p) array or a
+    device tensor, time-sorted; decisions come from the process-global numpy stream like the reference's. Returns the
+    augmented, time-sorted clip in device memory."""
+    _lib.require_device()
+    if not torch.is_tensor(events):
+        events = torch.from_numpy(np.ascontiguousarray(events, dtype=np.float64)).to(torch.device("cuda", torch.cuda.current_device()))
+    n = int(events.shape[0])
+    d = draw_erase_add(n)
+    if d is None:
+        return events
+    out, _ = events_augment_batch(events, [0, n], [d], size)
+    return out
+
+
+def events_augment(args, events, size, seed=None):
+    """Drop-in for events_augment.py:80-86."""
+    if seed is not None:
+        np.random.seed(seed)
+    return erase_and_add_events(args, events, size=size)

@@ -8,7 +8,7 @@ Here they are explicit, host-drawn int32 rows {x0, y0, w, h, hflip, tflip}:
     `RandomState(seed)` reproduces `evg_augment(..., seed=seed)` bit for bit (pinned by tests/golden/evg_augment.npz);
   * `draw_evg_params_batch(seed, step, B, ...)` -- a counter-based stream (Philox keyed by (seed, step, sample)): the
     decisions of a sample do not depend on worker scheduling or on how many draws other samples consumed.
-Event-level augmentations (erase / add correlated events, events_augment.py:29-57) stay on the host for now."""
+The event-level augmentations (erase / add correlated events) are in events_augment.py next to this file."""
 import math
 
 import numpy as np

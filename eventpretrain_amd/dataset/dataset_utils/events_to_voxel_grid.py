@@ -8,9 +8,12 @@ from ... import _lib
 from ..._lib import call, ptr, stream_ptr
 
 
-def voxel_grid_batch(events, clip_offsets, num_bins, size, is_txyp=False, assume_sorted=True, algo=0, tile_rows=0, out=None):
+def voxel_grid_batch(events, clip_offsets, num_bins, size, is_txyp=False, assume_sorted=True, algo=0, tile_rows=0, out=None,
+                     scale=None):
     """events: float64 CUDA tensor [n_total,4]; clip_offsets: int64 CUDA tensor [n_clips+1] -> float32
-    [n_clips, num_bins, H, W]. Rows of each clip must be time-sorted unless assume_sorted=False."""
+    [n_clips, num_bins, H, W]. Rows of each clip must be time-sorted unless assume_sorted=False.
+    scale=(sx, sy): the loader's sensor -> input rescale (reference events_augment.py:22-26, sx = input_w / sensor_w,
+    sy = input_h / sensor_h) applied to x and y inside the kernel, bit-identical to rescaling the array first."""
     _lib.require_device()
     if events.dtype != torch.float64 or events.dim() != 2 or events.shape[1] != 4 or not events.is_contiguous():
         raise _lib.EvpError("events must be a contiguous float64 [N,4] tensor")
@@ -23,8 +26,13 @@ def voxel_grid_batch(events, clip_offsets, num_bins, size, is_txyp=False, assume
         out = torch.empty(n_clips, num_bins, H, W, dtype=torch.float32, device=dev)
     n_total = int(events.shape[0])
     ws = torch.empty(n_clips * (num_bins + 2) + (3 * n_total + 1) // 2 + 2, dtype=torch.int64, device=dev)
-    call("evp_voxel_scatter_f32", ptr(events), ptr(clip_offsets), n_clips, n_total, int(num_bins), H, W, int(bool(is_txyp)),
-         int(bool(assume_sorted)), int(algo), int(tile_rows), ptr(ws), ptr(out), stream_ptr())
+    if scale is None:
+        call("evp_voxel_scatter_f32", ptr(events), ptr(clip_offsets), n_clips, n_total, int(num_bins), H, W, int(bool(is_txyp)),
+             int(bool(assume_sorted)), int(algo), int(tile_rows), ptr(ws), ptr(out), stream_ptr())
+    else:
+        call("evp_voxel_scatter_scaled_f32", ptr(events), ptr(clip_offsets), n_clips, n_total, int(num_bins), H, W,
+             int(bool(is_txyp)), int(bool(assume_sorted)), int(algo), int(tile_rows), float(scale[0]), float(scale[1]), ptr(ws),
+             ptr(out), stream_ptr())
     return out
 
 

@@ -52,6 +52,28 @@ const char *evp_target_arch(void);
 int evp_voxel_scatter_f32(const double *events, const int64_t *clip_offsets, int n_clips, int64_t n_events_total, int bins,
                           int H, int W, int is_txyp, int assume_sorted, int algo, int tile_rows, int64_t *workspace,
                           float *out, void *stream);
+/* The same with the loader's sensor -> input rescale fused in (reference dataset/augmentation/events_augment.py:22-26,
+ * `events[:,0] *= input_w/sensor_w; events[:,1] *= input_h/sensor_h`, applied by pr_n_imagenet_dataset.py:85-86 between
+ * the event-level augmentation and the voxelisation): x and y are multiplied by scale_x / scale_y in float64 before
+ * the truncation, bit-identical to rescaling the array first. scale 1.0 = evp_voxel_scatter_f32. */
+int evp_voxel_scatter_scaled_f32(const double *events, const int64_t *clip_offsets, int n_clips, int64_t n_events_total,
+                                 int bins, int H, int W, int is_txyp, int assume_sorted, int algo, int tile_rows,
+                                 double scale_x, double scale_y, int64_t *workspace, float *out, void *stream);
+/* Event-level augmentation, data movement (reference dataset/augmentation/events_augment.py:28-55
+ * `erase_and_add_events`): for every clip drop the rows erase_idx lists, add the rows
+ * events[add_idx[j]] + add_noise[j] (x, y, t; x clipped to [0, sensor_w-1], y to [0, sensor_h-1]; p copied) and keep the
+ * clip time-sorted. Input clips must be time-sorted (x,y,t,p) rows; the random decisions are the caller's, drawn in the
+ * reference's order (host side: eventpretrain_amd/dataset/augmentation/events_augment.py).
+ * erase_idx: int64, clip-relative, strictly ascending inside [erase_offsets[c], erase_offsets[c+1]);
+ * add_idx: int64 clip-relative [A_total]; add_noise: float64 [A_total,3]; add_offsets: int64 [n_clips+1];
+ * max_add_per_clip <= 8192 (the added rows of a clip are sorted in LDS); add_rows_ws: float64 [A_total,4];
+ * out_offsets: int64 [n_clips+1], out_offsets[c+1]-out_offsets[c] = n_c - erased_c + added_c;
+ * out_events: float64 [out_offsets[n_clips],4]. Rows with equal stamps: original rows first (numpy's argsort leaves
+ * their order unspecified). */
+int evp_events_erase_add_f64(const double *events, const int64_t *clip_offsets, int n_clips, const int64_t *erase_idx,
+                             const int64_t *erase_offsets, const int64_t *add_idx, const double *add_noise,
+                             const int64_t *add_offsets, int max_add_per_clip, double sensor_w, double sensor_h,
+                             double *add_rows_ws, const int64_t *out_offsets, double *out_events, void *stream);
 /* sorted_flags[c] = 1 if clip c's stamps are non-decreasing, else 0 (device int32 [n_clips]). */
 int evp_events_sorted_check(const double *events, const int64_t *clip_offsets, int n_clips, int is_txyp,
                             int32_t *sorted_flags, void *stream);

@@ -57,3 +57,47 @@ def evg_transform(view, params, out_hw, negate=True):
         if negate:
             out = -out
     return np.ascontiguousarray(out, dtype=np.float32)
+
+
+# ---- event-level augmentation (dataset/augmentation/events_augment.py) ------------------------------------------------
+def draw_erase_add(rs, n):
+    """The decisions of erase_and_add_events (events_augment.py:31-44) from a numpy RandomState `rs`, in the reference's
+    call order: erase count, erased rows (sorted), add count, three per-row normal noise columns (x: sd 1.5, y: sd 1.5,
+    t: sd 0.001 -- drawn for ALL n rows, as the reference does), added rows. Returns None when the clip is too short
+    (`int(0.01 n) == 0`), else (erase_index int64 [E] ascending, add_index int64 [A], add_noise float64 [A,3])."""
+    if int(0.01 * n) <= 0:
+        return None
+    lo, hi = int(0.001 * n), int(0.01 * n)
+    erase_num = rs.randint(lo, hi)
+    erase_index = np.sort(rs.choice(np.arange(n), size=erase_num, replace=False))
+    add_num = rs.randint(lo, hi)
+    nx = rs.normal(0, 1.5, size=(n, 1))
+    ny = rs.normal(0, 1.5, size=(n, 1))
+    nt = rs.normal(0, 0.001, size=(n, 1))
+    add_index = rs.choice(np.arange(n), size=add_num, replace=False)
+    noise = np.concatenate((nx[add_index], ny[add_index], nt[add_index]), 1)
+    return erase_index.astype(np.int64), add_index.astype(np.int64), np.ascontiguousarray(noise, dtype=np.float64)
+
+
+def erase_add_apply(events, decisions, size):
+    """The deterministic part of erase_and_add_events (events_augment.py:38-53) given the decisions: float64 [n,4]
+    (x,y,t,p) -> float64 [n-E+A,4], time-sorted (stable: on equal stamps original rows first)."""
+    if decisions is None:
+        return events
+    erase_index, add_index, noise = decisions
+    sensor_h, sensor_w = size
+    add = events[add_index].copy()
+    add[:, :3] += noise
+    add[:, 0] = np.clip(add[:, 0], 0, sensor_w - 1)
+    add[:, 1] = np.clip(add[:, 1], 0, sensor_h - 1)
+    kept = np.delete(events, erase_index, axis=0)
+    both = np.concatenate((kept, add))
+    return both[np.argsort(both[:, 2], kind="stable")]
+
+
+def events_reshape(events, sensor_w, sensor_h, input_w, input_h):
+    """events_augment.py:22-26: x *= input_w / sensor_w, y *= input_h / sensor_h (float64)."""
+    out = events.copy()
+    out[:, 0] *= (input_w / sensor_w)
+    out[:, 1] *= (input_h / sensor_h)
+    return out

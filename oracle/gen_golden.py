@@ -547,6 +547,31 @@ def gen_augment():
     save("evg_augment", **out)
 
 
+def gen_evaug():
+    """events_augment -> events_reshape -> events_to_voxel_grid of the reference itself (events_augment.py:80-86, :22-26,
+    pr_n_imagenet_dataset.py:84-87) on seeded sensor-shaped clips; the fixture keeps the clip seeds, the augmented event
+    arrays (small clips) and the voxel grids of the rescaled result."""
+    _ref()
+    from dataset.augmentation.events_augment import events_augment, events_reshape
+    from dataset.dataset_utils.events_to_voxel_grid import events_to_voxel_grid
+    out = {}
+    cases = [("a", 21, 6000, (480, 640), 64), ("b", 22, 3000, (260, 346), 32), ("c", 23, 150, (128, 128), 32), ("d", 24, 60, (128, 128), 32)]
+    for tag, seed, n, (sh, sw), S in cases:
+        rng = np.random.default_rng(5000 + seed)
+        ev = np.stack([np.floor(rng.uniform(0, sw, n)), np.floor(rng.uniform(0, sh, n)), np.sort(rng.uniform(0, 0.05, n)),
+                       rng.integers(0, 2, n).astype(np.float64)], 1)
+        a = make_args(num_bins=5)
+        aug = events_augment(a, ev.copy(), size=(sh, sw), seed=seed)
+        res = events_reshape(aug.copy(), sw, sh, S, S)
+        vox = events_to_voxel_grid(a, res.copy(), size=(S, S))
+        out[f"{tag}_meta"] = np.array([seed, n, sh, sw, S])
+        out[f"{tag}_events_in"] = ev
+        out[f"{tag}_events_out"] = aug
+        out[f"{tag}_voxel"] = vox.numpy() if hasattr(vox, "numpy") else np.asarray(vox)
+    out["tags"] = np.array(json.dumps([c[0] for c in cases]))
+    save("events_augment", **out)
+
+
 def gen_ftcls():
     """Classification fine-tuning step (model/finetune_cls/ft_cls_hub_model.py:118-139 + nn.CrossEntropyLoss,
     trainer/finetune_cls/ft_cls_trainer.py:66) on the ViT-Small and Swin-T hubs, B=2, 10 classes."""
@@ -578,7 +603,7 @@ def gen_ftcls():
 
 
 GENS = dict(voxel=gen_voxel, pos=gen_pos, mask=gen_mask, tiny=lambda: gen_composed("tiny"), small=gen_small,
-            base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall, swin=gen_swin, swincon=gen_swincon, augment=gen_augment, ftcls=gen_ftcls)
+            base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall, swin=gen_swin, swincon=gen_swincon, augment=gen_augment, evaug=gen_evaug, ftcls=gen_ftcls)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -334,6 +334,24 @@ FT_CFG = {"vit_small": dict(backbone="vit", patch=16, heads=12),
           "swin_tiny": dict(backbone="swin", input=224, window=7, depths=[2, 2, 6, 2], heads=[3, 6, 12, 24])}
 
 
+def test_events_augment_matches_reference():
+    """Event-level augmentation (erase rows, add correlated rows, re-sort), the sensor -> input rescale and the voxel grid
+    of the result: the oracle's decision stream + merge against the reference's events_augment / events_reshape /
+    events_to_voxel_grid under np.random.seed (bit-exact; fixture clips have distinct stamps)."""
+    from oracle import augment_oracle as ao
+    d = load_golden("events_augment")
+    for tag in jl(d["tags"]):
+        seed, n, sh, sw, S = (int(v) for v in d[tag + "_meta"])
+        ev = d[tag + "_events_in"]
+        dec = ao.draw_erase_add(np.random.RandomState(seed), n)
+        assert (dec is None) == (n < 100), tag
+        out = ao.erase_add_apply(ev, dec, (sh, sw))
+        assert np.array_equal(out, d[tag + "_events_out"]), tag
+        assert np.all(np.diff(out[:, 2]) >= 0)
+        g = voxel_grid(ao.events_reshape(out, sw, sh, S, S), 5, (S, S))
+        assert np.array_equal(g, d[tag + "_voxel"]), tag
+
+
 def ft_state_dict(d, grid=14):
     from eventpretrain_amd.testing import det_value_for
     sd = {}
