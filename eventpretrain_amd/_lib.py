@@ -81,6 +81,7 @@ SIGNATURES = {
     "evp_l2norm_rows_fwd": [_vp, _i64, _i, _vp, _vp, _vp],
     "evp_l2norm_rows_bwd": [_vp, _vp, _vp, _i64, _i, _vp, _vp],
     "evp_cross_entropy": [_vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp],
+    "evp_cross_entropy_smooth": [_vp, _vp, _i64, _i, _i64, _f, _vp, _vp, _vp, _vp],
     "evp_rowdot_f32": [_vp, _vp, _i64, _i, _vp, _vp],
     "evp_scale_rows_f32": [_vp, _vp, _vp, _i64, _i, _vp, _vp],
     "evp_infonce_queue": [_vp, _vp, _i64, _i, _i64, _f, _vp, _vp, _vp, _vp, _vp],

@@ -30,8 +30,10 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float *dy, const 
 }
 
 // one 256-thread block per row (n_cls may be 1+K = 65537)
+// smoothing s > 0: timm's LabelSmoothingCrossEntropy (ft_cls_trainer.py:63-64), per row
+//   (1 - s) * (-log p[label]) + s * (-mean_j log p[j]);   d/dlogit_j = p_j - ((1 - s) [j == label] + s / n_cls)
 __global__ __launch_bounds__(256) void ce_rows_kernel(const float *logits, const int64_t *labels, int64_t R, int n_cls, int64_t ld,
-                                                      float *row_loss, float *dlogits) {
+                                                      float smoothing, float *row_loss, float *dlogits) {
   __shared__ float red[16];
   const int64_t r = blockIdx.x;
   const float *lr = logits + r * ld;
@@ -46,12 +48,21 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float *logits, const
   for (int j = threadIdx.x; j < n_cls; j += 256) s += expf(lr[j] - mx);
   s = block_sum(s, red);
   const int64_t lab = labels[r];
-  if (threadIdx.x == 0) row_loss[r] = (logf(s) + mx) - lr[lab];
+  const float lse = logf(s) + mx;
+  float row = lse - lr[lab];
+  if (smoothing > 0.f) {  // block-uniform
+    float sl = 0.f;
+    for (int j = threadIdx.x; j < n_cls; j += 256) sl += lr[j];
+    __syncthreads();
+    sl = block_sum(sl, red);
+    row = (1.0f - smoothing) * row + smoothing * (lse - sl / (float)n_cls);
+  }
+  if (threadIdx.x == 0) row_loss[r] = row;
   if (dlogits) {
-    const float inv = 1.0f / s, invR = 1.0f / (float)R;
+    const float inv = 1.0f / s, invR = 1.0f / (float)R, off = smoothing / (float)n_cls, on = 1.0f - smoothing;
     float *dr = dlogits + r * ld;
     for (int j = threadIdx.x; j < ld; j += 256)
-      dr[j] = j < n_cls ? (expf(lr[j] - mx) * inv - (j == lab ? 1.f : 0.f)) * invR : 0.f;
+      dr[j] = j < n_cls ? (expf(lr[j] - mx) * inv - ((j == lab ? on : 0.f) + off)) * invR : 0.f;
   }
 }
 __global__ __launch_bounds__(1024) void mean_kernel(const float *v, int64_t n, float *out) {
@@ -150,16 +161,22 @@ extern "C" int evp_l2norm_rows_bwd(const float *dy, const float *y, const float 
   EVP_CHECK_LAUNCH("evp_l2norm_rows_bwd");
   return EVP_OK;
 }
-extern "C" int evp_cross_entropy(const float *logits, const int64_t *labels, int64_t R, int n_cls, int64_t ld, float *loss,
-                                 float *dlogits, float *workspace, void *stream) {
+extern "C" int evp_cross_entropy_smooth(const float *logits, const int64_t *labels, int64_t R, int n_cls, int64_t ld, float smoothing,
+                                        float *loss, float *dlogits, float *workspace, void *stream) {
   EVP_CHECK_ARG(logits && labels && loss && workspace, EVP_EINVAL, "evp_cross_entropy: null pointer");
   EVP_CHECK_ARG(R > 0 && n_cls > 0 && ld >= n_cls && R < 2147483647LL, EVP_ESHAPE, "evp_cross_entropy: bad shape");
+  EVP_CHECK_ARG(smoothing >= 0.f && smoothing < 1.f, EVP_EINVAL, "evp_cross_entropy: smoothing must be in [0, 1) (got %g)", (double)smoothing);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)R), dim3(256), 0, s, logits, labels, R, n_cls, ld, workspace, dlogits);
+  hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)R), dim3(256), 0, s, logits, labels, R, n_cls, ld, smoothing, workspace, dlogits);
   EVP_CHECK_LAUNCH("evp_cross_entropy");
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, workspace, R, loss);
   EVP_CHECK_LAUNCH("evp_cross_entropy(mean)");
   return EVP_OK;
+}
+
+extern "C" int evp_cross_entropy(const float *logits, const int64_t *labels, int64_t R, int n_cls, int64_t ld, float *loss,
+                                 float *dlogits, float *workspace, void *stream) {
+  return evp_cross_entropy_smooth(logits, labels, R, n_cls, ld, 0.f, loss, dlogits, workspace, stream);
 }
 
 extern "C" int evp_rowdot_f32(const float *a, const float *b, int64_t R, int C, float *out, void *stream) {

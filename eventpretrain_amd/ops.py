@@ -1494,16 +1494,18 @@ class TokenMeanFn(torch.autograd.Function):
 
 
 class CrossEntropyFn(torch.autograd.Function):
-    """nn.CrossEntropyLoss()(pred, label) (mean reduction; ft_cls_trainer.py:66) on f32 logits [B, n_cls]."""
+    """nn.CrossEntropyLoss()(pred, label) (mean reduction; ft_cls_trainer.py:66) on f32 logits [B, n_cls]; smoothing > 0:
+    timm's LabelSmoothingCrossEntropy(smoothing)(pred, label) (ft_cls_trainer.py:63-64)."""
 
     @staticmethod
-    def forward(ctx, logits, labels):
+    def forward(ctx, logits, labels, smoothing=0.0):
         B, Cn = logits.shape
         lg = _chk(logits.detach().contiguous(), torch.float32)
         loss = torch.empty(1, dtype=torch.float32, device=lg.device)
         dlog = torch.empty(B, Cn, dtype=torch.float32, device=lg.device)
         ws = torch.empty(B, dtype=torch.float32, device=lg.device)
-        call("evp_cross_entropy", ptr(lg), ptr(_chk(labels.contiguous(), torch.int64)), B, Cn, Cn, ptr(loss), ptr(dlog), ptr(ws), stream_ptr())
+        call("evp_cross_entropy_smooth", ptr(lg), ptr(_chk(labels.contiguous(), torch.int64)), B, Cn, Cn, float(smoothing), ptr(loss),
+             ptr(dlog), ptr(ws), stream_ptr())
         ctx.save_for_backward(dlog)
         return loss.view(())
 
@@ -1512,4 +1514,4 @@ class CrossEntropyFn(torch.autograd.Function):
         (dlog,) = ctx.saved_tensors
         out = dlog.clone()
         call("evp_scale_f32", ptr(out), ptr(_chk(g.contiguous().view(1), torch.float32)), out.numel(), stream_ptr())
-        return out, None
+        return out, None, None

@@ -27,8 +27,6 @@ def _topk_accuracy(pred, label, topk=(1,)):
 def ft_train_one_epoch(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer=None, evrepsl_model=None):
     if evrepsl_model is not None or getattr(args, "use_evrepsl", False):
         raise NotImplementedError("EvRepSL preprocessing is out of scope (SURVEY.md 2)")
-    if getattr(args, "smoothing", 0) > 0:
-        raise NotImplementedError("label smoothing > 0 is not built (main_finetune_cls.py:154 defaults to 0)")
     model.train(True)
     logger = misc.MetricLogger(delimiter="  ")
     logger.add_meter("lr", misc.SmoothedValue(window_size=1, fmt="{value:.6f}"))
@@ -43,7 +41,8 @@ def ft_train_one_epoch(args, model, data_loader, optimizer, epoch, loss_scaler, 
         events_voxel_grid = events_voxel_grid.to(args.device, non_blocking=True)
         label = label.to(args.device, non_blocking=True)
         _, pred = _forward(args, model, events_voxel_grid)
-        loss_cls = ops.CrossEntropyFn.apply(pred, label)
+        # nn.CrossEntropyLoss, or timm's LabelSmoothingCrossEntropy when args.smoothing > 0 (reference :63-66)
+        loss_cls = ops.CrossEntropyFn.apply(pred, label, float(getattr(args, "smoothing", 0) or 0))
         if args.backward:
             loss_cls = loss_cls / args.accum_iter
             step_now = (it + 1) % args.accum_iter == 0

@@ -204,9 +204,22 @@ class NativeScalerWithGradNormCount:
         loss.backward(create_graph=create_graph)
         if not update_grad:
             return None
-        if clip_grad is not None:
-            raise NotImplementedError("gradient clipping is not used by the pre-training recipe")
         norm = get_grad_norm_(parameters, optimizer=optimizer)
+        if clip_grad is not None:
+            # torch.nn.utils.clip_grad_norm_(parameters, clip_grad) (reference utils/misc.py:289-290): every gradient times
+            # min(1, clip / (total_norm + 1e-6)). The factor rides on FusedAdamW's grad_scale for this step (the kernel
+            # multiplies each gradient by it as it reads it) instead of a pass over the gradients; the returned norm is
+            # the pre-clip total norm, as clip_grad_norm_ returns.
+            coef = min(1.0, float(clip_grad) / (float(norm) + 1e-6))
+            if hasattr(optimizer, "grad_scale"):
+                saved = optimizer.grad_scale
+                optimizer.grad_scale = saved * coef
+                try:
+                    optimizer.step()
+                finally:
+                    optimizer.grad_scale = saved
+                return norm
+            torch.nn.utils.clip_grad_norm_(parameters, clip_grad)
         optimizer.step()
         return norm
 

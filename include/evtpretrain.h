@@ -304,6 +304,12 @@ int evp_l2norm_rows_bwd(const float *dy, const float *y, const float *norm, int6
  * workspace float32 [R]. */
 int evp_cross_entropy(const float *logits, const int64_t *labels, int64_t R, int n_cls, int64_t ld, float *loss,
                       float *dlogits, float *workspace, void *stream);
+/* The same with label smoothing s in [0,1): timm 0.3.2 `LabelSmoothingCrossEntropy(smoothing=s)` as the reference's
+ * fine-tune loop applies it (trainer/finetune_cls/ft_cls_trainer.py:63-64; timm is not vendored in the reference, its
+ * published formula is restated): per row (1-s)*(-log p[label]) + s*(-mean_j log p[j]), mean over rows;
+ * dlogits = (softmax - ((1-s)*onehot + s/n_cls))/R. s = 0 is evp_cross_entropy. */
+int evp_cross_entropy_smooth(const float *logits, const int64_t *labels, int64_t R, int n_cls, int64_t ld, float smoothing,
+                             float *loss, float *dlogits, float *workspace, void *stream);
 
 /* out[r] = <a[r,:], b[r,:]> (the positive logits l_pos of pr_hub_model.py:151) and out[r,c] = s[r]*x[r,c] (+ add). */
 int evp_rowdot_f32(const float *a, const float *b, int64_t R, int C, float *out, void *stream);

@@ -554,6 +554,23 @@ def ft_cls_step(sd, x, label, cfg):
     return F.cross_entropy(pred, label), pred, emb_h, attn
 
 
+def label_smoothing_ce(pred, label, smoothing):
+    """timm 0.3.2 `LabelSmoothingCrossEntropy(smoothing)` as trainer/finetune_cls/ft_cls_trainer.py:63-64 applies it. timm
+    is a pip dependency that is absent from /root/reference and from this image; its published forward is restated:
+    logp = log_softmax(x); loss = ((1-s) * -logp[label] + s * -logp.mean(-1)).mean(). Parity unpinned by a reference
+    fixture; cross-checked against torch's F.cross_entropy(label_smoothing=s), the same formula
+    (tests/test_oracle_golden.py)."""
+    logp = F.log_softmax(pred, dim=-1)
+    nll = -logp.gather(-1, label.view(-1, 1)).squeeze(1)
+    smooth = -logp.mean(dim=-1)
+    return ((1.0 - smoothing) * nll + smoothing * smooth).mean()
+
+
+def clip_coef(total_norm, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (reference utils/misc.py:289-290): factor applied to every gradient."""
+    return min(1.0, max_norm / (total_norm + 1e-6))
+
+
 # ----------------------------------------------------------------------------- optimiser-side glue
 def cosine_lr(epoch, lr, min_lr, warmup_epochs, epochs):
     """utils/lr_sched.py:3-16."""

@@ -75,3 +75,44 @@ def test_ft_cls_epoch_loops_learn_and_evaluate():
         ops.set_compute_dtype(torch.float32)
     assert math.isfinite(hist[-1]) and hist[-1] < 0.7 * hist[0], hist
     assert set(stats) == {"loss_cls", "acc1", "acc5"} and stats["acc1"] >= 50.0 and stats["acc5"] == 100.0
+
+
+def test_label_smoothing_and_grad_clipping():
+    """evp_cross_entropy_smooth through the C-ABI against the oracle's restated LabelSmoothingCrossEntropy (loss and
+    logits gradient, f32: 1e-5 rel), and NativeScalerWithGradNormCount(clip_grad=c): one FusedAdamW step equals the
+    oracle's AdamW update of gradients scaled by min(1, c / (norm + 1e-6)); the returned norm is the pre-clip norm."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.optim import FusedAdamW
+    from eventpretrain_amd.utils.misc import NativeScalerWithGradNormCount
+    from oracle import model_oracle as mo
+    g = torch.Generator().manual_seed(11)
+    for n_cls in (10, 101, 1000):
+        pred = (torch.randn(6, n_cls, generator=g) * 2).requires_grad_(True)
+        label = torch.randint(0, n_cls, (6,), generator=g)
+        for s_ in (0.0, 0.1):
+            ref = mo.label_smoothing_ce(pred.double(), label, s_)
+            (gref,) = torch.autograd.grad(ref, pred)
+            p2 = pred.detach().cuda().requires_grad_(True)
+            out = ops.CrossEntropyFn.apply(p2, label.cuda(), s_)
+            out.backward()
+            assert abs(out.item() - ref.item()) <= 1e-5 * abs(ref.item()), (n_cls, s_)
+            assert torch.allclose(p2.grad.cpu(), gref.float(), rtol=1e-4, atol=1e-7), (n_cls, s_)
+
+    w0 = torch.randn(32, 16, generator=g)
+    b0 = torch.randn(32, generator=g)
+    x = torch.randn(8, 16, generator=g)
+    for clip in (0.05, 1e6):
+        w = torch.nn.Parameter(w0.clone().cuda())
+        b = torch.nn.Parameter(b0.clone().cuda())
+        opt = FusedAdamW([{"params": [w], "weight_decay": 0.05}, {"params": [b], "weight_decay": 0.0}], lr=1e-2, betas=(0.9, 0.95))
+        loss = (torch.nn.functional.linear(x.cuda(), w, b) ** 2).mean()
+        norm = NativeScalerWithGradNormCount()(loss, opt, clip_grad=clip, parameters=[w, b])
+        gw, gb = w.grad.cpu(), b.grad.cpu()
+        total = mo.grad_norm([gw, gb])
+        assert abs(float(norm) - float(total)) <= 1e-5 * float(total)
+        c = mo.clip_coef(float(total), clip)
+        assert (c < 1.0) == (clip < 1.0)
+        for p_new, p_old, gr, wd in ((w, w0, gw, 0.05), (b, b0, gb, 0.0)):
+            ref, _, _ = mo.adamw_step(p_old, gr * c, torch.zeros_like(p_old), torch.zeros_like(p_old), 1, 1e-2, wd)
+            assert torch.allclose(p_new.detach().cpu(), ref, rtol=1e-5, atol=1e-6), clip
+        assert opt.grad_scale == 1.0

@@ -352,6 +352,16 @@ def test_events_augment_matches_reference():
         assert np.array_equal(g, d[tag + "_voxel"]), tag
 
 
+def test_label_smoothing_formula():
+    """The restated timm LabelSmoothingCrossEntropy against torch's built-in label_smoothing (same published formula)."""
+    g = torch.Generator().manual_seed(5)
+    pred = torch.randn(7, 10, generator=g, dtype=torch.float64) * 3
+    label = torch.randint(0, 10, (7,), generator=g)
+    for s_ in (0.0, 0.1, 0.3):
+        assert torch.allclose(mo.label_smoothing_ce(pred, label, s_), torch.nn.functional.cross_entropy(pred, label, label_smoothing=s_), rtol=1e-12)
+    assert mo.clip_coef(10.0, 1.0) == pytest.approx(1.0 / (10.0 + 1e-6)) and mo.clip_coef(0.5, 1.0) == 1.0
+
+
 def ft_state_dict(d, grid=14):
     from eventpretrain_amd.testing import det_value_for
     sd = {}
