@@ -63,6 +63,25 @@ def draw_erase_add(n, rs=None):
     return erase_index.astype(np.int64), add_index.astype(np.int64), np.ascontiguousarray(noise, dtype=np.float64)
 
 
+def draw_erase_add_batch(seed, step, sizes, first_sample=0):
+    """Counter-based decisions for a batch: sample i of optimizer step `step` uses the Philox stream keyed by
+    (seed, step, first_sample + i), so a clip's augmentation does not depend on worker scheduling. Same distribution as
+    the reference's (counts uniform in [int(0.001 n), int(0.01 n)), rows without replacement, N(0,1.5) / N(0,1.5) /
+    N(0,0.001) noise), but the noise is drawn for the added rows only (the reference draws 3 n normals and keeps <= 1 %)."""
+    out = []
+    for i, n in enumerate(int(v) for v in sizes):
+        if int(0.01 * n) <= 0:
+            out.append(None)
+            continue
+        g = np.random.Generator(np.random.Philox(key=[int(seed) & (2 ** 64 - 1), ((int(step) << 24) ^ (first_sample + i)) & (2 ** 64 - 1)]))
+        lo, hi = int(0.001 * n), int(0.01 * n)
+        erase_index = np.sort(g.choice(n, size=int(g.integers(lo, hi)), replace=False)).astype(np.int64)
+        add_index = g.choice(n, size=int(g.integers(lo, hi)), replace=False).astype(np.int64)
+        noise = g.normal(0.0, 1.0, size=(add_index.size, 3)) * np.array([1.5, 1.5, 0.001])
+        out.append((erase_index, add_index, np.ascontiguousarray(noise, dtype=np.float64)))
+    return out
+
+
 def events_augment_batch(events, clip_offsets, decisions, size):
     """events: float64 CUDA tensor [n_total,4] (x,y,t,p), every clip time-sorted; clip_offsets: int64 host sequence /
     array [n_clips+1]; decisions: one `draw_erase_add` result (or None) per clip; size = (sensor_h, sensor_w).

@@ -213,6 +213,15 @@ def test_events_augment_matches_reference_and_oracle():
         assert np.array_equal(out[out_off[i]:out_off[i + 1]], ref), i
     assert out_off[-1] == out.shape[0]
 
+    # counter-based decision stream: reproducible per (seed, step, sample), valid tables, same result as the oracle merge
+    decs2 = ea.draw_erase_add_batch(9, 3, sizes)
+    again = ea.draw_erase_add_batch(9, 3, sizes[3:], first_sample=3)
+    assert decs2[2] is None and decs2[3] is None and np.array_equal(decs2[5][0], again[2][0]) and np.array_equal(decs2[5][2], again[2][2])
+    out2, off2 = ea.events_augment_batch(torch.from_numpy(np.concatenate(evs)).cuda(), offs, decs2, (260, 346))
+    out2, off2 = out2.cpu().numpy(), off2.cpu().numpy()
+    for i, (e, dec) in enumerate(zip(evs, decs2)):
+        assert np.array_equal(out2[off2[i]:off2[i + 1]], ao.erase_add_apply(e, dec, (260, 346))), i
+
     # host-side argument errors surface as EvpError
     from eventpretrain_amd import EvpError
     with pytest.raises(EvpError):
