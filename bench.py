@@ -400,6 +400,9 @@ def main():
                            "kernel": "voxel_cuts_kernel+voxel_bin_kernel",
                            "us_per_batch": sec * 1e6, "clips_per_s": args.batch / sec, "events_per_s": args.batch * n_ev / sec,
                            "algorithmic_bytes_per_clip": n_ev * 32 + 5 * S * S * 4}
+        # SURVEY.md 8(d) "end-to-end" line: voxelisation of the batch (K1, events resident in HBM) + the step, back to back
+        result["end_to_end"] = {"value": args.batch * world / (ms * 1e-3 + sec), "unit": "samples/s",
+                                "includes": "K1 voxel scatter of the batch (%.0f us) + optimiser step, serial, per GPU" % (sec * 1e6)}
     if multi:
         dist.barrier()
 
