@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
                 ("C", _vp), ("c_dtype", _i), ("ldc", _i64), ("strideC0", _i64), ("strideC1", _i64),
                 ("batch0", _i), ("batch1", _i), ("alpha", _f), ("bias", _vp), ("act", _i),
                 ("aux", _vp), ("ldaux", _i64), ("residual", _vp), ("ldres", _i64),
-                ("accumulate", _i), ("tile", _i), ("splitk", _i)]
+                ("accumulate", _i), ("tile", _i), ("splitk", _i), ("sk_workspace", _vp), ("sk_workspace_bytes", _i64)]
 
 
 # name -> argtypes (all return int status unless listed in _OTHER_RESTYPE)

@@ -43,6 +43,11 @@ struct GemmParams {
   unsigned long long *dbgbuf; // measurement aid: per-workgroup cycle counters of the persistent kernel
   float *colsum;             // 256x256 TN body only: colsum[m] (+)= sum_k A[k][m] (bias gradient), written by the tile_n == 0 workgroups
   int colsum_acc;
+  // stream-K (gemm_sk_kernel): partial accumulator tiles and their ready flags, in the caller's workspace
+  float *sk_ws;
+  int *sk_flags;
+  int sk_kiters;             // K tiles per output tile
+  long long sk_total;        // output tiles x sk_kiters
 };
 
 template <typename T> struct Cfg;
@@ -548,9 +553,21 @@ __device__ __forceinline__ void epilogue_lds(const f32x4 (&acc)[MI][NI], const G
   }
 }
 
+constexpr int SK_FLAG_BYTES = 4096;              // ready flags (one per workgroup) + the error word, at the start of the workspace
+constexpr int SK_MAX_GRID = SK_FLAG_BYTES / 4 - 8;
+constexpr int SK_ERR_WORD = SK_FLAG_BYTES / 4 - 1;
+// stream-K segment context (gemm_sk_kernel): the XCD's iteration range [base, base + span) is cut into gx equal runs, run
+// j belongs to workgroup blockIdx = j * 8 + xcd; mode 1 = park the accumulators, 2 = whole tile, 3 = collect + finish
+struct SkCtx {
+  int mode, kbeg, kend, j, gx, xcd;
+  long long base, span, tile_begin;
+  __device__ __forceinline__ long long run_begin(int jj) const { return base + (long long)jj * span / gx; }
+};
+
 // ---- the tile body (shared by the plain and the grouped kernel) ------------------------------------------------
 template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN, bool GLDS, int STAGES, int BK>
-__device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m, const int tile_n, const int bz, const int kslice) {
+__device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m, const int tile_n, const int bz, const int kslice,
+                                          const SkCtx sk = SkCtx{0, 0, 0, 0, 1, 0, 0, 0, 0}) {
   constexpr int NT = WM * WN * 64;
   constexpr int KSTEP = Cfg<T>::KSTEP;
   constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
@@ -574,8 +591,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m,
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int kbeg = kslice * p.k_per_split;
-  const int kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
+  const int kbeg = sk.mode ? sk.kbeg : kslice * p.k_per_split;
+  const int kend = sk.mode ? sk.kend : ((kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K);
   const int ntiles = (kend - kbeg + BK - 1) / BK;
 
   auto compute_tile = [&](const char *ia, const char *ib) {
@@ -690,6 +707,56 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m,
     }
   }
 
+  // ---- stream-K hand-over (mode 1: this segment does not end its tile -> park the accumulators; mode 3: this segment
+  //      ends a tile that earlier workgroups of the same XCD started -> collect theirs). See gemm_sk_kernel.
+  if (sk.mode == 1) {
+    const int slot = sk.j * 8 + sk.xcd;
+    float4 *ws = reinterpret_cast<float4 *>(p.sk_ws + (size_t)slot * (BM * BN));
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        ws[(i * NI + j) * NT + tid] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    // Producer and consumer sit on ONE XCD (blockIdx and blockIdx - 8k): they share its L2, the vector L1 is
+    // write-through, so "stores acknowledged" (vmcnt 0, which the workgroup-scope release waits for) is all the
+    // consumer needs -- no L2 write-back / invalidate (an agent-scope fence per wave cost ~140 us per launch here).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(p.sk_flags + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  if (sk.mode == 3) {
+    __shared__ int sk_ok;
+    if (p.dbgbuf && tid == 0) p.dbgbuf[blockIdx.x * 16 + 13] = __builtin_readcyclecounter();   // main loop done
+    for (int jj = sk.j - 1; jj >= 0; --jj) {
+      const int slot = jj * 8 + sk.xcd;
+      if (tid == 0) {
+        int spins = 0, got = 0;
+        while (!(got = __hip_atomic_load(p.sk_flags + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) && ++spins < (1 << 18))
+          __builtin_amdgcn_s_sleep(8);
+        if (got) __hip_atomic_store(p.sk_flags + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one consumer per flag
+        else __hip_atomic_store(p.sk_flags + SK_ERR_WORD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // gave up
+        sk_ok = got;
+        if (p.dbgbuf) p.dbgbuf[blockIdx.x * 16 + 14] = __builtin_readcyclecounter();   // flag seen
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the slot's lines were never in this CU's L1 (one reader per slot and launch)
+      if (sk_ok) {
+        const float4 *ws = reinterpret_cast<const float4 *>(p.sk_ws + (size_t)slot * (BM * BN));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const float4 t = ws[(i * NI + j) * NT + tid];
+            acc[i][j][0] += t.x; acc[i][j][1] += t.y; acc[i][j][2] += t.z; acc[i][j][3] += t.w;
+          }
+      }
+      __syncthreads();    // sk_ok is rewritten by the next round
+      if (sk.run_begin(jj) <= sk.tile_begin) break;   // that run held the tile's first K tile
+    }
+    if (p.dbgbuf && tid == 0) p.dbgbuf[blockIdx.x * 16 + 15] = __builtin_readcyclecounter();   // parts added
+  }
+
   // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4
   const int64_t coff = b0 * p.sC0 + b1 * p.sC1;
   const int li = lane & 15, lg = lane >> 4;
@@ -726,11 +793,12 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m,
 // Block -> tile map (speed only, never correctness): (1) blocks b and b+8 share an XCD, so renumber to give every XCD
 // a contiguous run of tiles (bijective for any grid size); (2) inside the run walk GROUP_M x tiles_n panels, M
 // fastest, so the ~64 blocks an XCD runs at once share 8 A panels and 8 B panels that fit its 4 MiB L2.
-__device__ __forceinline__ void map_tile(int nblk, int bid, int tiles_m, int &tile_m, int &tile_n) {
+__device__ __forceinline__ int xcd_renumber(int nblk, int bid) {
   const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-  const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+__device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int &tile_m, int &tile_n) {
   constexpr int GROUP_M = 8;
-  const int tiles_n = nblk / tiles_m;
   const int per_group = GROUP_M * tiles_n;
   const int gid = t / per_group, first_m = gid * GROUP_M;
   const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
@@ -738,12 +806,73 @@ __device__ __forceinline__ void map_tile(int nblk, int bid, int tiles_m, int &ti
   tile_m = first_m + in_g % gsz;
   tile_n = in_g / gsz;
 }
+__device__ __forceinline__ void map_tile(int nblk, int bid, int tiles_m, int &tile_m, int &tile_n) {
+  tile_of(xcd_renumber(nblk, bid), tiles_m, nblk / tiles_m, tile_m, tile_n);
+}
 
 template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN, bool GLDS, int STAGES, int BK, int MINW>
 __global__ __launch_bounds__(WM *WN * 64, MINW) void gemm_kernel(const GemmParams p) {
   int tile_m, tile_n;
   map_tile(gridDim.x, blockIdx.x, p.tiles_m, tile_m, tile_n);
   gemm_body<T, TC, EPI, TA, TB, BM, BN, WM, WN, GLDS, STAGES, BK>(p, tile_m, tile_n, blockIdx.z, blockIdx.y);
+}
+
+// ---- stream-K form of the same body ---------------------------------------------------------------------------------
+// The forward / dgrad GEMMs of this path have 294-1176 output tiles for 512 resident workgroups: a data-parallel launch
+// leaves up to 43 % of the slots idle in its last round, and all workgroups reach their C-tile stores together. Here a
+// grid of the resident workgroups cuts the iteration space (output tile x K tile, tile-major) into equal runs -- per
+// XCD: each XCD owns an eighth of the tiles and splits it over its own workgroups (blockIdx % 8), so partial tiles
+// never cross XCDs and the panels an XCD streams stay in its L2. A run is [tail of a tile][whole tiles][head of a
+// tile] and is walked BACKWARDS: the head segment (which does not end its tile) comes first and parks its accumulators
+// (64 KiB, raw register layout, coalesced) in the workspace; the tail segment comes last, and the workgroup that ends
+// a tile collects the parked parts of the workgroups before it (blockIdx - 8, -16, ...). So a wait never depends on
+// another wait (no chain), it only ever targets workgroups that were dispatched EARLIER (no deadlock even if the grid
+// were not fully resident), and the summation order is fixed (results are run-to-run identical). Flags are consumed
+// (reset to 0) by their single reader, so a replayed HIP graph finds them clean. The poll is bounded: a lost producer
+// costs a wrong tile and an error word, never a hung GPU.
+// Measured (tools/gemm_sk_check.py, gemm_sk_trace.py; MI355X): bit-reproducible and equal to the data-parallel result
+// to f32 rounding, but 4-15 us SLOWER than it on every shape of this path (enc.fc2 56.9 vs 53.1 us). Per workgroup:
+// park 2.2 us, wait for the neighbour's flag 5.4 us (all runs are equally long, so the part a workgroup needs is
+// finished just when it asks for it -- no slack), adding the parked parts 5.0 us (32 MB of parks do not stay in the
+// 4 MiB L2s), one extra pipeline fill per segment. Kept as an explicit variant (evp_gemm_desc::tile = 12) with its
+// parity test; the next thing to try is the hybrid: one whole tile per CU for the first 256 tiles, stream-K only for
+// the remainder, so that hand-overs sit on workgroups with slack.
+template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN, int STAGES, int BK>
+__global__ __launch_bounds__(WM *WN * 64, 2) void gemm_sk_kernel(const GemmParams p) {
+  const int g = gridDim.x;                         // multiple of 8
+  SkCtx sk;
+  sk.xcd = blockIdx.x & 7;
+  sk.j = blockIdx.x >> 3;
+  sk.gx = g >> 3;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const long long tiles = (long long)p.tiles_m * tiles_n;
+  const long long t_lo = tiles * sk.xcd / 8, t_hi = tiles * (sk.xcd + 1) / 8;   // this XCD's tiles: no hand-over crosses XCDs
+  sk.base = t_lo * p.sk_kiters;
+  sk.span = (t_hi - t_lo) * p.sk_kiters;
+  const long long it0 = sk.run_begin(sk.j);
+  long long it1 = sk.run_begin(sk.j + 1);
+  // measurement aid (evp_gemm_set_debug_buffer): 16 words per workgroup: start, then (end stamp, mode << 16 | K tiles) per segment
+  int dbg_n = 0;
+  if (p.dbgbuf && threadIdx.x == 0) p.dbgbuf[blockIdx.x * 16] = __builtin_readcyclecounter();
+  while (it1 > it0) {                              // last segment of the run first
+    const int t = (int)((it1 - 1) / p.sk_kiters);
+    sk.tile_begin = (long long)t * p.sk_kiters;
+    const long long seg0 = it0 > sk.tile_begin ? it0 : sk.tile_begin;
+    const int k0 = (int)(seg0 - sk.tile_begin), k1 = (int)(it1 - sk.tile_begin);
+    int tile_m, tile_n;
+    tile_of(t, p.tiles_m, tiles_n, tile_m, tile_n);
+    sk.mode = k1 < p.sk_kiters ? 1 : (k0 > 0 ? 3 : 2);
+    sk.kbeg = k0 * BK;
+    sk.kend = k1 * BK < p.K ? k1 * BK : p.K;
+    gemm_body<T, TC, EPI, TA, TB, BM, BN, WM, WN, true, STAGES, BK>(p, tile_m, tile_n, 0, 0, sk);
+    __syncthreads();      // the epilogue's LDS scratch is the next segment's staging ring
+    if (p.dbgbuf && threadIdx.x == 0 && dbg_n < 7) {
+      p.dbgbuf[blockIdx.x * 16 + 1 + 2 * dbg_n] = __builtin_readcyclecounter();
+      p.dbgbuf[blockIdx.x * 16 + 2 + 2 * dbg_n] = ((unsigned long long)sk.mode << 16) | (unsigned)(k1 - k0);
+      ++dbg_n;
+    }
+    it1 = seg0;
+  }
 }
 
 // ---- grouped weight-gradient GEMM: many independent (dY^T . X) problems in ONE launch ------------------------------
@@ -836,6 +965,59 @@ int launch(const evp_gemm_desc *d, hipStream_t s) {
   return EVP_OK;
 }
 
+
+// stream-K launch of the 128x128 LDS-DMA body (bf16, A row-major). Workspace (caller-owned, evp_gemm_desc::sk_workspace):
+// [0, 4096) int32 ready flags + error word -- zeroed ONCE by the caller, kept clean by the kernel -- then one 64 KiB
+// accumulator slot per workgroup.
+template <typename TC, int EPI, bool TB> int sk_resident_blocks() {
+  static int blocks = -1;   // per instantiation
+  if (blocks < 0) {
+    constexpr int smem = 2 * (Img<bf16_t, false, 128, 64>::BYTES + Img<bf16_t, TB, 128, 64>::BYTES);
+    auto k = gemm_sk_kernel<bf16_t, TC, EPI, false, TB, 128, 128, 2, 2, 2, 64>;
+    if (smem > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return blocks = 0;
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, smem) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return blocks = 0;
+    if (per_cu > 2) per_cu = 2;
+    blocks = per_cu * cus;
+    if (blocks > SK_MAX_GRID) blocks = SK_MAX_GRID;
+    blocks &= ~7;             // whole workgroups per XCD
+  }
+  return blocks;
+}
+// usable for this call? (shape and workspace); *grid = workgroups to launch
+template <typename TC, int EPI, bool TB> bool sk_usable(const evp_gemm_desc *d, int *grid) {
+  const int64_t nb = (int64_t)(d->batch0 > 0 ? d->batch0 : 1) * (d->batch1 > 0 ? d->batch1 : 1);
+  if (nb != 1 || d->K % 64 != 0 || d->K < 256 || !d->sk_workspace || d->splitk > 1) return false;
+  const int g = sk_resident_blocks<TC, EPI, TB>();
+  const int64_t tiles = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128);
+  if (g < 8 || tiles * (d->K / 64) < (int64_t)g * 4) return false;
+  if (d->sk_workspace_bytes < SK_FLAG_BYTES + (int64_t)g * 128 * 128 * 4) return false;
+  *grid = g;
+  return true;
+}
+template <typename TC, int EPI, bool TB> int launch_sk(const evp_gemm_desc *d, hipStream_t s, int g) {
+  GemmParams p;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.A = d->A; p.lda = d->lda; p.sA0 = 0; p.sA1 = 0;
+  p.B = d->B; p.ldb = d->ldb; p.sB0 = 0; p.sB1 = 0;
+  p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = 0; p.sC1 = 0;
+  p.batch1 = 1;
+  p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
+  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = g_gemm_dbg; p.dbgbuf = g_gemm_dbgbuf; p.colsum = nullptr; p.colsum_acc = 0;
+  p.tiles_m = (d->M + 127) / 128;
+  p.splitk = 1; p.k_per_split = d->K;
+  p.sk_flags = reinterpret_cast<int *>(d->sk_workspace);
+  p.sk_ws = reinterpret_cast<float *>(reinterpret_cast<char *>(d->sk_workspace) + SK_FLAG_BYTES);
+  p.sk_kiters = d->K / 64;
+  p.sk_total = (long long)p.tiles_m * ((d->N + 127) / 128) * p.sk_kiters;
+  constexpr int smem = 2 * (Img<bf16_t, false, 128, 64>::BYTES + Img<bf16_t, TB, 128, 64>::BYTES);
+  hipLaunchKernelGGL((gemm_sk_kernel<bf16_t, TC, EPI, false, TB, 128, 128, 2, 2, 2, 64>), dim3((unsigned)g), dim3(256), smem, s, p);
+  EVP_CHECK_LAUNCH("evp_gemm(stream-K)");
+  return EVP_OK;
+}
 
 // ---- 256x256x64 tile, 8 waves, half-tile ring ("8-phase" schedule) ----------------------------------------------
 // The 128x128 body above re-reads 16 KiB of LDS per wave for every 32 MFMAs, which is exactly the LDS port's rate at
@@ -1459,6 +1641,19 @@ template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(cons
     tile = (d->M >= 128 && d->N >= 128 && (t128 >= 192 || splittable)) ? 1 : 2;
   }
   // bf16: LDS-DMA staging (variant 1, default) or register staging (variant 2, kept for A/B runs); f32: registers
+  if constexpr (sizeof(T) == 2 && !TA) {
+    // stream-K is explicit only (tile 12): measured on this path's shapes it does not beat the data-parallel launch (see
+    // the note at gemm_sk_kernel)
+    if (d->tile == 12) {
+      int g = 0;
+      if (sk_usable<TC, EPI, TB>(d, &g)) return launch_sk<TC, EPI, TB>(d, s, g);
+      evp_set_error("evp_gemm: tile 12 (stream-K) needs bf16 A row-major, no batch, K %% 64 == 0, K >= 256, >= 4 K tiles per workgroup and sk_workspace");
+      return EVP_ESHAPE;
+    }
+  }
+  if constexpr (sizeof(T) == 2 && TA) {
+    if (d->tile == 12) { evp_set_error("evp_gemm: tile 12 (stream-K) is not built for transA"); return EVP_EUNSUPPORTED; }
+  }
   if constexpr (sizeof(T) == 2) {
     if (tile == 8) {        // persistent 128x128 with the epilogue folded into the next tile's K loop
       if constexpr (!TA) {

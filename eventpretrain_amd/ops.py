@@ -50,6 +50,19 @@ def _chk(t, dtype=None):
 
 
 # ----------------------------------------------------------------------------------------------------- raw calls
+_SK_BYTES = 4096 + 65536 * 1024          # flags page + one 64 KiB accumulator slot per resident workgroup (<= 1023)
+_sk_ws = {}                              # (device index, stream handle) -> workspace: launches sharing one must be ordered
+
+
+def _streamk_workspace(dev):
+    key = (dev.index, stream_ptr())
+    ws = _sk_ws.get(key)
+    if ws is None:
+        ws = torch.zeros(_SK_BYTES, dtype=torch.uint8, device=dev)      # the flags page must start zeroed
+        _sk_ws[key] = ws
+    return ws
+
+
 def gemm(a, b, out, *, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, bias=None, act=ACT_NONE,
          aux=None, residual=None, alpha=1.0, accumulate=False, batch=(1, 1), stride_a=(0, 0), stride_b=(0, 0),
          stride_c=(0, 0), a_off=0, b_off=0, c_off=0, tile=0, splitk=0):
@@ -84,6 +97,9 @@ def gemm(a, b, out, *, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None
     d.accumulate = int(accumulate)
     d.tile = int(tile)
     d.splitk = int(splitk)
+    if tile == 12:           # stream-K variant (explicit only): needs the caller-owned workspace
+        ws = _streamk_workspace(a.device)
+        d.sk_workspace, d.sk_workspace_bytes = ws.data_ptr(), ws.numel()
     call("evp_gemm", C.byref(d), stream_ptr())
     return out
 

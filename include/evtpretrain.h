@@ -113,8 +113,14 @@ typedef struct {
   void *aux; int64_t ldaux;            /* element type = c_dtype; batch strides = C's */
   const float *residual; int64_t ldres; /* batch strides = C's */
   int accumulate;
-  int tile;                             /* 0 auto, 1 = 128x128, 2 = 64x64, 6 = 256x256 ring (bf16, K % 64 == 0) */
+  int tile;                             /* 0 auto, 1 = 128x128, 2 = 64x64, 6 = 256x256 ring (bf16, K % 64 == 0), 12 = stream-K 128x128 */
   int splitk;                           /* 0 auto, n = cut K into n slices summed with f32 atomics (plain f32 C only) */
+  /* Optional stream-K workspace (bf16, transA = 0, no batch): device memory, >= 4096 + 65536 * 2 * CUs bytes, its first
+   * 4096 bytes zeroed ONCE by the caller (the kernel leaves them zero). Used by tile = 12 only (the stream-K form of the
+   * 128x128 kernel; an explicit variant -- it does not beat the data-parallel launch on this path's shapes).
+   * One workspace per stream: launches that share it must be ordered. */
+  void *sk_workspace;
+  int64_t sk_workspace_bytes;
 } evp_gemm_desc;
 int evp_gemm(const evp_gemm_desc *d, void *stream);
 /* Grouped weight-gradient GEMM: n problems C_g[M_g,N_g] (f32) = A_g^T . B_g, A_g stored [K_g][M_g] and B_g stored

@@ -217,3 +217,43 @@ def test_grouped_tn256_with_fused_column_sums_exact():
             assert torch.equal(db, dy.float().sum(0) + (5.0 if acc else 0.0))
         else:
             assert torch.equal(db, torch.full_like(db, 5.0))
+
+
+@pytest.mark.parametrize("tb", [False, True])
+def test_stream_k_variant_matches_data_parallel(tb):
+    """evp_gemm tile 12 (stream-K form of the 128x128 bf16 kernel: partial tiles handed over through the caller's
+    workspace): exact on small-integer operands, equal to the data-parallel result to f32 rounding with every epilogue,
+    identical run to run, flag page left clean (so a replayed HIP graph can reuse it), refused when it cannot apply."""
+    from eventpretrain_amd import EvpError, ops
+    from eventpretrain_amd._lib import ACT_GELU
+    gen = torch.Generator().manual_seed(31)
+    for (M, N, K) in [(6272, 768, 3072), (2000, 520, 2048), (12544, 512, 512)]:
+        a, b, a_log, b_log = _mk(M, N, K, False, tb, torch.bfloat16, gen, ints=True)
+        a, b = a.cuda(), b.cuda()
+        out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        kw = dict(M=M, N=N, K=K, trans_b=tb, ldb=(N if tb else K))
+        ops.gemm(a, b, out, tile=12, **kw)
+        assert torch.equal(out.cpu().double(), a_log @ b_log.t()), (M, N, K)
+        # random data + bias + residual / GELU + aux, against the data-parallel kernel
+        a, b, _, _ = _mk(M, N, K, False, tb, torch.bfloat16, gen)
+        a, b = a.cuda(), (b * 0.05).cuda()
+        bias = torch.randn(N, generator=gen).cuda()
+        res = torch.randn(M, N, generator=gen).cuda()
+        o1, o2, o3 = (torch.empty(M, N, dtype=torch.float32, device="cuda") for _ in range(3))
+        ops.gemm(a, b, o1, tile=1, bias=bias, residual=res, **kw)
+        ops.gemm(a, b, o2, tile=12, bias=bias, residual=res, **kw)
+        ops.gemm(a, b, o3, tile=12, bias=bias, residual=res, **kw)
+        assert torch.equal(o2, o3)
+        assert (o1 - o2).abs().max().item() <= 2e-5 * max(1.0, o1.abs().max().item())
+        if not tb:
+            h1, h2 = (torch.empty(M, N, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+            x1, x2 = (torch.empty(M, N, dtype=torch.bfloat16, device="cuda") for _ in range(2))
+            ops.gemm(a, b, h1, tile=1, bias=bias, act=ACT_GELU, aux=x1, **kw)
+            ops.gemm(a, b, h2, tile=12, bias=bias, act=ACT_GELU, aux=x2, **kw)
+            assert (h1.float() - h2.float()).abs().max().item() <= 1e-2 * max(1.0, h1.float().abs().max().item())
+            assert (x1.float() - x2.float()).abs().max().item() <= 1e-2 * max(1.0, x1.float().abs().max().item())
+    flags = next(iter(ops._sk_ws.values()))[:4096].view(torch.int32)
+    assert int((flags != 0).sum()) == 0
+    small = torch.zeros(128, 64, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(EvpError):
+        ops.gemm(small, small, torch.empty(128, 128, device="cuda"), M=128, N=128, K=64, tile=12)
