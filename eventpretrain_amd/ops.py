@@ -349,6 +349,7 @@ class _DeferredGrads:
             self.zero = zero            # buffers that accumulate with atomics: cleared before every run
             self.keep = keep            # operand tensors referenced by the tables
             self.post = list(post)      # split-K reductions: (workspace, out, n_slices, numel, accumulate)
+            self.round = 0              # steps of one round touch disjoint gradients (may run concurrently); rounds are ordered
 
         def run(self):
             for z in self.zero:
@@ -473,6 +474,7 @@ class _DeferredGrads:
                     it_ = table(tag + "i", items.view(np.uint8).reshape(-1), dev)
                     steps.append(self._Step(entry, pt, it_, int(items.shape[0]), [flat] if flat is not None else [], [],
                                             [(it[1], it[2]) for it in part], post))
+                    steps[-1].round = r
         if b:
             dev = b[0][1].device
             probs = np.zeros(len(b), dtype=np.dtype([("x", "<u8"), ("out", "<u8"), ("M", "<i8"), ("N", "<i4"), ("ld", "<i4"),

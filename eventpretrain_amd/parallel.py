@@ -39,21 +39,44 @@ class OverlappedPlan:
     chunk's all-reduce is exposed. The small gradients autograd produced inside the graph go through the packed bucket
     first."""
 
-    def __init__(self, steps, others, bucket, views, group):
+    def __init__(self, steps, others, bucket, views, group, two_streams=True):
         self.steps, self.others, self.bucket, self.views, self.group = steps, others, bucket, views, group
         self.srcs = [p.grad for p in others]
         for p, v in zip(others, views):
             p.grad = v
+        # Chunks of one round write disjoint gradients: they alternate between two side streams, so the ramp-down of
+        # chunk c (its last, partly filled round of workgroups) is filled by the first workgroups of chunk c+1 instead
+        # of idling at a kernel boundary. Each chunk's all-reduce is issued from the stream the chunk ran on.
+        self.streams = (torch.cuda.Stream(), torch.cuda.Stream()) if (two_streams and torch.cuda.is_available()) else None
 
     def run(self):
         works = []
         if self.others:
             torch._foreach_copy_(self.views, self.srcs)
             works.append(dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for st in self.steps:
-            st.run()
-            for f in st.flats:
-                works.append(dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.streams is None:
+            for st in self.steps:
+                st.run()
+                for f in st.flats:
+                    works.append(dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            cur = torch.cuda.current_stream()
+            for s in self.streams:
+                s.wait_stream(cur)                    # the forward+backward graph has finished
+            prev_round, k = None, 0
+            for st in self.steps:
+                r = getattr(st, "round", 0)
+                if prev_round is not None and r != prev_round:      # a later round accumulates onto the earlier one's results
+                    self.streams[0].wait_stream(self.streams[1])
+                    self.streams[1].wait_stream(self.streams[0])
+                prev_round = r
+                with torch.cuda.stream(self.streams[k & 1]):
+                    st.run()
+                    for f in st.flats:
+                        works.append(dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                k += 1
+            for s in self.streams:
+                cur.wait_stream(s)
         for w in works:
             w.wait()                                  # stream wait, no host sync
 
