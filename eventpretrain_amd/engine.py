@@ -31,6 +31,7 @@ class GraphedStep:
         self.gen = generator if generator is not None else torch.Generator(device=dev)
         self.noise = torch.empty(*noise_shape, device=dev) if noise_shape is not None else None
         self.graph = self.graph2 = self.plan = None
+        self.parts = False
         self.loss = None
         self.note = "eager"
         self.multi = reducer is not None
@@ -82,11 +83,22 @@ class GraphedStep:
                 # chunked weight-gradient launches interleaved with their all-reduces (parallel.OverlappedPlan)
                 with torch.cuda.stream(side):
                     self.plan = self.reducer.make_overlapped_plan(self.wgrad_chunks)
+                # AdamW in parts, each launched as soon as its gradient buffer is reduced (the graph then only holds the
+                # H2D copies of the per-step scalar tables); one launch after the last all-reduce otherwise
+                self.parts = self.plan.streams is not None
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, stream=side, capture_error_mode="thread_local"):
                     self.opt.refresh()
-                    self.opt.launch()
-                self.graph2, self.note = g2, "hip-graph (fwd+bwd) + %d weight-gradient chunks overlapped with RCCL all-reduce + hip-graph (AdamW)" % self.wgrad_chunks
+                    if not self.parts:
+                        self.opt.launch()
+                if self.parts:
+                    with torch.cuda.stream(side):
+                        self.plan.attach_optimizer(self.opt, [p for p in self.model.parameters() if p.requires_grad])
+                side.synchronize()
+                self.graph2 = g2
+                self.note = ("hip-graph (fwd+bwd) + %d weight-gradient chunks on two streams, each all-reduced (RCCL) while the next "
+                             "computes, AdamW per reduced buffer" % self.wgrad_chunks) if self.parts else \
+                            ("hip-graph (fwd+bwd) + %d weight-gradient chunks overlapped with RCCL all-reduce + hip-graph (AdamW)" % self.wgrad_chunks)
         except Exception as e:               # keep training; say what happened
             self.graph = self.graph2 = self.plan = None
             self.note = "eager (graph capture failed: %r)" % (e,)
@@ -114,6 +126,10 @@ class GraphedStep:
         self.opt.stage_scalars()
         self.graph.replay()
         if self.plan is not None:
-            self.plan.run()
-            self.graph2.replay()
+            if self.parts:
+                self.graph2.replay()         # this step's lr / bias-correction tables -> device
+                self.plan.run()              # weight gradients, all-reduces and the update, part by part
+            else:
+                self.plan.run()
+                self.graph2.replay()
         return self.loss

@@ -162,6 +162,42 @@ class FusedAdamW(torch.optim.Optimizer):
              T["chunk_o"].data_ptr(), T["n_chunks"], CHUNK, 1.0, float(b1), float(b2), float(self.param_groups[0]["eps"]),
              max(self._step, 1), self.grad_scale, T["hyper"].data_ptr(), stream_ptr())
 
+    def build_parts(self, param_lists):
+        """Cut the update into parts (data-parallel plan: one per all-reduced gradient buffer, so a part's update runs
+        while the next buffer is still on the wire). `param_lists`: disjoint lists of parameters; parameters with a
+        gradient that appear in none form a last part. Call after refresh(); returns the number of parts."""
+        T = self._tabs
+        index = {id(p): i for i, (_, p) in enumerate(self._act)}
+        numel = T["numel"].cpu().numpy()
+        taken, parts = set(), []
+
+        def tables(ts):
+            ct = np.concatenate([np.full((int(numel[t]) + CHUNK - 1) // CHUNK, t, dtype=np.int32) for t in ts])
+            co = np.concatenate([np.arange(0, int(numel[t]), CHUNK, dtype=np.int64) for t in ts])
+            return torch.from_numpy(ct).to(T["dev"]), torch.from_numpy(co).to(T["dev"]), int(ct.shape[0])
+
+        for plist in list(param_lists) + [None]:
+            if plist is None:
+                ts = [t for t in range(T["n"]) if t not in taken]
+            else:
+                ts = [index[id(p)] for p in plist if id(p) in index and index[id(p)] not in taken]
+            taken.update(ts)
+            parts.append(tables(ts) if ts else None)
+        self._parts = parts
+        return len(parts)
+
+    def launch_part(self, i):
+        """Device side of the update for part i of build_parts() (same kernel, that part's chunk table)."""
+        part = self._parts[i]
+        if part is None:
+            return
+        T = self._tabs
+        b1, b2 = self.param_groups[0]["betas"]
+        call("evp_adamw_multi", T["params"].data_ptr(), T["grads"].data_ptr(), T["m"].data_ptr(), T["v"].data_ptr(),
+             T["lp"].data_ptr(), T["numel"].data_ptr(), T["wd"].data_ptr(), T["lr"].data_ptr(), part[0].data_ptr(),
+             part[1].data_ptr(), part[2], CHUNK, 1.0, float(b1), float(b2), float(self.param_groups[0]["eps"]),
+             max(self._step, 1), self.grad_scale, T["hyper"].data_ptr(), stream_ptr())
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None

@@ -48,6 +48,23 @@ class OverlappedPlan:
         # chunk c (its last, partly filled round of workgroups) is filled by the first workgroups of chunk c+1 instead
         # of idling at a kernel boundary. Each chunk's all-reduce is issued from the stream the chunk ran on.
         self.streams = (torch.cuda.Stream(), torch.cuda.Stream()) if (two_streams and torch.cuda.is_available()) else None
+        self.opt, self.update_stream = None, None
+
+    def attach_optimizer(self, opt, params):
+        """Run the optimizer update in parts, each right after its gradient buffer has been all-reduced (on a third
+        stream), instead of one launch after the last all-reduce: part 0 = the small-gradient bucket, part 1 + i = the
+        gradients step i completes, last part = anything else. Needs the two-stream form and opt.refresh() done."""
+        if self.streams is None:
+            return False
+
+        def owners(flats):
+            spans = [(f.data_ptr(), f.data_ptr() + f.numel() * f.element_size()) for f in flats]
+            return [p for p in params if p.grad is not None and any(lo <= p.grad.data_ptr() < hi for lo, hi in spans)]
+
+        lists = [list(self.others)] + [owners(st.flats) for st in self.steps]
+        self.n_parts = opt.build_parts(lists)
+        self.opt, self.update_stream = opt, torch.cuda.Stream()
+        return True
 
     def run(self):
         works = []
@@ -63,6 +80,13 @@ class OverlappedPlan:
             cur = torch.cuda.current_stream()
             for s in self.streams:
                 s.wait_stream(cur)                    # the forward+backward graph has finished
+            upd = self.update_stream
+            if upd is not None:
+                upd.wait_stream(cur)                  # this step's lr / bias-correction tables are on the device
+                if works:
+                    with torch.cuda.stream(upd):
+                        works[0].wait()
+                        self.opt.launch_part(0)
             prev_round, k = None, 0
             for st in self.steps:
                 r = getattr(st, "round", 0)
@@ -70,13 +94,28 @@ class OverlappedPlan:
                     self.streams[0].wait_stream(self.streams[1])
                     self.streams[1].wait_stream(self.streams[0])
                 prev_round = r
+                mine = []
                 with torch.cuda.stream(self.streams[k & 1]):
                     st.run()
                     for f in st.flats:
-                        works.append(dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                        mine.append(dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                works += mine
+                if upd is not None:
+                    with torch.cuda.stream(upd):
+                        for w in mine:
+                            w.wait()                  # the update stream waits for this buffer only
+                        if not mine:
+                            upd.wait_stream(self.streams[k & 1])
+                        self.opt.launch_part(1 + k)
                 k += 1
             for s in self.streams:
                 cur.wait_stream(s)
+            if upd is not None:
+                with torch.cuda.stream(upd):
+                    if not self.others:
+                        self.opt.launch_part(0)
+                    self.opt.launch_part(self.n_parts - 1)
+                cur.wait_stream(upd)
         for w in works:
             w.wait()                                  # stream wait, no host sync
 
@@ -119,6 +158,10 @@ class BucketedGradReducer:
         """HIP-graph mode with overlap: call once after a forward+backward captured under ops.hold_deferred_grads(True)."""
         from . import ops
         steps = ops.build_deferred_plan(n_chunks)
+        if any(getattr(st, "round", 0) != 0 for st in steps):
+            # a parameter with several contributions per backward (rec+con) would be all-reduced before its later rounds
+            raise RuntimeError("overlapped data-parallel plan: parameters with more than one gradient contribution per step "
+                               "are not supported; use the eager reducer (BucketedGradReducer.finish)")
         flats = ops.take_deferred_flat_buffers()
         spans = [(f.data_ptr(), f.data_ptr() + f.numel() * f.element_size()) for f in flats]
         others = [p for p in self.params if p.grad is not None and not any(lo <= p.grad.data_ptr() < hi for lo, hi in spans)]
