@@ -236,6 +236,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python each step (no HIP graph)")
+    ap.add_argument("--wgrad-chunks", type=int, default=4,
+                    help="N > 1: weight-gradient launches per step (each chunk's buffer is all-reduced while the next computes)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (process group, reducer, split graphs) even with one rank")
     args = ap.parse_args()
@@ -280,7 +282,7 @@ def main():
     n_warm_eager = min(args.warmup, 3) if use_graph else 0
     executor = GraphedStep(model, opt, lambda m, x, y, noise: m(x, y, is_rec=True, noise=noise), [vox, tgt],
                            noise_shape=(args.batch, L), generator=gen, reducer=reducer, use_graph=use_graph,
-                           warmup=max(n_warm_eager, 2))
+                           warmup=max(n_warm_eager, 2), wgrad_chunks=args.wgrad_chunks)
     graph_note = executor.note
     step, eager_step = executor.step, executor.eager_step
     loss = None

@@ -652,7 +652,9 @@ extern "C" int evp_batchnorm_bwd(const void *dy, const void *x, const void *y, i
   int64_t g = (total + 255) / 256; if (g > 4096) g = 4096;
   hipLaunchKernelGGL(bn_bwd_apply, dim3((int)g), dim3(256), 0, s, dy, x, y, dtype, R, C, gamma, mean, invstd, relu, sum_dy, sum_dy_xhat, dx);
   EVP_CHECK_LAUNCH("evp_batchnorm_bwd(apply)");
-  if (dgamma) hipMemcpyAsync(dgamma, sum_dy_xhat, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
-  if (dbeta) hipMemcpyAsync(dbeta, sum_dy, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
+  hipError_t e = hipSuccess;
+  if (dgamma) e = hipMemcpyAsync(dgamma, sum_dy_xhat, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
+  if (dbeta && e == hipSuccess) e = hipMemcpyAsync(dbeta, sum_dy, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
+  EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_batchnorm_bwd: copying the affine gradients failed: %s", hipGetErrorString(e));
   return EVP_OK;
 }
