@@ -205,6 +205,35 @@ __device__ __forceinline__ bf16x8 frag_bf16(const char *img, int rb, int ks, int
     return __builtin_bit_cast(bf16x8, v);
   }
 }
+// The same fragment through inline-asm LDS reads. Why: the compiler's waitcnt pass knows that an LDS-DMA
+// (buffer_load ... lds) writes LDS and puts `s_waitcnt vmcnt(0)` in front of every ds_read it can see after one -- which
+// silently turned every counted vmcnt(N) of the staging rings into "wait for everything", i.e. no K tile was ever in
+// flight across the fragment reads. Reads it cannot see are not guarded; the loops guard them themselves (counted vmcnt
+// + barrier before, s_waitcnt lgkmcnt + the `tie` below after).
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+template <bool TR, int ROWS, int BK>
+__device__ __forceinline__ u32x4 frag_bf16_asm(const char *img, int rb, int ks, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  if constexpr (!TR) {
+    const unsigned a = (unsigned)(uintptr_t)(lds_void *)(img + Img<bf16_t, false, ROWS, BK>::chunk_off(rb + i, ks * 4 + g));
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory");
+    return v;
+  } else {
+    const int q = i >> 2, p = i & 3;
+    const int k = ks * 32 + 8 * g + q;
+    const int ch = (rb >> 3) + (p >> 1);
+    const unsigned a0 = (unsigned)(uintptr_t)(lds_void *)(img + Img<bf16_t, true, ROWS, BK>::chunk_off(k, ch) + 8 * (p & 1));
+    const unsigned a1 = (unsigned)(uintptr_t)(lds_void *)(img + Img<bf16_t, true, ROWS, BK>::chunk_off(k + 4, ch) + 8 * (p & 1));
+    u32x2 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1) : "memory");
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+  }
+}
+// orders the consumers of x after every earlier `asm volatile` (the s_waitcnt lgkmcnt in front of it); no instruction
+__device__ __forceinline__ void tie(u32x4 &x) { asm volatile("" : "+v"(x)); }
+
 template <bool TR, int ROWS>
 __device__ __forceinline__ float frag_f32(const char *img, int rb, int ks, int lane) {
   const int g = lane >> 4, i = lane & 15;
@@ -624,6 +653,44 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m,
     }
   };
 
+  // bf16 + LDS-DMA staging: the fragment reads go through frag_bf16_asm (see there); all reads of the K tile are issued
+  // first, the MFMAs of K step ks start when its own 8 reads are back (ds_reads return in order)
+  auto compute_tile_asm = [&](const char *ia, const char *ib) {
+    if constexpr (sizeof(T) == 2) {
+      constexpr int KS = BK / KSTEP;
+      static_assert(KS == 1 || KS == 2, "lgkmcnt literals below");
+      u32x4 af[KS][MI], bf[KS][NI];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[ks][i] = frag_bf16_asm<TA, BM, BK>(ia, wm * WTM + i * 16, ks, lane);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bf[ks][j] = frag_bf16_asm<TB, BN, BK>(ib, wn * WTN + j * 16, ks, lane);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        constexpr int PER_KS = (TA ? 2 : 1) * MI + (TB ? 2 : 1) * NI;      // ds_read instructions per K step
+        if (ks + 1 < KS && PER_KS <= 15) {
+          if constexpr (PER_KS == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+          else if constexpr (PER_KS == 12) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) tie(af[ks][i]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) tie(bf[ks][j]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[ks][j]), __builtin_bit_cast(bf16x8, af[ks][i]),
+                                                                acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
   if constexpr (GLDS) {
     // LDS-DMA pipeline: tile t+1 streams into the other stage while tile t is multiplied; a counted vmcnt leaves
     // the newest tile's pieces in flight across the raw barrier (a __syncthreads() would drain them).
@@ -651,7 +718,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m,
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        compute_tile(cur, cur + A_BYTES);
+        compute_tile_asm(cur, cur + A_BYTES);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
@@ -676,7 +743,7 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m,
           GB::issue(rsB, ldb, n0, kbeg + (t + 2) * BK, p.N, kend, smem + s2 * STAGE_BYTES + A_BYTES, wave, lane);
         }
         const char *cur = smem + st * STAGE_BYTES;
-        compute_tile(cur, cur + A_BYTES);
+        compute_tile_asm(cur, cur + A_BYTES);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         st = st == 2 ? 0 : st + 1;
       }
@@ -1103,7 +1170,7 @@ __device__ __forceinline__ void gemm256_body(const GemmParams &p, const int tile
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 af[4][2], bq0[2][2], bq1[2][2];
+  u32x4 af[4][2], bq0[2][2], bq1[2][2];    // fragments, read through frag_bf16_asm (the compiler must not guard them with vmcnt(0))
   // bias gradient riding on the weight-gradient GEMM: colsum[m] = sum_k A[k][m]. The A fragments of the wc == 0 waves of
   // the tile_n == 0 workgroups already hold every A value once; v_dot2c_f32_bf16 against (1, 1) adds a fragment's 8 k values
   // in 4 VALU instructions that issue in the shadow of the MFMAs.
@@ -1128,21 +1195,21 @@ __device__ __forceinline__ void gemm256_body(const GemmParams &p, const int tile
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) bq0[jj][ks] = frag_bf16<TB, 128, 64>(base + 1 * HALF, wc * 32 + jj * 16, ks, lane);
+        for (int ks = 0; ks < 2; ++ks) bq0[jj][ks] = frag_bf16_asm<TB, 128, 64>(base + 1 * HALF, wc * 32 + jj * 16, ks, lane);
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) af[ii][ks] = frag_bf16<TA, 128, 64>(base, wr * 64 + ii * 16, ks, lane);
+        for (int ks = 0; ks < 2; ++ks) af[ii][ks] = frag_bf16_asm<TA, 128, 64>(base, wr * 64 + ii * 16, ks, lane);
     } else if constexpr (P == 1) {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) bq1[jj][ks] = frag_bf16<TB, 128, 64>(base + 2 * HALF, wc * 32 + jj * 16, ks, lane);
+        for (int ks = 0; ks < 2; ++ks) bq1[jj][ks] = frag_bf16_asm<TB, 128, 64>(base + 2 * HALF, wc * 32 + jj * 16, ks, lane);
     } else if constexpr (P == 2) {
 #pragma unroll
       for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) af[ii][ks] = frag_bf16<TA, 128, 64>(base + 3 * HALF, wr * 64 + ii * 16, ks, lane);
+        for (int ks = 0; ks < 2; ++ks) af[ii][ks] = frag_bf16_asm<TA, 128, 64>(base + 3 * HALF, wr * 64 + ii * 16, ks, lane);
     }
     const int g = 4 * t + P;
     if (g + AHEAD <= last) issue(std::integral_constant<int, (P + AHEAD) & 3>{}, (g + AHEAD) >> 2);
@@ -1153,6 +1220,13 @@ __device__ __forceinline__ void gemm256_body(const GemmParams &p, const int tile
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) tie(af[ii][ks]);
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) { tie(bq0[jj][ks]); tie(bq1[jj][ks]); }
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
     constexpr int mh = (P >= 2) ? 1 : 0, nh = (P == 1 || P == 2) ? 1 : 0;
@@ -1162,8 +1236,8 @@ __device__ __forceinline__ void gemm256_body(const GemmParams &p, const int tile
       for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
-          acc[mh * 4 + ii][nh * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(nh ? bq1[jj][ks] : bq0[jj][ks], af[ii][ks],
-                                                                                  acc[mh * 4 + ii][nh * 2 + jj], 0, 0, 0);
+          acc[mh * 4 + ii][nh * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8, nh ? bq1[jj][ks] : bq0[jj][ks]), __builtin_bit_cast(bf16x8, af[ii][ks]), acc[mh * 4 + ii][nh * 2 + jj], 0, 0, 0);
     if constexpr (P == 0 || P == 2) {         // the phases that loaded a new A half
       if (do_colsum) {
         typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -1174,7 +1248,7 @@ __device__ __forceinline__ void gemm256_body(const GemmParams &p, const int tile
         for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 f = af[ii][ks];
+            const bf16x8 f = __builtin_bit_cast(bf16x8, af[ii][ks]);
             float c = csum[mh * 4 + ii];
             c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), ones, c, false);
             c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), ones, c, false);
