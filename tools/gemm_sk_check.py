@@ -22,7 +22,7 @@ T = torch.bfloat16
 Me, Md = 64 * 98, 64 * 196
 shapes = [("enc.qkv", Me, 2304, 768), ("enc.proj", Me, 768, 768), ("enc.fc1", Me, 3072, 768), ("enc.fc2", Me, 768, 3072),
           ("dec.qkv", Md, 1536, 512), ("dec.proj", Md, 512, 512), ("dec.fc1", Md, 2048, 512), ("dec.fc2", Md, 512, 2048),
-          ("patch", Me, 768, 1280), ("dec.embed", Me, 512, 768), ("ragged", 2000, 520, 448)]
+          ("patch", Me, 768, 1280), ("dec.embed", Me, 512, 768), ("ragged", 2000, 520, 2048)]
 only = sys.argv[1] if len(sys.argv) > 1 else ""
 tot = {1: 0.0, 12: 0.0}
 for name, M, N, K in shapes:
