@@ -1213,11 +1213,6 @@ __device__ __forceinline__ void gemm256_body(const GemmParams &p, const int tile
     }
     const int g = 4 * t + P;
     if (g + AHEAD <= last) issue(std::integral_constant<int, (P + AHEAD) & 3>{}, (g + AHEAD) >> 2);
-    {
-      const int newest = g + AHEAD <= last ? g + AHEAD : last;
-      const int rem = newest - (g + 2);
-      wait_halves(rem < 0 ? 0 : rem);
-    }
     __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -1260,6 +1255,12 @@ __device__ __forceinline__ void gemm256_body(const GemmParams &p, const int tile
     }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+    {   // the counted wait sits after the MFMA cluster (the DMA has that much longer to land) and before the barrier that
+        // publishes this wave's landed pieces to the readers of the next phase
+      const int newest = g + AHEAD <= last ? g + AHEAD : last;
+      const int rem = newest - (g + 2);
+      wait_halves(rem < 0 ? 0 : rem);
+    }
     __builtin_amdgcn_s_barrier();
   };
 
