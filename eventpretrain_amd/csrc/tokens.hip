@@ -44,21 +44,32 @@ __global__ __launch_bounds__(256) void mask_kernel(const float *noise, int L, in
   }
 }
 
-// vit.py:80-89: noise[b, gy*gw+gx] = sign * mean_{patch}( |sum_c x[b,c,y,x]| )
+// vit.py:80-89: noise[b, gy*gw+gx] = sign * mean_{patch}( |sum_c x[b,c,y,x]| ).
+// The ids that follow are an argsort of these values, and on real voxel grids |sum over bins| is near-integer, so ties
+// and one-ulp near-ties are the norm: the value must be the reference's BIT FOR BIT. Its ATen composition on the CPU is
+// torch.sum(dim=1) = bins added in order 0..C-1, abs, AvgPool2d = the window's p*p values added one after the other in
+// row-major order in f32, then ONE division by p*p (checked bit-exact against the reference, tests/golden/
+// masking_density.npz). So: the per-pixel values go to LDS and ONE lane adds them in that order -- a wave-tree sum
+// differs in the last bit and flips ids.
 __global__ __launch_bounds__(256) void density_kernel(const float *x, int C, int H, int W, int p, float sign, float *noise) {
-  __shared__ float red[16];
+  extern __shared__ float pix[];           // p*p per-pixel |sum over bins|
   const int gw = W / p, gh = H / p;
   const int cell = blockIdx.x % (gw * gh), b = blockIdx.x / (gw * gh);
   const int gy = cell / gw, gx = cell % gw;
-  float s = 0.f;
   for (int e = threadIdx.x; e < p * p; e += blockDim.x) {
     const int py = e / p, px = e % p;
-    float t = 0.f;
-    for (int c = 0; c < C; ++c) t += x[(((int64_t)b * C + c) * H + gy * p + py) * W + gx * p + px];
-    s += fabsf(t);
+    const float *src = x + (((int64_t)b * C) * H + gy * p + py) * W + gx * p + px;
+    float t = src[0];
+    for (int c = 1; c < C; ++c) t += src[(int64_t)c * H * W];
+    pix[e] = fabsf(t);
   }
-  s = block_sum(s, red);
-  if (threadIdx.x == 0) noise[(int64_t)b * gw * gh + cell] = sign * s / (float)(p * p);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int e = 0; e < p * p; ++e) s += pix[e];
+    const float m = s / (float)(p * p);
+    noise[(int64_t)b * gw * gh + cell] = sign < 0.f ? -m : m;
+  }
 }
 
 // cols[(b, j), c*p*p + py*p + px] = x[b, c, gy*p+py, gx*p+px], token = ids_keep[b,j] (or j) -> (gy, gx)
@@ -230,7 +241,8 @@ extern "C" int evp_mask_from_noise(const float *noise, int B, int L, int len_kee
 extern "C" int evp_density_noise(const float *x, int B, int C, int H, int W, int patch, float sign, float *noise, void *stream) {
   EVP_CHECK_ARG(x && noise, EVP_EINVAL, "evp_density_noise: null pointer");
   EVP_CHECK_ARG(B > 0 && C > 0 && patch > 0 && H % patch == 0 && W % patch == 0, EVP_ESHAPE, "evp_density_noise: bad shape");
-  hipLaunchKernelGGL(density_kernel, dim3(B * (H / patch) * (W / patch)), dim3(256), 0, (hipStream_t)stream, x, C, H, W, patch, sign, noise);
+  EVP_CHECK_ARG(patch * patch * 4 <= 48 * 1024, EVP_ESHAPE, "evp_density_noise: patch %d too large", patch);
+  hipLaunchKernelGGL(density_kernel, dim3(B * (H / patch) * (W / patch)), dim3(256), patch * patch * sizeof(float), (hipStream_t)stream, x, C, H, W, patch, sign, noise);
   EVP_CHECK_LAUNCH("evp_density_noise");
   return EVP_OK;
 }

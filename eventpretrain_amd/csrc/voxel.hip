@@ -37,8 +37,10 @@ __device__ __forceinline__ double stamp(const double *ev, int64_t i, int is_txyp
 __device__ __forceinline__ double ts_of(double t, double t0, double dT, int bins) { return (double)(bins - 1) * (t - t0) / dT; }
 
 // cuts[c][k], k = 0..bins: first row i (clip-relative) with ts_i >= k; cuts[c][bins+1] = n (unused sentinel)
+// flags (verify mode, else NULL): flags[c] = 1 when the cuts partition the clip the way sorted stamps do (cuts[0] == 0, non-
+// decreasing, cuts[bins] == n) -- the bin kernel then clears it if it meets a row outside the region its position says.
 __global__ __launch_bounds__(512) void voxel_cuts_kernel(const double *events, const int64_t *offsets, int bins, int is_txyp,
-                                                         int64_t *cuts) {
+                                                         int64_t *cuts, int32_t *flags) {
   const int c = blockIdx.x;
   const int64_t beg = offsets[c], n = offsets[c + 1] - beg;
   const double *ev = events + beg * 4;
@@ -46,6 +48,7 @@ __global__ __launch_bounds__(512) void voxel_cuts_kernel(const double *events, c
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   if (n <= 0) {
     for (int k = threadIdx.x; k <= bins + 1; k += blockDim.x) out[k] = 0;
+    if (flags && threadIdx.x == 0) flags[c] = 1;
     return;
   }
   const double t0 = stamp(ev, 0, is_txyp), t1 = stamp(ev, n - 1, is_txyp);
@@ -73,6 +76,14 @@ __global__ __launch_bounds__(512) void voxel_cuts_kernel(const double *events, c
     if (lane == 0) out[k] = lo;
   }
   if (threadIdx.x == 0) out[bins + 1] = n;
+  if (flags) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      bool ok = out[0] == 0 && out[bins] == n;
+      for (int k = 0; k < bins; ++k) ok = ok && out[k] <= out[k + 1];
+      flags[c] = ok ? 1 : 0;
+    }
+  }
 }
 
 constexpr int VB_THREADS = 1024;
@@ -109,8 +120,12 @@ __device__ __forceinline__ bool in_safe_range(double v) {
 // second reader finds the rows in the XCD's L2 instead of fetching them again (all blocks of a clip share an XCD).
 template <bool TXYP>
 __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *events, const int64_t *offsets, const int64_t *cuts,
-                                                               int n_clips, int bins, int H, int W, int assume_sorted, int tile_rows,
-                                                               int n_yt, double sx, double sy, float *out) {
+                                                               int n_clips, int bins, int H, int W, int mode, int tile_rows,
+                                                               int n_yt, double sx, double sy, float *out, int32_t *flags) {
+  // mode 0: any row order (every block scans its whole clip); 1: sorted stamps promised (slabs between the cuts);
+  // 2: as 1, but every row that is normalised is checked to lie in the region its POSITION says (floor(ts) == k for a row
+  //    of slab [cuts[k], cuts[k+1])) -- the only property of sortedness the slab schedule uses -- and flags[clip] is
+  //    cleared otherwise; 3: repair pass = mode 0 for the clips whose flag is 0, nothing for the others.
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float *tile = reinterpret_cast<float *>(smem_raw);
   const int n_j = bins > 1 ? bins - 1 : 1;
@@ -124,6 +139,12 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *eve
     clip = blockIdx.x / per_clip;
     sub = blockIdx.x % per_clip;
   }
+  if (mode >= 2) {
+    const int ok = flags[clip];
+    if (mode == 2 ? !ok : ok) return;      // 2: the cuts are no partition, the repair pass takes the clip; 3: nothing to repair
+  }
+  const bool assume_sorted = mode == 1 || mode == 2;
+  bool inconsistent = false;
   const int j = sub / n_yt, yt = sub % n_yt;
   const int y0 = yt * tile_rows, y1 = (y0 + tile_rows < H) ? y0 + tile_rows : H;
   const int tile_elems = (y1 - y0) * W;
@@ -155,6 +176,7 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *eve
         const bool upper = (part == 0) == swapped;
         const int64_t lo = assume_sorted ? (upper ? cc[b] : cc[b > 0 ? b - 1 : 0]) : 0;
         const int64_t hi = assume_sorted ? (upper ? cc[b + 1] : cc[b]) : n;
+        const double region = upper ? bd : bd - 1.0;      // floor(ts) of every row of this slab if the stamps are sorted
         for (int64_t k0 = threadIdx.x; k0 < hi - lo; k0 += (int64_t)VB_THREADS * VB_UNROLL) {
           double2 ra[VB_UNROLL], rb[VB_UNROLL];
           bool live[VB_UNROLL];
@@ -179,6 +201,7 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *eve
             const double a = scale * (t - t0);
             const double ts = (clip_fast && in_safe_range(a)) ? div_by_clip_constant(a, dT, rT) : a / dT;
             const double tf = floor(ts);
+            if (mode == 2 && !(tf == region)) inconsistent = true;   // NaN included
             if (!(tf >= 0.0)) continue;                   // also rejects NaN
             float p = (float)pd;
             if (p == 0.0f) p = -1.0f;
@@ -201,6 +224,7 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *eve
       for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) dst[i] = tile[i];
     }
   }
+  if (inconsistent) flags[clip] = 0;       // every writer stores 0: no atomic needed
 }
 
 // ---- two-pass form (algo 2): decode once, bin from packed records ------------------------------------------------
@@ -366,8 +390,11 @@ extern "C" int evp_voxel_scatter_scaled_f32(const double *events, const int64_t 
   EVP_CHECK_ARG((size_t)tile_rows * W * 4 <= 160 * 1024, EVP_ESHAPE, "evp_voxel_scatter_f32: tile of %d rows x %d exceeds LDS", tile_rows, W);
   const int n_yt = (H + tile_rows - 1) / tile_rows;
   const size_t smem = (size_t)tile_rows * W * sizeof(float);
+  EVP_CHECK_ARG(assume_sorted >= 0 && assume_sorted <= 2, EVP_EINVAL, "evp_voxel_scatter_f32: assume_sorted must be 0, 1 or 2");
+  EVP_CHECK_ARG(assume_sorted != 2 || algo == 0, EVP_EUNSUPPORTED, "evp_voxel_scatter_f32: the verified mode (assume_sorted = 2) is built for algo 0");
+  int32_t *flags = assume_sorted == 2 ? reinterpret_cast<int32_t *>(workspace + (int64_t)n_clips * (bins + 2)) : nullptr;
   if (assume_sorted) {
-    hipLaunchKernelGGL(voxel_cuts_kernel, dim3(n_clips), dim3(512), 0, s, events, clip_offsets, bins, is_txyp, workspace);
+    hipLaunchKernelGGL(voxel_cuts_kernel, dim3(n_clips), dim3(512), 0, s, events, clip_offsets, bins, is_txyp, workspace, flags);
     EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(cuts)");
   }
   if (algo == 2) {
@@ -391,13 +418,16 @@ extern "C" int evp_voxel_scatter_scaled_f32(const double *events, const int64_t 
     EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_voxel_scatter_f32: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
   }
   const int n_blocks = n_clips * (bins > 1 ? bins - 1 : 1) * n_yt;  // plane 0 and plane bins-1 share a workgroup
-  if (is_txyp)
-    hipLaunchKernelGGL(voxel_bin_kernel<true>, dim3(n_blocks), dim3(VB_THREADS), smem, s, events, clip_offsets, workspace, n_clips, bins, H,
-                       W, assume_sorted, tile_rows, n_yt, scale_x, scale_y, out);
-  else
-    hipLaunchKernelGGL(voxel_bin_kernel<false>, dim3(n_blocks), dim3(VB_THREADS), smem, s, events, clip_offsets, workspace, n_clips, bins, H,
-                       W, assume_sorted, tile_rows, n_yt, scale_x, scale_y, out);
-  EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(bin)");
+  for (int pass = 0; pass < (assume_sorted == 2 ? 2 : 1); ++pass) {
+    const int mode = pass ? 3 : assume_sorted;      // verified mode: fast pass, then the repair pass for flagged clips
+    if (is_txyp)
+      hipLaunchKernelGGL(voxel_bin_kernel<true>, dim3(n_blocks), dim3(VB_THREADS), smem, s, events, clip_offsets, workspace, n_clips, bins,
+                         H, W, mode, tile_rows, n_yt, scale_x, scale_y, out, flags);
+    else
+      hipLaunchKernelGGL(voxel_bin_kernel<false>, dim3(n_blocks), dim3(VB_THREADS), smem, s, events, clip_offsets, workspace, n_clips, bins,
+                         H, W, mode, tile_rows, n_yt, scale_x, scale_y, out, flags);
+    EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(bin)");
+  }
   return EVP_OK;
 }
 

@@ -11,7 +11,10 @@ from ..._lib import call, ptr, stream_ptr
 def voxel_grid_batch(events, clip_offsets, num_bins, size, is_txyp=False, assume_sorted=True, algo=0, tile_rows=0, out=None,
                      scale=None):
     """events: float64 CUDA tensor [n_total,4]; clip_offsets: int64 CUDA tensor [n_clips+1] -> float32
-    [n_clips, num_bins, H, W]. Rows of each clip must be time-sorted unless assume_sorted=False.
+    [n_clips, num_bins, H, W]. assume_sorted=True (default): the time-slab fast path, VERIFIED per clip on the device
+    (evp_voxel_scatter_f32 assume_sorted = 2): a clip whose rows are not where sorted stamps would put them is redone by a
+    full scan, so the result is the reference's for any row order without a host read-back. assume_sorted="trust": the
+    unchecked fast path; assume_sorted=False: full scan for every clip.
     scale=(sx, sy): the loader's sensor -> input rescale (reference events_augment.py:22-26, sx = input_w / sensor_w,
     sy = input_h / sensor_h) applied to x and y inside the kernel, bit-identical to rescaling the array first."""
     _lib.require_device()
@@ -25,13 +28,17 @@ def voxel_grid_batch(events, clip_offsets, num_bins, size, is_txyp=False, assume
     if out is None:
         out = torch.empty(n_clips, num_bins, H, W, dtype=torch.float32, device=dev)
     n_total = int(events.shape[0])
+    if assume_sorted == "trust":
+        mode = 1
+    else:
+        mode = (2 if algo == 0 else 1) if assume_sorted else 0
     ws = torch.empty(n_clips * (num_bins + 2) + (3 * n_total + 1) // 2 + 2, dtype=torch.int64, device=dev)
     if scale is None:
         call("evp_voxel_scatter_f32", ptr(events), ptr(clip_offsets), n_clips, n_total, int(num_bins), H, W, int(bool(is_txyp)),
-             int(bool(assume_sorted)), int(algo), int(tile_rows), ptr(ws), ptr(out), stream_ptr())
+             mode, int(algo), int(tile_rows), ptr(ws), ptr(out), stream_ptr())
     else:
         call("evp_voxel_scatter_scaled_f32", ptr(events), ptr(clip_offsets), n_clips, n_total, int(num_bins), H, W,
-             int(bool(is_txyp)), int(bool(assume_sorted)), int(algo), int(tile_rows), float(scale[0]), float(scale[1]), ptr(ws),
+             int(bool(is_txyp)), mode, int(algo), int(tile_rows), float(scale[0]), float(scale[1]), ptr(ws),
              ptr(out), stream_ptr())
     return out
 
@@ -49,4 +56,4 @@ def events_to_voxel_grid(args, events, size, is_txyp=False):
     dev = torch.device("cuda", torch.cuda.current_device())
     ev_d = torch.from_numpy(ev).to(dev)
     off = torch.tensor([0, ev.shape[0]], dtype=torch.int64, device=dev)
-    return voxel_grid_batch(ev_d, off, args.num_bins, size, is_txyp=is_txyp, assume_sorted=is_sorted)[0]
+    return voxel_grid_batch(ev_d, off, args.num_bins, size, is_txyp=is_txyp, assume_sorted="trust" if is_sorted else False)[0]

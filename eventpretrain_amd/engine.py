@@ -55,7 +55,45 @@ class GraphedStep:
         return out[0]
 
     # ------------------------------------------------------------------------------------------------ capture
+    def _snapshot(self):
+        """Everything the warm-up steps of _capture() would otherwise leave changed: weights, module buffers (BatchNorm
+        statistics, MoCo queue and pointer), optimizer moments + step counter, and the mask-noise generator."""
+        params = [p for p in self.model.parameters()]
+        snap = dict(params=[p.detach().clone() for p in params],
+                    buffers=[(b, b.detach().clone()) for b in self.model.buffers()],
+                    step=self.opt._step, gen=self.gen.get_state(), moments={})
+        for p in params:
+            st = self.opt.state.get(p, {})
+            if "exp_avg" in st:
+                snap["moments"][p] = (st["exp_avg"].clone(), st["exp_avg_sq"].clone())
+        return snap
+
+    @torch.no_grad()
+    def _restore(self, snap):
+        """In place: the captured graphs keep pointing at these tensors."""
+        for p, v in zip(self.model.parameters(), snap["params"]):
+            p.copy_(v)
+        for b, v in snap["buffers"]:
+            b.copy_(v)
+        for p in self.model.parameters():
+            st = self.opt.state.get(p, {})
+            if "exp_avg" in st:
+                if p in snap["moments"]:
+                    st["exp_avg"].copy_(snap["moments"][p][0])
+                    st["exp_avg_sq"].copy_(snap["moments"][p][1])
+                else:                     # moments born during the warm-up: back to their initial zeros
+                    st["exp_avg"].zero_()
+                    st["exp_avg_sq"].zero_()
+        self.opt._step = snap["step"]
+        self.gen.set_state(snap["gen"])
+        ops.refresh_lp_shadows(self.model.parameters())
+
     def _capture(self, warmup):
+        # The warm-up runs real optimizer steps on whatever the static inputs hold (allocator / autograd warm-up, and the
+        # optimizer's state tensors must exist before capture). Training must nevertheless start from the weights,
+        # moments, buffers and noise stream the caller handed over -- a resumed checkpoint in particular -- so all of it is
+        # snapshotted here and put back, in place, once the graphs exist.
+        snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):       # warm up on the capture stream so every AccumulateGrad node is born there
@@ -107,6 +145,10 @@ class GraphedStep:
             dev = self.inputs[0].device
             seed = self.gen.initial_seed()
             self.gen = torch.Generator(device=dev).manual_seed(seed)      # a failed capture can poison the old generator
+            snap["gen"] = self.gen.get_state()
+        torch.cuda.synchronize()
+        self._restore(snap)
+        torch.cuda.synchronize()
 
     def resync_weights(self):
         """Call after the weights were changed behind the optimizer's back (load_state_dict, manual edits): refreshes the

@@ -158,3 +158,13 @@ def swin_tiny_window7(args, **kwargs):
     return SwinTransformer(args=args, pretrain_img_size=224, patch_size=4, decoder_num_patches=49,
                            embed_dim=[96, 192, 384, 768], depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7,
                            mlp_ratio=4., norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def swin_base_window7(args, **kwargs):
+    """Swin-Base (BASELINE.json config 5 at its named size): the reference's class (swin.py:13-292) with the standard
+    Swin-B stage plan -- depths 2-2-18-2, widths 128..1024, 4..32 heads (32 channels per head, as in Swin-T) -- for which
+    the reference itself ships no factory (swin.py:295-302 is Swin-T only). Parity: tests/golden/rec_swin_base.npz, made by
+    instantiating the reference's SwinTransformer with exactly these arguments."""
+    return SwinTransformer(args=args, pretrain_img_size=224, patch_size=4, decoder_num_patches=49,
+                           embed_dim=[128, 256, 512, 1024], depths=[2, 2, 18, 2], num_heads=[4, 8, 16, 32], window_size=7,
+                           mlp_ratio=4., norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)

@@ -40,7 +40,11 @@ class PrHubModel(nn.Module):
                 raise ValueError(args.model_size)
             self.backbone = convvit.__dict__[factory[args.model_size]](**common)
         elif args.backbone_type == "swin":
-            self.backbone = swin.__dict__["swin_tiny_window7"](**common)
+            factory = {"tiny": "swin_tiny_window7", "small": "swin_tiny_window7", "base": "swin_base_window7"}
+            # ("small" keeps selecting Swin-T: the reference ignores model_size for swin, pr_hub_model.py:61-67)
+            if args.model_size not in factory:
+                raise ValueError(args.model_size)
+            self.backbone = swin.__dict__[factory[args.model_size]](**common)
         else:
             raise ValueError(args.backbone_type)
 
@@ -149,6 +153,14 @@ def pretrain_hub_model_small_patch16(args, **kwargs):
 def pretrain_hub_model_swin_tiny_patch16(args, **kwargs):
     """Swin-T hub (BASELINE.json config 5): 49 decoder cells of 32x32 pixels (pr_hub_model.py:269-274)."""
     return PrHubModel(args=args, patch_size=32, num_patches=49, embed_dim=[96, 192, 384, 768], mlp_dim=4096,
+                      proj_mlp_layers=3, pred_mlp_layers=2, norm_layer=nn.LayerNorm, **kwargs)
+
+
+def pretrain_hub_model_swin_base_patch16(args, **kwargs):
+    """Swin-Base hub (BASELINE.json config 5 at its named size; needs args.model_size == "base"). No counterpart in the
+    reference, which only builds Swin-T; same composition one size up."""
+    kwargs.setdefault("rec_decoder_factory", "pretrain_rec_decoder_swin_base_patch32")
+    return PrHubModel(args=args, patch_size=32, num_patches=49, embed_dim=[128, 256, 512, 1024], mlp_dim=4096,
                       proj_mlp_layers=3, pred_mlp_layers=2, norm_layer=nn.LayerNorm, **kwargs)
 
 

@@ -54,6 +54,14 @@ def pretrain_rec_decoder_swin_tiny_patch32(**kwargs):
                         num_heads=8, mlp_ratio=[4, 4, 4], norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
 
 
+def pretrain_rec_decoder_swin_base_patch32(**kwargs):
+    """Decoder for the Swin-Base backbone (BASELINE.json config 5). The reference ships only the Swin-T pair
+    (pr_rec_decoder.py:81-87); this is the same class at the base decoder's width (pr_rec_decoder.py:89-95: 512 wide,
+    16 heads) on the 49 cells of 32x32 pixels of the Swin hub."""
+    return PrRecDecoder(patch_size=32, num_patches=49, encoder_embed_dim=[128, 256, 512, 1024], embed_dim=512, depth=8,
+                        num_heads=16, mlp_ratio=[4, 4, 4], norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
 def pretrain_rec_decoder_base_patch16(**kwargs):
     return PrRecDecoder(patch_size=16, num_patches=196, encoder_embed_dim=[256, 384, 768], embed_dim=512, depth=8,
                         num_heads=16, mlp_ratio=[4, 4, 4], norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)

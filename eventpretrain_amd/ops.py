@@ -272,7 +272,9 @@ class _DeferredGrads:
         self.w, self.b = [], []
         self.armed = False
         self._pin = {}
+        self._capture_pins = []     # pinned tables owned by captured HIP graphs (never rewritten; see _stage)
         self.flat_buffers = []      # flat f32 buffers holding the gradients written by the last flush(es)
+        self.track_flats = False    # set by the data-parallel reducer: without a consumer the list must not grow
 
     def arm(self):
         if not self.armed:
@@ -295,24 +297,32 @@ class _DeferredGrads:
         self.arm()
 
     def _stage(self, key, arr, dev):
-        """numpy bytes -> persistent pinned staging -> fresh device tensor (async H2D; capturable in a HIP graph
-        once the pinned buffer exists, i.e. after one eager step)."""
+        """numpy bytes -> pinned staging -> fresh device tensor (async H2D).
+        Eager: one persistent pinned buffer per table key, guarded by an event so that it is not rewritten before the
+        previous step's copy has run. Under HIP-graph capture: a NEW pinned buffer per table, owned by this object for
+        the life of the process and never written again -- the graph's H2D node re-reads it at every replay, so it
+        must not be shared with later eager steps or with other captures."""
         raw = torch.from_numpy(arr)
         n = raw.numel()
-        capturing = torch.cuda.is_current_stream_capturing()
+        if torch.cuda.is_current_stream_capturing():
+            pin = torch.empty(max(n, 1), dtype=torch.uint8).pin_memory()
+            pin[:n].copy_(raw)
+            self._capture_pins.append(pin)
+            d = torch.empty(n, dtype=torch.uint8, device=dev)
+            d.copy_(pin[:n], non_blocking=True)
+            return d
         ent = self._pin.get(key)
         if ent is None or ent[0].numel() < n:
             ent = [torch.empty(max(n, 1 << 16), dtype=torch.uint8).pin_memory(), None]
             self._pin[key] = ent
         pin, ev = ent
-        if ev is not None and not capturing:
+        if ev is not None:
             ev.synchronize()              # the previous step's H2D copy out of this pinned buffer must have run
         pin[:n].copy_(raw)
         d = torch.empty(n, dtype=torch.uint8, device=dev)
         d.copy_(pin[:n], non_blocking=True)
-        if not capturing:
-            ent[1] = torch.cuda.Event()
-            ent[1].record()
+        ent[1] = torch.cuda.Event()
+        ent[1].record()
         return d
 
     @staticmethod
@@ -379,7 +389,8 @@ class _DeferredGrads:
             for p_, n_ in zip(fresh, sizes):
                 p_.grad = flat[o:o + p_.numel()].view_as(p_)
                 o += n_
-            self.flat_buffers.append(flat)
+            if static or self.track_flats:      # only a reducer (or a plan being built) takes these; otherwise the
+                self.flat_buffers.append(flat)  # parameters' .grad views are the only owners and zero_grad frees them
             return flat, {id(p_) for p_ in fresh}
 
         if w:
@@ -532,6 +543,14 @@ def hold_deferred_grads(flag):
 
 def build_deferred_plan(n_chunks=4):
     return _deferred.build_plan(n_chunks)
+
+
+def track_deferred_flat_buffers(flag):
+    """Called by the data-parallel reducer: keep the flat gradient buffers of each flush for take_deferred_flat_buffers().
+    Off by default -- without a consumer the list would pin one set of gradient buffers per step."""
+    _deferred.track_flats = bool(flag)
+    if not flag:
+        _deferred.flat_buffers = []
 
 
 def take_deferred_flat_buffers():
@@ -972,6 +991,10 @@ class InfoNCEQueueFn(torch.autograd.Function):
         call("evp_rowdot_f32", ptr(q2), ptr(k2), R, C_, ptr(pos), stream_ptr())
         qw = queue.detach() if Kp == K else torch.nn.functional.pad(queue.detach(), (0, Kp - K))   # tiny test queues only
         ql, qul = cast(q2, Tc), cast(qw.contiguous(), Tc)
+        if qul.data_ptr() == queue.data_ptr():
+            # f32 mode with K % 8 == 0: cast()/contiguous() returned the live buffer, which _dequeue_and_enqueue overwrites
+            # in place before backward reads it (the reference uses self.queue.clone().detach(), pr_hub_model.py:152)
+            qul = qul.clone()
         neg = torch.empty(B, L, Kp, dtype=torch.float32, device=dev)
         # neg[b,l,:] = q[b,l,:] . queue[:,l,:]   ('blc,clk->blk'), batched over l
         gemm(ql, qul, neg, M=B, N=K, K=C_, trans_b=True, lda=L * C_, ldb=L * Kp, ldc=L * Kp, batch=(L, 1),

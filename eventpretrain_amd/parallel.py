@@ -121,11 +121,34 @@ class OverlappedPlan:
 
 
 class BucketedGradReducer:
-    def __init__(self, params, bucket_mb=64.0, process_group=None):
+    def __init__(self, params, bucket_mb=64.0, process_group=None, buffers=None, broadcast=True):
+        """`params`: the model's parameters; `buffers`: its buffers (BatchNorm statistics, MoCo queue), broadcast once
+        together with the parameters. With `broadcast` (default) every rank starts from rank 0's weights, which is what
+        DistributedDataParallel's constructor does for the reference (main_pretrain.py:319, seeds differ per rank,
+        main_pretrain.py:174); the bf16 weight shadows are refreshed afterwards."""
+        from . import ops
         self.group = process_group
+        params = list(params)
         self.params = [p for p in params if p.requires_grad]
         self.bucket_mb = bucket_mb                    # kept for API compatibility; flat buffers are reduced whole
         self._bucket, self._sig = None, None
+        ops.track_deferred_flat_buffers(True)         # this object consumes them in _collect / make_overlapped_plan
+        if broadcast and dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+            src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+            with torch.no_grad():
+                for t in params + list(buffers or []):
+                    dist.broadcast(t.data, src=src, group=process_group)
+            if params and params[0].is_cuda:
+                ops.refresh_lp_shadows(params)
+
+    @classmethod
+    def for_module(cls, module, **kw):
+        """Reducer over a module's parameters with its buffers included in the initial broadcast."""
+        return cls(module.parameters(), buffers=module.buffers(), **kw)
+
+    @property
+    def world_size(self):
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
 
     def _collect(self):
         from . import ops

@@ -194,17 +194,30 @@ def get_grad_norm_(parameters, norm_type: float = 2.0, optimizer=None):
 class NativeScalerWithGradNormCount:
     """Callable with the reference's signature (utils/misc.py:274-300). The reference wraps a fp16 GradScaler; this
     path computes in bf16 / f32 with f32 accumulation, which needs no loss scaling, so the object only sequences
-    backward -> grad norm -> optimizer step. state_dict() keeps the key layout of a disabled GradScaler."""
+    backward -> (data-parallel gradient all-reduce) -> grad norm -> optimizer step. state_dict() keeps the key layout of
+    a disabled GradScaler.
+
+    `reducer` (a parallel.BucketedGradReducer, here or per call) takes the place of the reference's DDP wrap
+    (main_pretrain.py:319): after the LAST accumulation backward of an optimizer step it SUM-all-reduces the gradients;
+    the mean (1 / world) rides on FusedAdamW.grad_scale. The returned norm and the clip coefficient are those of the
+    MEAN gradient, as under DDP."""
     state_dict_key = "amp_scaler"
 
-    def __init__(self):
+    def __init__(self, reducer=None):
         self._state = {}
+        self.reducer = reducer
 
-    def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
+    def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True, reducer=None):
         loss.backward(create_graph=create_graph)
         if not update_grad:
             return None
+        reducer = reducer if reducer is not None else self.reducer
+        if reducer is not None:
+            reducer.finish()
         norm = get_grad_norm_(parameters, optimizer=optimizer)
+        gs = float(getattr(optimizer, "grad_scale", 1.0))
+        if reducer is not None and gs != 1.0:
+            norm = norm * gs                 # the buffers hold the SUM over ranks; grad_scale = 1 / world makes it the mean
         if clip_grad is not None:
             # torch.nn.utils.clip_grad_norm_(parameters, clip_grad) (reference utils/misc.py:289-290): every gradient times
             # min(1, clip / (total_norm + 1e-6)). The factor rides on FusedAdamW's grad_scale for this step (the kernel

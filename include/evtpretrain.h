@@ -39,11 +39,15 @@ const char *evp_target_arch(void);
  * Replaces dataset/dataset_utils/events_to_voxel_grid.py:4-61 (two index_add_ scatters, :46-57) for a BATCH of
  * clips. events: float64 [n_total,4], columns (x,y,t,p) or (t,x,y,p) if is_txyp; clip c owns rows
  * [clip_offsets[c], clip_offsets[c+1]). out: float32 [n_clips,bins,H,W], fully overwritten.
- * assume_sorted != 0: rows of each clip are non-decreasing in t (what every reference dataset produces; the
- * reference itself relies on it for t0/t1, :19-22) -> each block scans only its time slab. assume_sorted == 0:
- * correct for any row order (every block scans the whole clip).
+ * assume_sorted == 1: rows of each clip are non-decreasing in t (what every reference dataset produces; the
+ * reference itself relies on it for t0/t1, :19-22) -> each block scans only its time slab; NOT checked.
+ * assume_sorted == 2 (algo 0): the same fast path, VERIFIED on the device with no host sync: while binning, every row is
+ * checked to lie in the time slab its position says (the one property of sortedness the slab schedule uses); clips that
+ * fail are redone by a repair pass that scans the whole clip, the others cost one extra empty launch. The result is the
+ * reference's for any row order. workspace then also holds int32 [n_clips] flags after the cuts.
+ * assume_sorted == 0: correct for any row order (every block scans the whole clip).
  * n_events_total = clip_offsets[n_clips] (known to the host that built the offsets).
- * algo 0 (default) = single-pass LDS-binned straight from the float64 rows, workspace int64 [n_clips*(bins+2)].
+ * algo 0 (default) = single-pass LDS-binned straight from the float64 rows, workspace int64 [n_clips*(bins+2) + (n_clips+1)/2].
  * algo 2 = decode-once two-pass form: pass A packs every event into 12 bytes (pixel/bin key + the two float32
  * contributions), pass B bins the packed streams; workspace int64 [n_clips*(bins+2) + (3*n_events_total + 1)/2]
  * (measured 1.3x slower than algo 0 on MI355X; kept for A/B). algo 1 = memset + global float atomics, no workspace

@@ -14,7 +14,7 @@ module object supplying `to_2tuple`, `trunc_normal_` and a `DropPath` that is
 never executed (all drop rates are 0 -> nn.Identity, vit_block.py:241) is put
 in sys.modules for the duration of this script.
 
-Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin,swincon,augment,ftcls]
+Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin,swincon,augment,evaug,ftcls,density,autocast,conbase,swinbase]
 """
 import argparse
 import json
@@ -602,8 +602,207 @@ def gen_ftcls():
         save("ft_cls_" + tag, **out)
 
 
+# --------------------------------------------------------------------------- density / anti-density masking
+def gen_density():
+    """ViT.random_masking of the reference itself with masking_strategy in {density, anti-density} (vit.py:80-103):
+    (a) voxel grids the reference makes from synthetic clips (|sum over bins| is near-integer: near-ties are the norm),
+    one of them with an event-free band (exact ties at 0); (b) bell-shaped random grids. The fixture keeps the clip
+    seeds / generator names (the grids are re-made bit-exactly by the tests through the pinned voxel oracle), the
+    reference's density noise and its ids. Also records whether the reference's ids equal a STABLE argsort of its noise
+    (they do on this torch build: ties -> lower index first)."""
+    _ref()
+    torch.set_num_threads(1)
+    from dataset.dataset_utils.events_to_voxel_grid import events_to_voxel_grid
+    from model.backbone.vit import ViT
+    out, cases = {}, []
+
+    def grids_from_clips(seeds, n_ev, band=None):
+        gs = []
+        for sd in seeds:
+            ev = synthetic_events(sd, n_ev)
+            if band is not None:                      # drop the events of some patch rows: exact zero densities
+                keep = ~((ev[:, 1] >= band[0]) & (ev[:, 1] < band[1]))
+                ev = ev[keep]
+            gs.append(events_to_voxel_grid(make_args(num_bins=5), ev.copy(), (224, 224)))
+        return torch.stack([torch.as_tensor(g) for g in gs]).float()
+
+    inputs = [("clips", dict(kind="clips", seeds=[300, 301], n_ev=100_000, band=None)),
+              ("sparse", dict(kind="clips", seeds=[302, 303], n_ev=3_000, band=[64, 128])),
+              ("randn", dict(kind="randn", name="density.randn", B=3))]
+    for tag, spec in inputs:
+        if spec["kind"] == "clips":
+            x = grids_from_clips(spec["seeds"], spec["n_ev"], spec["band"])
+        else:
+            x = det_normalish(spec["name"], (spec["B"], 5, 224, 224)) * 0.5
+        out[f"{tag}_x_checksums"] = checksums(x)
+        for strat in ("density", "anti-density"):
+            for ratio in (0.5, 0.75):
+                a = make_args(mask_ratio=ratio, masking_strategy=strat)
+                m = ViT(a, input_size=224, patch_size=16, embed_dim=32, depth=1, num_heads=1, mask_ratio=ratio)
+                ids_keep, mask, ids_restore = m.random_masking(x)
+                with torch.no_grad():
+                    dens = torch.nn.AvgPool2d(16, 16)(abs(torch.sum(x, dim=1))).flatten(1)
+                noise = dens if strat == "density" else -dens
+                key = f"{tag}_{strat}_{int(ratio * 100)}"
+                stable = torch.argsort(noise, dim=1, stable=True)
+                out[key + "_noise"], out[key + "_ids_keep"] = noise, ids_keep
+                out[key + "_mask"], out[key + "_ids_restore"] = mask, ids_restore
+                srt = torch.sort(noise, dim=1).values
+                n_ties = int((srt[:, 1:] == srt[:, :-1]).sum())
+                eq = bool(torch.equal(stable[:, :ids_keep.shape[1]], ids_keep))
+                cases.append(dict(key=key, tag=tag, strategy=strat, ratio=ratio, ties=n_ties, ref_equals_stable=eq))
+                print(f"  {key}: ties={n_ties} reference ids == stable argsort: {eq}")
+    out["inputs"] = np.array(json.dumps(dict(inputs)))
+    out["cases"] = np.array(json.dumps(cases))
+    save("masking_density", **out)
+    torch.set_num_threads(8)
+
+
+# --------------------------------------------------------------------------- bf16 autocast of the reference (CPU)
+def gen_autocast():
+    """SURVEY.md 8d parity gates: the reference's own step under torch.autocast("cpu", bfloat16) on the inputs of the
+    rec_{tiny,small,base} fixtures -- what "the reference in bf16" gives, to report the HIP bf16 mode against (the fp32
+    fixture stays the parity gate)."""
+    _ref()
+    out = {}
+    for tag in ("tiny", "small", "base"):
+        if tag == "small":
+            from model.pretrain.pr_hub_model import pretrain_hub_model_small_patch16
+            cfg = dict(input=224, patch=16, mask_ratio=0.5, B=2)
+            a = make_args(model_size="small", pr_phase="rec")
+            hub = pretrain_hub_model_small_patch16(a, emb_frames_dim=512, queue_length=1024, T=0.07)
+            det_fill_module_(hub)
+            hub.train(True)
+            fwd = lambda x, y: hub(x, y, is_rec=True)
+        else:
+            cfg = CFGS[tag]
+            a, hub = _compose(cfg)
+
+            def fwd(x, y, hub=hub, a=a, cfg=cfg):
+                emb_l1, emb_l2, emb_lh, mask, ids_restore = hub.backbone(x, mask=True)
+                pred = hub.pretrain_rec_decoder(emb_lh, ids_restore)
+                return (_rec_loss_ref(a, cfg["patch"], pred.float(), y, mask),)
+        x, y, noise = _inputs(tag, cfg)
+        real_rand = torch.rand
+        torch.rand = lambda *s, **k: noise.clone()
+        try:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                loss = fwd(x, y)[0]
+        finally:
+            torch.rand = real_rand
+        loss.float().backward()
+        gn = float(np.sqrt(sum(p.grad.double().pow(2).sum().item() for p in hub.parameters() if p.grad is not None)))
+        out[f"{tag}_loss"] = np.array(float(loss))
+        out[f"{tag}_total_grad_norm"] = np.array(gn)
+        print(f"  {tag}: autocast-bf16 loss {float(loss):.6f}, total grad norm {gn:.6f}")
+    save("rec_autocast_bf16", **out)
+
+
+# --------------------------------------------------------------------------- ViT-Base contrastive stage (config 3)
+def gen_con_base():
+    """PrHubModel.forward(is_rec=False) through the reference's pretrain_hub_model_base_patch16 (ViT-Base, 768-wide heads,
+    BASELINE.json config 3) with the queue, B=2, queue_length=8 (a multiple of 8: the f32 path then reads the live queue
+    buffer layout without padding). Same contents as con_small_queue."""
+    _ref()
+    from model.pretrain.pr_hub_model import pretrain_hub_model_base_patch16
+    a = make_args(model_size="base", pr_phase="con", use_queue=True, mask_ratio=0.0)
+    hub = pretrain_hub_model_base_patch16(a, emb_frames_dim=512, queue_length=8, T=0.07)
+    det_fill_module_(hub)
+    hub.train(True)
+    x = det_normalish("conb.voxels", (2, 5, 224, 224)) * 0.5
+    clip = det_normalish("conb.clip_emb", (2, 197, 512))
+    q0 = hub.queue.clone()
+    loss, emb_h_org, emb_h_proj, clip_org, clip_proj, attn = hub(x, clip)
+    loss.backward()
+    out = dict(loss=loss.detach().double(), emb_h_org_checksums=checksums(emb_h_org),
+               emb_h_proj_checksums=checksums(emb_h_proj), clip_org_checksums=checksums(clip_org),
+               clip_proj_checksums=checksums(clip_proj), attn_checksums=checksums(attn))
+    names, gn = [], []
+    for n, p in hub.named_parameters():
+        if p.grad is not None:
+            names.append(n)
+            gn.append(p.grad.double().norm().item())
+    out["grad_names"], out["grad_norms"] = np.array(json.dumps(names)), np.array(gn)
+    out["queue_after_checksums"] = checksums(hub.queue)
+    out["queue_ptr_after"] = hub.queue_ptr.clone()
+    out["queue_changed"] = np.array(float((hub.queue - q0).abs().sum()))
+    bn = {k: checksums(v) for k, v in hub.state_dict().items() if "running_" in k}
+    out["bn_keys"] = np.array(json.dumps(list(bn.keys())))
+    out["bn_checksums"] = np.stack(list(bn.values()))
+    out["state_keys"] = np.array(json.dumps({k: list(v.shape) for k, v in hub.state_dict().items()}))
+    save("con_base_queue", **out)
+    # the 'adj' ("Trans") stage on the same inputs: every backbone parameter frozen except norm_layer
+    # (main_pretrain.py:281-284); same forward, gradients only for the heads / CLIP branch / backbone.norm_layer
+    hub2 = pretrain_hub_model_base_patch16(make_args(model_size="base", pr_phase="adj", use_queue=True, mask_ratio=0.0),
+                                           emb_frames_dim=512, queue_length=8, T=0.07)
+    det_fill_module_(hub2)
+    hub2.train(True)
+    for k, v in hub2.backbone.named_parameters():
+        if "norm_layer" not in k:
+            v.requires_grad = False
+    loss2 = hub2(x, clip)[0]
+    loss2.backward()
+    names, gn = [], []
+    for n, p in hub2.named_parameters():
+        if p.grad is not None:
+            names.append(n)
+            gn.append(p.grad.double().norm().item())
+    save("adj_base_queue", loss=loss2.detach().double(), grad_names=np.array(json.dumps(names)), grad_norms=np.array(gn),
+         frozen=np.array(json.dumps([n for n, p in hub2.named_parameters() if not p.requires_grad])))
+
+
+# --------------------------------------------------------------------------- Swin-Base (config 5 at its named width)
+SWIN_BASE = dict(input=224, patch=32, dims=[128, 256, 512, 1024], depths=[2, 2, 18, 2], heads=[4, 8, 16, 32], window=7,
+                 dec_dim=512, dec_depth=8, dec_heads=16, mask_ratio=0.5, B=2)
+
+
+def gen_swin_base():
+    """Swin-Base (depths 2-2-18-2, widths 128..1024, window 7) hand-composed from the reference CLASSES -- the
+    reference ships only the Swin-T factory (swin.py:295-302) -- with a PrRecDecoder of the base width, masked
+    reconstruction step, B=2, closed-form weights. Same contents as rec_swin_tiny (checksums instead of full tensors)."""
+    _ref()
+    from functools import partial
+    from model.backbone.swin import SwinTransformer
+    from model.pretrain.pr_rec_decoder import PrRecDecoder
+    cfg = SWIN_BASE
+    a = make_args(model_size="base", pr_phase="rec", backbone_type="swin")
+    ln = partial(torch.nn.LayerNorm, eps=1e-6)
+    bb = SwinTransformer(args=a, pretrain_img_size=224, patch_size=4, decoder_num_patches=49, num_bins=5, mask_ratio=0.5,
+                         embed_dim=cfg["dims"], depths=cfg["depths"], num_heads=cfg["heads"], window_size=7, mlp_ratio=4.,
+                         drop_rate=0., attn_drop_rate=0., drop_path_rate=0., norm_layer=ln)
+    dec = PrRecDecoder(patch_size=32, num_patches=49, encoder_embed_dim=cfg["dims"], embed_dim=cfg["dec_dim"],
+                       depth=cfg["dec_depth"], num_heads=cfg["dec_heads"], mlp_ratio=[4, 4, 4], norm_layer=ln, frame_chans=1)
+
+    class Hub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone, self.pretrain_rec_decoder = bb, dec
+
+    hub = Hub()
+    det_fill_module_(hub)
+    hub.train(True)
+    keep = {}
+
+    def fwd(x, y):
+        (emb_l1, emb_l2, emb_l3, emb_l4, emb_lh, c1, c2, c3, c4, mask, ids_restore, attn) = hub.backbone(x, mask=True)
+        pred = hub.pretrain_rec_decoder(emb_lh, ids_restore)
+        loss = _rec_loss_ref(a, 32, pred, y, mask)
+        keep.update(emb_l3=emb_l3, emb_l4=emb_l4, attn=attn)
+        return loss, emb_l1, emb_l2, emb_lh, pred, mask, ids_restore
+
+    def extra(res):
+        return dict(emb_l3_checksums=checksums(keep["emb_l3"]), emb_l4_checksums=checksums(keep["emb_l4"]),
+                    attn_checksums=checksums(keep["attn"]), attn_shape=np.array(keep["attn"].shape))
+
+    out = _run_rec("swinb", cfg, fwd, list(hub.named_parameters()), extra)
+    out["cfg"] = np.array(json.dumps(cfg))
+    out["state_keys"] = np.array(json.dumps({k: list(v.shape) for k, v in hub.state_dict().items()}))
+    save("rec_swin_base", **out)
+
+
 GENS = dict(voxel=gen_voxel, pos=gen_pos, mask=gen_mask, tiny=lambda: gen_composed("tiny"), small=gen_small,
-            base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall, swin=gen_swin, swincon=gen_swincon, augment=gen_augment, evaug=gen_evaug, ftcls=gen_ftcls)
+            base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall, swin=gen_swin, swincon=gen_swincon, augment=gen_augment, evaug=gen_evaug, ftcls=gen_ftcls,
+            density=gen_density, autocast=gen_autocast, conbase=gen_con_base, swinbase=gen_swin_base)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

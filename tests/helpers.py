@@ -62,3 +62,54 @@ def rec_inputs(tag, cfg):
 
 def jl(a):
     return json.loads(str(a))
+
+
+# ----------------------------------------------------------------------------------------------- density masking
+def density_inputs(d, tag):
+    """Re-make the input grids of tests/golden/masking_density.npz bit for bit: clip cases go through the pinned CPU
+    voxel oracle (bit-exact against the reference's events_to_voxel_grid), the random case through det_normalish. The
+    fixture's checksums of the reference-made grids are asserted."""
+    from eventpretrain_amd.testing import det_normalish, synthetic_events
+    from oracle.voxel_oracle import voxel_grid
+    spec = jl(d["inputs"])[tag]
+    if spec["kind"] == "clips":
+        gs = []
+        for sd in spec["seeds"]:
+            ev = synthetic_events(sd, spec["n_ev"])
+            if spec["band"] is not None:
+                ev = ev[~((ev[:, 1] >= spec["band"][0]) & (ev[:, 1] < spec["band"][1]))]
+            gs.append(torch.from_numpy(voxel_grid(ev, 5, (224, 224))))
+        x = torch.stack(gs).float()
+    else:
+        x = det_normalish(spec["name"], (spec["B"], 5, 224, 224)) * 0.5
+    # (float64 sums of identical float32 data; only the summation order of torch.sum varies with the thread count)
+    assert np.allclose(checksums(x), d[f"{tag}_x_checksums"], rtol=1e-12, atol=0), f"input grids of case {tag} differ from the fixture's"
+    return x
+
+
+def assert_ids_equal_up_to_ties(noise, keep, ref, got, what=""):
+    """ref / got = (ids_keep, mask, ids_restore) as numpy. The order among EQUAL noise values is not a property of the
+    reference's algorithm but of the sort routine torch picked (x86-simd-sort on the CPU build that made the fixture, a
+    radix sort on CUDA): an implementation must (1) produce a valid ascending argsort, (2) agree with the reference on
+    every token whose noise value is unique in its row -- rank, keep-membership and mask -- and (3) give each group of
+    tied tokens the same SET of ranks. Rows without ties are therefore compared bit for bit."""
+    noise = np.asarray(noise)
+    B, L = noise.shape
+    for name, (ids_keep, mask, restore) in (("reference", ref), ("implementation", got)):
+        for b in range(B):
+            assert sorted(restore[b].tolist()) == list(range(L)), (what, name, b, "ids_restore is not a permutation")
+            order = np.argsort(restore[b], kind="stable")
+            assert np.all(np.diff(noise[b][order]) >= 0), (what, name, b, "not an ascending argsort")
+            assert np.array_equal(order[:keep], ids_keep[b]), (what, name, b, "ids_keep is not the head of the order")
+            assert np.array_equal(mask[b], (restore[b] >= keep).astype(np.float32)), (what, name, b, "mask")
+    for b in range(B):
+        vals, inv, cnt = np.unique(noise[b], return_inverse=True, return_counts=True)
+        uniq = cnt[inv] == 1
+        assert np.array_equal(ref[2][b][uniq], got[2][b][uniq]), (what, b, "rank of a token with a unique noise value")
+        assert np.array_equal(ref[1][b][uniq], got[1][b][uniq]), (what, b, "mask of a token with a unique noise value")
+        for g in np.nonzero(cnt > 1)[0]:
+            idx = np.nonzero(inv == g)[0]
+            assert sorted(ref[2][b][idx].tolist()) == sorted(got[2][b][idx].tolist()), (what, b, "rank set of a tie group")
+        if not (cnt > 1).any():
+            for k in range(3):
+                assert np.array_equal(ref[k][b], got[k][b]), (what, b, k)

@@ -395,3 +395,101 @@ def test_ft_cls_matches_reference(tag):
     for k in ("classify_head.weight", "classify_head.bias"):
         ref = torch.from_numpy(d["grad::" + k])
         assert torch.allclose(sd[k].grad, ref, atol=1e-6 + 1e-4 * ref.abs().max().item(), rtol=1e-4), k
+
+
+# ----------------------------------------------------------------------------------------------- round 2 fixtures
+def test_density_masking_matches_reference():
+    """vit.py:80-103 with masking_strategy density / anti-density: the oracle's noise equals the reference's bit for bit
+    (voxel-made grids with their many exact ties, an event-free band, random grids), its ids agree with the reference's up to
+    the order among tied values (helpers.assert_ids_equal_up_to_ties says why that order is not a property of the algorithm)."""
+    from helpers import assert_ids_equal_up_to_ties, density_inputs
+    d = load_golden("masking_density")
+    seen_ties = seen_exact = 0
+    for c in jl(d["cases"]):
+        key = c["key"]
+        x = density_inputs(d, c["tag"])
+        n = mo.density_noise(x, 16, c["strategy"])
+        assert np.array_equal(n.numpy(), d[key + "_noise"]), key
+        k, m, r = mo.masking_from_noise(n, c["ratio"])
+        assert_ids_equal_up_to_ties(d[key + "_noise"], k.shape[1], (d[key + "_ids_keep"], d[key + "_mask"], d[key + "_ids_restore"]),
+                                    (k.numpy(), m.numpy(), r.numpy()), key)
+        seen_ties += c["ties"] > 0
+        seen_exact += c["ties"] == 0
+    assert seen_ties and seen_exact
+
+
+def _con_state_dict(d, grid=14):
+    from eventpretrain_amd.testing import det_uniform, det_value_for
+    sd = {}
+    for k, shp in jl(d["state_keys"]).items():
+        leaf = k.split(".")[-1]
+        if leaf == "pos_embed":
+            sd[k] = torch.from_numpy(mo.sincos_2d(shp[-1], grid)).float().unsqueeze(0)
+        elif leaf == "queue":
+            sd[k] = torch.nn.functional.normalize(det_uniform(k, shp, -1.0, 1.0), dim=0)
+        elif leaf == "queue_ptr":
+            sd[k] = torch.zeros(1, dtype=torch.long)
+        else:
+            sd[k] = det_value_for(k, shp)
+        if sd[k].is_floating_point() and leaf not in ("pos_embed", "queue", "running_mean", "running_var"):
+            sd[k].requires_grad_(True)
+    return sd
+
+
+@pytest.mark.slow
+def test_con_base_and_adj_match_reference():
+    """BASELINE.json config 3 at its named width: the reference's ViT-Base hub in the `con` phase (queue length 8) and the
+    same step with the backbone frozen except norm_layer (`adj`, main_pretrain.py:281-284)."""
+    from eventpretrain_amd.testing import det_normalish
+    d = load_golden("con_base_queue")
+    sd = _con_state_dict(d)
+    x = det_normalish("conb.voxels", (2, 5, 224, 224)) * 0.5
+    clip = det_normalish("conb.clip_emb", (2, 197, 512))
+    cfg = dict(patch=16, heads=12, T=0.07, use_queue=True)
+    loss, h_org, h_proj, c_org, c_proj, attn, side = mo.con_step(sd, x, clip, cfg)
+    assert loss.item() == pytest.approx(float(d["loss"]), rel=5e-6)
+    assert_checksums(h_org, d["emb_h_org_checksums"], 2e-5)
+    assert_checksums(h_proj, d["emb_h_proj_checksums"], 5e-5)
+    assert_checksums(attn, d["attn_checksums"], 2e-5)
+    assert_checksums(side["queue"], d["queue_after_checksums"], 1e-6)
+    assert int(side["queue_ptr"]) == int(d["queue_ptr_after"][0])
+    # adj: same forward; only the unfrozen parameters receive gradients
+    a = load_golden("adj_base_queue")
+    assert float(a["loss"]) == pytest.approx(float(d["loss"]), rel=1e-6)
+    frozen = set(jl(a["frozen"]))
+    for k in frozen:
+        sd[k].requires_grad_(False)
+    loss2 = mo.con_step(sd, x, clip, cfg)[0]
+    loss2.backward()
+    names = jl(a["grad_names"])
+    assert not (set(names) & frozen) and all(k.startswith("backbone.") and "norm_layer" not in k for k in frozen)
+    for n, gn in zip(names, a["grad_norms"]):
+        assert sd[n].grad is not None, n
+        assert sd[n].grad.double().norm().item() == pytest.approx(gn, rel=3e-3, abs=1e-6), n
+    assert all(sd[k].grad is None for k in frozen)
+
+
+@pytest.mark.slow
+def test_rec_swin_base_matches_reference():
+    """Swin-Base (2-2-18-2, 128..1024) instantiated from the reference's classes: forward through the oracle."""
+    d = load_golden("rec_swin_base")
+    cfg = jl(d["cfg"])
+    sd = swin_state_dict(d)
+    x, y, noise = rec_inputs("swinb", cfg)
+    assert np.array_equal(noise.numpy(), d["noise"])
+    with torch.no_grad():
+        loss, outs, lh, pred, mask, restore, attn = mo.swin_rec_step(sd, x, y, noise, cfg)
+    assert np.array_equal(mask.numpy(), d["mask"]) and np.array_equal(restore.numpy(), d["ids_restore"])
+    assert abs(loss.item() - float(d["loss"])) <= 2e-6 * abs(float(d["loss"]))
+    assert list(attn.shape) == list(d["attn_shape"])
+    for t, k in ((outs[0][0], "emb_l1"), (outs[1][0], "emb_l2"), (outs[2][0], "emb_l3"), (outs[3][0], "emb_l4"), (lh, "emb_lh"),
+                 (pred, "pred"), (attn, "attn")):
+        assert_checksums(t, d[k + "_checksums"], 2e-5, k)
+
+
+def test_autocast_fixture_is_bf16_class():
+    """The reference's own bf16-autocast losses sit within 1e-2 of its fp32 losses: the scale the HIP bf16 mode is reported on."""
+    a = load_golden("rec_autocast_bf16")
+    for tag in ("tiny", "small", "base"):
+        f = float(load_golden(f"rec_{tag}")["loss"])
+        assert abs(float(a[f"{tag}_loss"]) - f) / f <= 1e-2, tag

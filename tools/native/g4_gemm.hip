@@ -1,0 +1,337 @@
+// Development harness (not part of the product): the "G4" large-tile bf16 GEMM body, C[M][N] = A[M][K] . B[N][K]^T.
+//
+//   * one workgroup of 4 waves per CU, ONE wave per SIMD with the whole 512-register budget;
+//   * a wave owns 128 x (32*NJ) of a 256 x (64*NJ) tile as v_mfma_f32_32x32x16_bf16 accumulators (one wave per SIMD
+//     only issues the 32x32x16 shape at full rate);
+//   * K tiles of 64 in a 2-stage LDS ring filled by LDS-DMA (buffer_load ... lds), ONE barrier per K tile, placed in
+//     front of the last K step's MFMAs so that barrier skew and the next tile's first fragment reads hide under them;
+//   * fragment reads (inline asm, counted lgkmcnt) for K step s+1 are issued in front of the MFMAs of step s.
+// Why: the 128x128 body with two workgroups per CU is bound by the CU's global->LDS fill rate (~60-65 GB/s: 64 KB per
+// K tile per CU); a 256x320 tile moves 72 KB for 5x the FLOPs.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o g4_gemm g4_gemm.hip && ./g4_gemm
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef uint16_t bf16_t;
+
+struct G4Params {
+  int M, N, K;
+  const bf16_t *A; int lda;
+  const bf16_t *B; int ldb;
+  void *C; int ldc;
+  int tiles_m, tiles_n;
+};
+
+template <int OFF> __device__ __forceinline__ u32x4 lds_read128i(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ void tie(u32x4 &x) { asm volatile("" : "+v"(x)); }
+
+template <int N> __device__ __forceinline__ void wait_lgkm() {
+  static_assert(N >= 0 && N <= 15, "lgkmcnt range");
+  if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ int xcd_renumber(int nblk, int bid) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+template <int NJ, bool F32OUT, int MODE>
+__device__ __forceinline__ void g4_body(const G4Params &p) {
+  constexpr int BM = 256, BN = 64 * NJ, BK = 64;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int PA = A_BYTES / 1024 / 4, PB = B_BYTES / 1024 / 4;   // LDS-DMA pieces per wave and K tile
+  constexpr int NP = PA + PB;
+  constexpr int R = 4 + NJ;                                          // fragment reads per K step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // tile map: XCD-contiguous runs, N fastest inside a run (the tiles an XCD runs together share A panels)
+  const int t_lin = xcd_renumber(gridDim.x, blockIdx.x);
+  const int tile_m = t_lin / p.tiles_n, tile_n = t_lin % p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.A), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.B), 0, 0x7FFFFFFF, 0x00020000);
+
+  // LDS-DMA source offsets (bytes) of this wave's pieces at K tile 0. Piece = 8 rows x 128 B, written lane-linearly;
+  // the image's swizzle (16-byte chunk ^ ((row >> 1) & 7)) is applied to the SOURCE chunk.
+  int voffA[PA], voffB[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = (wave * PA + i) * 8 + (lane >> 3), pos = lane & 7;
+    const int gr = m0 + row;
+    voffA[i] = gr < p.M ? (gr * p.lda + ((pos ^ ((row >> 1) & 7)) << 3)) * 2 : (int)0x80000000;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int row = (wave * PB + i) * 8 + (lane >> 3), pos = lane & 7;
+    const int gr = n0 + row;
+    voffB[i] = gr < p.N ? (gr * p.ldb + ((pos ^ ((row >> 1) & 7)) << 3)) * 2 : (int)0x80000000;
+  }
+  auto dma_piece = [&](int idx, int t, char *stage) {      // idx in [0, NP): compile-time after unrolling
+    if (idx < PA) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void *)(stage + (wave * PA + idx) * 1024), 16, voffA[idx < PA ? idx : 0], t * (BK * 2), 0, 0);
+    } else {
+      const int j = idx - PA;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void *)(stage + A_BYTES + (wave * PB + j) * 1024), 16, voffB[j < PB && j >= 0 ? j : 0], t * (BK * 2), 0, 0);
+    }
+  };
+
+  // fragment read addresses: row = rb + (lane & 31), chunk = 2 ks + (lane >> 5); (row >> 1) & 7 depends on the lane only
+  const int rowl = lane & 31, hsel = lane >> 5, sw = (rowl >> 1) & 7;
+  unsigned lane_ks[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) lane_ks[ks] = (unsigned)(rowl * 128 + (((2 * ks + hsel) ^ sw) << 4));
+  const unsigned smem_base = (unsigned)(uintptr_t)(lds_void *)smem;
+  const unsigned a_wave = smem_base + (unsigned)(wm * 128 * 128);
+  const unsigned b_wave = smem_base + (unsigned)(A_BYTES + wn * 32 * NJ * 128);
+
+  f32x16 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 fa0[4], fb0[NJ], fa1[4], fb1[NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa1[i] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) fb1[j] = u32x4{0u, 0u, 0u, 0u};
+
+  auto read_frags = [&](u32x4 (&fa)[4], u32x4 (&fb)[NJ], unsigned stage_off, int ks) {
+    if constexpr (MODE == 3) return;
+    const unsigned aa = a_wave + stage_off + lane_ks[ks], ba = b_wave + stage_off + lane_ks[ks];
+    fa[0] = lds_read128i<0 * 4096>(aa);
+    fa[1] = lds_read128i<1 * 4096>(aa);
+    fa[2] = lds_read128i<2 * 4096>(aa);
+    fa[3] = lds_read128i<3 * 4096>(aa);
+    fb[0] = lds_read128i<0>(ba);
+    if constexpr (NJ > 1) fb[1] = lds_read128i<1 * 4096>(ba);
+    if constexpr (NJ > 2) fb[2] = lds_read128i<2 * 4096>(ba);
+    if constexpr (NJ > 3) fb[3] = lds_read128i<3 * 4096>(ba);
+    if constexpr (NJ > 4) fb[4] = lds_read128i<4 * 4096>(ba);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto tie_frags = [&](u32x4 (&fa)[4], u32x4 (&fb)[NJ]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tie(fa[i]);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) tie(fb[j]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // the 4 x NJ MFMAs of one K step; DMA pieces [d0, d1) of K tile `tn` are issued one per MFMA from the start
+  auto mfma_block = [&](u32x4 (&fa)[4], u32x4 (&fb)[NJ], bool dma, int d0, int d1, int tn, char *nstage) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (MODE != 2)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[j]), __builtin_bit_cast(bf16x8, fa[i]), acc[i][j], 0, 0, 0);
+        const int q = j * 4 + i;
+        if (d0 + q < d1 && dma && MODE != 1) {
+          dma_piece(d0 + q, tn, nstage);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  const int nk = p.K / BK;
+  // prologue: K tile 0 into stage 0
+#pragma unroll
+  for (int i = 0; i < NP; ++i) dma_piece(i, 0, smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  constexpr int Q = 4 * NJ;                    // MFMAs per K step
+  auto iteration = [&](auto more_c, int t) {
+    constexpr bool more = decltype(more_c)::value;
+    const unsigned soff = (unsigned)((t & 1) * STAGE);
+    char *nstage = smem + ((t + 1) & 1) * STAGE;
+    read_frags(fa0, fb0, soff, 0);
+    // last K step of the previous tile (zeros in the first iteration): runs while the reads above are in flight
+    mfma_block(fa1, fb1, false, 0, 0, 0, nstage);
+    read_frags(fa1, fb1, soff, 1);
+    wait_lgkm<R>();
+    tie_frags(fa0, fb0);
+    mfma_block(fa0, fb0, more, 0, NP, t + 1, nstage);
+    read_frags(fa0, fb0, soff, 2);
+    wait_lgkm<R>();
+    tie_frags(fa1, fb1);
+    mfma_block(fa1, fb1, more, Q, NP, t + 1, nstage);
+    read_frags(fa1, fb1, soff, 3);
+    wait_lgkm<R>();
+    tie_frags(fa0, fb0);
+    mfma_block(fa0, fb0, more, 2 * Q, NP, t + 1, nstage);
+    wait_lgkm<0>();
+    tie_frags(fa1, fb1);
+    if constexpr (more) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  };
+  for (int t = 0; t + 1 < nk; ++t) iteration(std::true_type{}, t);
+  iteration(std::false_type{}, nk - 1);
+  mfma_block(fa1, fb1, false, 0, 0, 0, smem);
+
+  // harness epilogue: straight from the accumulators (lane: m = .. + (lane & 31); reg r: n = .. + 8 (r >> 2) + 4 (lane >> 5) + (r & 3))
+  const int mrow = m0 + wm * 128 + (lane & 31);
+  const int ncol = n0 + wn * 32 * NJ + 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mrow + 32 * i;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = ncol + 32 * j + 8 * g;
+        if (n + 3 >= p.N) continue;                  // harness: N % 4 == 0
+        const float v0 = acc[i][j][4 * g], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
+        if constexpr (F32OUT) {
+          *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.C) + (int64_t)m * p.ldc + n) = make_float4(v0, v1, v2, v3);
+        } else {
+          typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+          bf16x4 o = {(__bf16)v0, (__bf16)v1, (__bf16)v2, (__bf16)v3};
+          *reinterpret_cast<bf16x4 *>(reinterpret_cast<bf16_t *>(p.C) + (int64_t)m * p.ldc + n) = o;
+        }
+      }
+  }
+}
+
+template <int NJ, bool F32OUT, int MODE>
+__global__ __launch_bounds__(256) void g4_kernel(const G4Params p) {
+  g4_body<NJ, F32OUT, MODE>(p);
+}
+
+// ------------------------------------------------------------------------------------------------------------ host
+static inline bf16_t f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7FFF + ((u >> 16) & 1);
+  return (bf16_t)(u >> 16);
+}
+static inline float bf2f(bf16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+template <int NJ, int MODE> static float run(const G4Params &p, int reps, hipEvent_t e0, hipEvent_t e1) {
+  constexpr int smem = 2 * (256 + 64 * NJ) * 128;
+  void (*k)(const G4Params) = g4_kernel<NJ, false, MODE>;
+  hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  G4Params q = p;
+  q.tiles_m = (p.M + 255) / 256;
+  q.tiles_n = (p.N + 64 * NJ - 1) / (64 * NJ);
+  const dim3 grid(q.tiles_m * q.tiles_n);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(256), smem, 0, q);
+  hipEventRecord(e0);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, grid, dim3(256), smem, 0, q);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { printf("launch error: %s\n", hipGetErrorString(e)); exit(2); }
+  return ms / reps * 1e3f;   // us
+}
+
+static float run_nj(int nj, int mode, const G4Params &p, int reps, hipEvent_t e0, hipEvent_t e1) {
+  if (mode == 1) return nj == 4 ? run<4, 1>(p, reps, e0, e1) : run<2, 1>(p, reps, e0, e1);
+  if (mode == 2) return nj == 4 ? run<4, 2>(p, reps, e0, e1) : run<2, 2>(p, reps, e0, e1);
+  if (mode == 3) return nj == 4 ? run<4, 3>(p, reps, e0, e1) : run<2, 3>(p, reps, e0, e1);
+  switch (nj) {
+    case 1: return run<1, 0>(p, reps, e0, e1);
+    case 2: return run<2, 0>(p, reps, e0, e1);
+    case 3: return run<3, 0>(p, reps, e0, e1);
+    case 4: return run<4, 0>(p, reps, e0, e1);
+    default: return run<5, 0>(p, reps, e0, e1);
+  }
+}
+
+int main(int argc, char **argv) {
+  struct Shape { const char *name; int M, N, K; };
+  std::vector<Shape> shapes = {
+      {"check", 520, 648, 256},       {"enc.qkv", 6272, 2304, 768},  {"enc.proj", 6272, 768, 768},  {"enc.fc1", 6272, 3072, 768},
+      {"enc.fc2", 6272, 768, 3072},   {"enc.dqkv", 6272, 768, 2304}, {"dec.qkv", 12544, 1536, 512}, {"dec.proj", 12544, 512, 512},
+      {"dec.fc1", 12544, 2048, 512},  {"dec.fc2", 12544, 512, 2048}, {"sq4096", 4096, 4096, 4096},  {"sq8192", 8192, 8192, 8192},
+  };
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  srand(1);
+  int bad_total = 0;
+  for (const Shape &s : shapes) {
+    const size_t na = (size_t)s.M * s.K, nb = (size_t)s.N * s.K, nc = (size_t)s.M * s.N;
+    std::vector<bf16_t> ha(na), hb(nb), hc(nc);
+    for (auto &v : ha) v = f2bf((float)(rand() & 0xFFFFFF) / 8388608.f - 1.f);
+    for (auto &v : hb) v = f2bf((float)(rand() & 0xFFFFFF) / 8388608.f - 1.f);
+    bf16_t *da, *db, *dc;
+    hipMalloc(&da, na * 2); hipMalloc(&db, nb * 2); hipMalloc(&dc, nc * 2);
+    hipMemcpy(da, ha.data(), na * 2, hipMemcpyHostToDevice);
+    hipMemcpy(db, hb.data(), nb * 2, hipMemcpyHostToDevice);
+    G4Params p{s.M, s.N, s.K, da, s.K, db, s.K, dc, s.N, 0, 0};
+    printf("%-9s %5dx%5dx%5d ", s.name, s.M, s.N, s.K);
+    for (int nj = 1; nj <= 4; ++nj) {
+      hipMemset(dc, 0xFF, nc * 2);
+      const int reps = (double)s.M * s.N * s.K > 1e11 ? 5 : 20;
+      const float us = run_nj(nj, 0, p, reps, e0, e1);
+      hipMemcpy(hc.data(), dc, nc * 2, hipMemcpyDeviceToHost);
+      // check: every element for the small case, 4000 random ones otherwise
+      int bad = 0;
+      const size_t nchk = nc <= 400000 ? nc : 4000;
+      for (size_t c = 0; c < nchk; ++c) {
+        const size_t e = nc <= 400000 ? c : ((size_t)rand() * 2654435761u + c * 7919) % nc;
+        const int m = (int)(e / s.N), n = (int)(e % s.N);
+        double ref = 0;
+        for (int k = 0; k < s.K; ++k) ref += (double)bf2f(ha[(size_t)m * s.K + k]) * bf2f(hb[(size_t)n * s.K + k]);
+        const double got = bf2f(hc[e]);
+        if (!(fabs(got - ref) <= 0.01 * fabs(ref) + 0.02 * sqrt((double)s.K) * 0.35)) {
+          if (bad < 3) printf("\n  MISMATCH nj=%d m=%d n=%d got %g ref %g", nj, m, n, got, ref);
+          ++bad;
+        }
+      }
+      bad_total += bad;
+      const int tiles = ((s.M + 255) / 256) * ((s.N + 64 * nj - 1) / (64 * nj));
+      printf(" | nj%d %4dt %7.1fus %6.0fTF%s", nj, tiles, us, 2.0 * s.M * s.N * s.K / us * 1e-6, bad ? " BAD" : "");
+    }
+    if (s.M >= 4096) {
+      printf("\n          ablation (us):");
+      for (int nj : {2, 4})
+        for (int mode : {1, 2, 3}) printf("  nj%d %s %7.1f", nj, mode == 1 ? "noDMA" : mode == 2 ? "noMFMA" : "noREAD", run_nj(nj, mode, p, 10, e0, e1));
+    }
+    printf("\n");
+    fflush(stdout);
+    hipFree(da); hipFree(db); hipFree(dc);
+  }
+  printf(bad_total ? "FAILED: %d mismatches\n" : "checks OK\n", bad_total);
+  return bad_total ? 1 : 0;
+}
