@@ -47,17 +47,37 @@ def step_flops_per_sample(cfg):
     return 3 * fwd
 
 
+CONFIGS = {
+    # name: (workload label, backbone_type, model_size, pr_phase, hub factory, supp kind, noise cells, graphable)
+    "vit_base_rec": ("ViT-Base masked modeling (diff-map decoder)", "vit", "base", "rec", "pretrain_hub_model_base_patch16", "frame", 196, True),
+    "vit_base_con": ("ViT-Base contrastive stage (MoCo-v3 heads, CLIP tokens as input, queue 1024)", "vit", "base", "con",
+                     "pretrain_hub_model_base_patch16", "clip", 0, True),
+    "vit_base_adj": ("ViT-Base Trans stage (backbone frozen except norm_layer, MoCo-v3 heads, queue 1024)", "vit", "base", "adj",
+                     "pretrain_hub_model_base_patch16", "clip", 0, True),
+    "convvit_base_rec": ("ConvViT-Base masked modeling", "convvit", "base", "rec", "pretrain_hub_model_base_patch16", "frame", 196, True),
+    "swin_tiny_rec": ("Swin-T masked modeling (window 7)", "swin", "tiny", "rec", "pretrain_hub_model_swin_tiny_patch16", "frame", 49, False),
+    "swin_base_rec": ("Swin-Base masked modeling (window 7)", "swin", "base", "rec", "pretrain_hub_model_swin_base_patch16", "frame", 49, False),
+}
+
+
 def build(args, device):
     from eventpretrain_amd import ops
     from eventpretrain_amd.model.pretrain import pr_hub_model as hub
     from eventpretrain_amd.optim import FusedAdamW
     from eventpretrain_amd.testing import make_args
     from eventpretrain_amd.utils import lr_decay as lrd
-    a = make_args(model_size=args.model, pr_phase="rec", device="cuda", batch_size=args.batch)
+    label, bb, size, phase, fac_name, supp, cells, graphable = CONFIGS[args.config]
+    if args.config == "vit_base_rec" and args.model != "base":
+        size = args.model
+        fac_name = {"small": "pretrain_hub_model_small_patch16", "tiny": "pretrain_hub_model_tiny_patch16_64"}[args.model]
+    a = make_args(model_size=size, pr_phase=phase, backbone_type=bb, device="cuda", batch_size=args.batch,
+                  use_queue=True, mask_ratio=0.5 if phase == "rec" else 0.0)
     torch.manual_seed(1234)       # identical initial weights on every rank (DDP broadcasts them in the reference)
-    fac = {"base": hub.pretrain_hub_model_base_patch16, "small": hub.pretrain_hub_model_small_patch16,
-           "tiny": hub.pretrain_hub_model_tiny_patch16_64}[args.model]
-    model = fac(a, emb_frames_dim=512, queue_length=1024, T=0.07).to(device).train()
+    model = getattr(hub, fac_name)(a, emb_frames_dim=512, queue_length=1024, T=0.07).to(device).train()
+    if phase == "adj":            # main_pretrain.py:281-284
+        for k, v in model.backbone.named_parameters():
+            if "norm_layer" not in k:
+                v.requires_grad = False
     world = dist.get_world_size() if dist.is_initialized() else 1
     a.lr = a.blr * args.batch * world / 256
     groups = lrd.param_groups_lrd(a, model, a.weight_decay, layer_decay=1)
@@ -87,7 +107,10 @@ def make_batch(args, device, rank):
     off = torch.arange(0, (B + 1) * n_ev, n_ev, dtype=torch.int64, device=device)
     vox = voxel_grid_batch(ev, off, 5, (S, S))
     g = torch.Generator(device="cpu").manual_seed(1 + rank)
-    tgt = torch.randn(B, 1, S, S, generator=g).to(device)
+    if CONFIGS[args.config][5] == "clip":
+        tgt = torch.randn(B, 197, 512, generator=g).to(device)      # frozen-CLIP image tokens: an input tensor
+    else:
+        tgt = torch.randn(B, 1, S, S, generator=g).to(device)
     return ev, off, vox, tgt, S, n_ev
 
 
@@ -161,13 +184,12 @@ class GemmTimer:
         return out
 
 
-def cpu_baseline(cfgs, n_threads):
-    """Oracle (torch-CPU fp32 restatement + its own AdamW) on a bounded sample: ViT-Base, B=4, one optimiser step."""
+def cpu_baseline(cfgs, n_threads, Bc=16, n_steps=6):
+    """Oracle (torch-CPU fp32 restatement + its own AdamW) on a bounded sample: ViT-Base, Bc samples x n_steps optimiser steps."""
     from oracle import model_oracle as mo
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import rec_state_dict
     torch.set_num_threads(n_threads)
-    Bc, n_steps = 16, 6
     cfg = dict(input=224, patch=16, dim=768, depth=12, heads=12, dec_dim=512, dec_depth=8, dec_heads=16, mask_ratio=0.5, B=Bc)
     sd = rec_state_dict(cfg)
     train = [k for k in sd if "pos_embed" not in k]
@@ -197,14 +219,16 @@ def pmc_traffic(kernel_key):
     """HBM-side bytes per launch of a kernel from the committed PMC summary (profiles/r01_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the guide's gfx950 correction), or None. bench.py cannot collect
     PMC counters itself; the figure is from the same command profiled offline."""
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
-            k = json.load(f)["kernels"]
-        for name, v in k.items():
-            if name in kernel_key:
-                return float(v["traffic_bytes"])
-    except Exception:
-        pass
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(here, fn)) as f:
+                k = json.load(f)["kernels"]
+            for name, v in k.items():
+                if name in kernel_key:
+                    return float(v["traffic_bytes"])
+        except Exception:
+            pass
     return None
 
 
@@ -227,8 +251,10 @@ def cpu_voxel_baseline():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (SURVEY.md 8d: 20 warm-up + 100 timed when not overridden)")
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="vit_base_rec", choices=sorted(CONFIGS),
+                    help="vit_base_rec = the headline workload (BASELINE.json configs[1]); the others are configs[2-4] on one GPU")
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--model", default="base", choices=["base", "small", "tiny"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
@@ -266,6 +292,7 @@ def main():
         reducer = BucketedGradReducer([p for p in model.parameters() if p.requires_grad], bucket_mb=args.bucket_mb)
     gen = torch.Generator(device=device).manual_seed(100 + rank)     # seed + rank, as main_pretrain.py:174
     L = model.backbone.num_patches
+    label, _bb, _size, phase, _fac, _supp, cells, graphable = CONFIGS[args.config]
 
     def barrier():
         if multi:
@@ -278,10 +305,13 @@ def main():
     # replay. With N > 1 the collectives stay outside the graphs: [forward+backward graph] -> in-place RCCL all-reduce of
     # the flat gradient buffers -> [AdamW graph].
     from eventpretrain_amd.engine import GraphedStep
-    use_graph = not args.no_graph
+    use_graph = (not args.no_graph) and graphable       # the Swin step plans its windows on the host per step: eager
     n_warm_eager = min(args.warmup, 3) if use_graph else 0
-    executor = GraphedStep(model, opt, lambda m, x, y, noise: m(x, y, is_rec=True, noise=noise), [vox, tgt],
-                           noise_shape=(args.batch, L), generator=gen, reducer=reducer, use_graph=use_graph,
+    if phase == "rec":
+        fwd, noise_shape = (lambda m, x, y, noise: m(x, y, is_rec=True, noise=noise)), (args.batch, cells)
+    else:
+        fwd, noise_shape = (lambda m, x, y, noise: m(x, y)), None
+    executor = GraphedStep(model, opt, fwd, [vox, tgt], noise_shape=noise_shape, generator=gen, reducer=reducer, use_graph=use_graph,
                            warmup=max(n_warm_eager, 2), wgrad_chunks=args.wgrad_chunks)
     graph_note = executor.note
     step, eager_step = executor.step, executor.eager_step
@@ -304,20 +334,52 @@ def main():
     ms = elapsed / args.steps * 1e3
     value = args.batch * world * args.steps / elapsed
     dims = dict(base=(768, 12, 512, 8), small=(384, 12, 256, 8), tiny=(192, 12, 128, 4))[args.model]
-    fcfg = dict(L=L, keep=int(L * 0.5), dim=dims[0], depth=dims[1], dec_dim=dims[2], dec_depth=dims[3], patch_k=5 * 256, pred=256)
-    fl_sample = step_flops_per_sample(fcfg)
+    fcfg = dict(L=196 if S == 224 else 16, keep=98 if S == 224 else 8, dim=dims[0], depth=dims[1], dec_dim=dims[2], dec_depth=dims[3],
+                patch_k=5 * 256, pred=256)
+    headline = args.config == "vit_base_rec"
+    fl_sample = step_flops_per_sample(fcfg) if headline else None
+    workload = label if not headline else "ViT-%s masked modeling (diff-map decoder)" % args.model.capitalize()
     result = {
         "metric": "pretrain samples/sec (masked-ViT step, B=64 224^2)", "value": value, "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "ViT-%s masked modeling (diff-map decoder), %dx%d 5-bin voxels, batch=%d per GPU, AdamW step included"
-                               % (args.model.capitalize(), S, S, args.batch),
-                   "global_batch": args.batch * world, "parallelism": "dp%d" % world, "mask_ratio": 0.5,
+        "config": {"workload": "%s, %dx%d 5-bin voxels, batch=%d per GPU, AdamW step included" % (workload, S, S, args.batch),
+                   "name": args.config, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                   "mask_ratio": 0.5 if phase == "rec" else 0.0,
                    "params_M": sum(p.numel() for p in model.parameters()) / 1e6},
         "final_loss": final_loss, "launch_mode": graph_note,
-        "step_tflops_per_gpu": fl_sample * args.batch / (ms * 1e-3) / 1e12,
-        "step_mfma_frac": fl_sample * args.batch / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
     }
+    if headline:
+        result["step_tflops_per_gpu"] = fl_sample * args.batch / (ms * 1e-3) / 1e12
+        result["step_mfma_frac"] = result["step_tflops_per_gpu"] / MFMA_BF16_PEAK_TFLOPS
+
+    # ---- median of per-step times (HIP events around single steps, after the timed region; SURVEY.md 8d asks for the
+    # median; `value` above stays the mean over exactly K steps as the driver's contract says)
+    n_med = min(args.steps, 50)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_med + 1)]
+    barrier()
+    evs[0].record()
+    for i in range(n_med):
+        step()
+        evs[i + 1].record()
+    barrier()
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_med))
+    result["ms_per_step_median"] = per[n_med // 2]
+    result["ms_per_step_min"] = per[0]
+
+    if multi and getattr(executor, "plan", None) is not None:
+        # per-rank tail of the data-parallel step: from "last weight-gradient chunk computed" to "every all-reduce and update
+        # part done" on the step's stream -- what is NOT hidden behind compute (diagnoses the 1 -> 8 scaling from one run)
+        executor.plan.timing = []
+        for _ in range(10):
+            step()
+        barrier()
+        tail = [a_.elapsed_time(b_) for a_, b_ in executor.plan.timing]
+        executor.plan.timing = None
+        t_ = torch.tensor([sum(tail) / max(len(tail), 1)], dtype=torch.float64, device=device)
+        gathered = [torch.zeros_like(t_) for _ in range(world)]
+        dist.all_gather(gathered, t_)
+        result["dp_tail_ms_per_rank"] = [round(float(g_.item()), 4) for g_ in gathered]
 
     if rank == 0 and not args.no_kernel_timing:
         # ---- dominant kernel, HIP events around every GEMM launch of real steps (instrumented, after the timed region)
@@ -357,6 +419,18 @@ def main():
                 g_["tiles"] = g_.get("tiles", 0) + ((n_out + T_ - 1) // T_) * ((k_in + T_ - 1) // T_)
             return orig_flush()
 
+        attn_flops = [0.0]
+        orig_af, orig_ab = _ops.attention_fused_fwd, _ops.attention_fused_bwd
+
+        def af(qkv, B_, N_, heads_, dh_, **kw):
+            attn_flops[0] += 4.0 * B_ * heads_ * N_ * N_ * dh_
+            return orig_af(qkv, B_, N_, heads_, dh_, **kw)
+
+        def ab(qkv, out_, dout_, lse_, B_, N_, heads_, dh_):
+            attn_flops[0] += 8.0 * B_ * heads_ * N_ * N_ * dh_       # backward = 2x forward (SURVEY.md 8d convention)
+            return orig_ab(qkv, out_, dout_, lse_, B_, N_, heads_, dh_)
+
+        _ops.attention_fused_fwd, _ops.attention_fused_bwd = af, ab
         _ops.call, _ops._deferred.flush = timed_call, counting_flush
         timer.install()
         saved_reducer, executor.reducer = executor.reducer, None      # rank-0-only pass: no collective may run in it
@@ -364,6 +438,7 @@ def main():
         executor.reducer = saved_reducer
         timer.remove()
         _ops.call, _ops._deferred.flush = orig_call, orig_flush
+        _ops.attention_fused_fwd, _ops.attention_fused_bwd = orig_af, orig_ab
         ks = timer.summary()
         timer.calls = []
         torch.cuda.synchronize()
@@ -376,14 +451,35 @@ def main():
                            flops_per_step=g_["flops"]))
         ks.sort(key=lambda d: -d["ms_per_step"])
         if ks:
-            top = ks[0]
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
-            result["roofline"] = {"bound": "mfma", "achieved": top["tflops"], "peak": peak, "unit": "TFLOP/s",
-                                  "frac": top["tflops"] / peak, "traffic": pmc_traffic(top["kernel"]), "kernel": top["kernel"],
-                                  "avg_launch_us": top["avg_us"], "launches_per_step": top["launches_per_step"],
-                                  "ms_per_step_in_kernel": top["ms_per_step"],
-                                  "note": "achieved = algorithmic 2MNK FLOPs of this kernel's launches in one step / their "
-                                          "HIP-event durations (each distinct call re-launched 10x between two events)"}
+            # dominant kernel = the FAMILY with the most time: the 128x128-tile forward / data-gradient GEMM, whose
+            # instantiations (layout x epilogue x output type) rocprofv3 lists under separate names
+            fam = [d for d in ks if d["kernel"].startswith("gemm_kernel<") and "128x128" in d["kernel"]]
+            grp = [d for d in ks if "grouped" in d["kernel"]]
+
+            def fam_entry(ds, name, note):
+                fl_, sec_, n_ = sum(d["flops_per_step"] for d in ds), sum(d["ms_per_step"] for d in ds) * 1e-3, sum(d["launches_per_step"] for d in ds)
+                return {"bound": "mfma", "achieved": fl_ / sec_ / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl_ / sec_ / 1e12 / peak,
+                        "traffic": pmc_traffic(name), "kernel": name, "avg_launch_us": sec_ / n_ * 1e6, "launches_per_step": n_,
+                        "ms_per_step_in_kernel": sec_ * 1e3, "note": note}
+            note = ("achieved = algorithmic 2MNK FLOPs of these launches in one step / their HIP-event durations (each distinct "
+                    "call re-launched 10x between two events on the launch stream)")
+            entries = []
+            if fam:
+                entries.append(fam_entry(fam, "gemm_kernel<...,tile=128x128> (forward + data-gradient GEMM family, %d instantiations)" % len(fam), note))
+            if grp:
+                entries.append(fam_entry(grp[:1], grp[0]["kernel"], note))
+            entries.sort(key=lambda e_: -e_["ms_per_step_in_kernel"])
+            if not entries:
+                entries.append(fam_entry(ks[:1], ks[0]["kernel"], note))
+            result["roofline"] = entries[0]
+            if len(entries) > 1:
+                result["roofline_second"] = entries[1]
+            launched = sum(d["flops_per_step"] for d in ks) + attn_flops[0]
+            result["step_tflops_launched"] = launched / (ms * 1e-3) / 1e12
+            result["step_mfma_frac_launched"] = result["step_tflops_launched"] / peak
+            if not headline:
+                result["step_tflops_per_gpu"], result["step_mfma_frac"] = result["step_tflops_launched"], result["step_mfma_frac_launched"]
             result["gemm_kernels"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items() if k != "flops_per_step"} for d in ks]
         # ---- K1 voxel scatter (HBM-bound)
         from eventpretrain_amd.dataset.dataset_utils.events_to_voxel_grid import voxel_grid_batch
@@ -411,10 +507,11 @@ def main():
     if multi:
         dist.barrier()
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n_thr = min(os.cpu_count() or 1, 16)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and headline and args.model == "base":
+        n_thr = os.cpu_count() or 1
         try:
-            result["cpu_baseline"] = cpu_baseline(fcfg, n_thr)
+            result["cpu_baseline"] = cpu_baseline(fcfg, n_thr, 16, 6)          # all host cores
+            result["cpu_baseline_1thread"] = cpu_baseline(fcfg, 1, 2, 3)         # the reference's shipped torch.set_num_threads(1)
             result["cpu_baseline_voxel"] = cpu_voxel_baseline()
         except Exception as e:  # the baseline is a reported figure; never lose the GPU line over it
             result["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": n_thr, "kind": "port", "sample": "failed: %r" % (e,)}

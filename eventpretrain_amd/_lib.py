@@ -47,6 +47,7 @@ SIGNATURES = {
     "evp_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp, _i, _vp, _vp, _vp],
     "evp_layernorm_bwd_nblk": [_i64],
     "evp_layernorm_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "evp_layernorm_bwd_cs": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp],
     "evp_colsum_nblk": [_i64],
     "evp_colsum_grouped": [_vp, _vp, _i, _vp],
     "evp_colsum": [_vp, _i, _i64, _i, _i64, _vp, _vp, _vp],

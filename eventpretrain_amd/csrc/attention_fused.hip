@@ -317,8 +317,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *qkv, const 
     }
   }
 
-  // ---- pass 2, key on the lane: dK, dV ----
-  for (int strip = wave; strip * 16 < N; strip += 4) {
+  // ---- pass 2, key on the lane: dK, dV ---- (strips dealt to the waves in the opposite order of pass 1: with 13 strips
+  // the wave that took four in pass 1 takes three here)
+  for (int strip = 3 - wave; strip * 16 < N; strip += 4) {
     bf16x8 kf[KS], vf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {

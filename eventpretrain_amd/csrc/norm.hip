@@ -117,18 +117,23 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const float *x, cons
 }
 
 // ------------------------------------------------------------------------------------------------ LN backward
-// partial layout: part[blk][0][D] = dgamma partial, part[blk][1][D] = dbeta partial
-template <int VPL>
+// partial layout: part[blk][0][D] = dgamma partial, part[blk][1][D] = dbeta partial and, with CS, part[blk][2][D] = column sums
+// of the OUTPUT dx (= the residual-stream gradient: its column sum is the bias gradient of the Linear that fed the stream,
+// so the grouped column-sum launch reduces these few rows instead of re-reading the whole f32 gradient)
+template <int VPL, bool CS>
 __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void *dy, int dy_dtype, const float *x, const float *x2,
                                                      const float *x3, const float *gamma, const float *mean,
                                                      const float *rstd, const float *gres, int64_t M, int D, float *dx,
                                                      void *dx_lp, float *part) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float *sh = reinterpret_cast<float *>(smem_raw);  // [ROWS_PER_BLOCK][2][D]
+  float *sh = reinterpret_cast<float *>(smem_raw);  // [ROWS_PER_BLOCK][NP][D]
+  constexpr int NP = CS ? 3 : 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float4 dg[VPL], db[VPL];
+  float4 dg[VPL], db[VPL], dc[CS ? VPL : 1];
 #pragma unroll
   for (int i = 0; i < VPL; ++i) dg[i] = db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < (CS ? VPL : 1); ++i) dc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   for (int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; r < M; r += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
     Row<VPL> xr, gr;
@@ -174,6 +179,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void *dy, int 
         }
         if (dx) *reinterpret_cast<float4 *>(dx + r * D + c * 4) = o;
         if (dx_lp) store4_any(dx_lp, EVP_BF16, r * D + c * 4, o);
+        if constexpr (CS) { dc[i].x += o.x; dc[i].y += o.y; dc[i].z += o.z; dc[i].w += o.w; }
       }
     }
   }
@@ -182,16 +188,17 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void *dy, int 
   for (int i = 0; i < VPL; ++i) {
     const int c = lane + 64 * i;
     if (c * 4 < D) {
-      *reinterpret_cast<float4 *>(sh + (wave * 2 + 0) * D + c * 4) = dg[i];
-      *reinterpret_cast<float4 *>(sh + (wave * 2 + 1) * D + c * 4) = db[i];
+      *reinterpret_cast<float4 *>(sh + (wave * NP + 0) * D + c * 4) = dg[i];
+      *reinterpret_cast<float4 *>(sh + (wave * NP + 1) * D + c * 4) = db[i];
+      if constexpr (CS) *reinterpret_cast<float4 *>(sh + (wave * NP + 2) * D + c * 4) = dc[i];
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < 2 * D; e += blockDim.x) {
+  for (int e = threadIdx.x; e < NP * D; e += blockDim.x) {
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < ROWS_PER_BLOCK; ++w) s += sh[w * 2 * D + e];
-    part[(int64_t)blockIdx.x * 2 * D + e] = s;
+    for (int w = 0; w < ROWS_PER_BLOCK; ++w) s += sh[w * NP * D + e];
+    part[(int64_t)blockIdx.x * NP * D + e] = s;
   }
 }
 
@@ -550,14 +557,31 @@ extern "C" int evp_layernorm_bwd(const void *dy, int dy_dtype, const float *x, c
   const int g = ln_grid(M);
   const size_t sh = (size_t)ROWS_PER_BLOCK * 2 * D * sizeof(float);
   DISPATCH_VPL(D, {
-    if (sh > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ln_bwd_kernel<V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(ln_bwd_kernel<V>, dim3(g), dim3(LN_THREADS), sh, s, dy, dy_dtype, x, x2, x3, gamma, mean, rstd, gres, M, D, dx, dx_lp, workspace);
+    if (sh > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ln_bwd_kernel<V, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL((ln_bwd_kernel<V, false>), dim3(g), dim3(LN_THREADS), sh, s, dy, dy_dtype, x, x2, x3, gamma, mean, rstd, gres, M, D, dx, dx_lp, workspace);
   });
   EVP_CHECK_LAUNCH("evp_layernorm_bwd");
   if (dgamma || dbeta) {   // both NULL: the caller reduces the per-block partials workspace[g][2][D] itself (deferred, grouped)
     hipLaunchKernelGGL(ln_bwd_finalize, dim3((2 * D + 63) / 64), dim3(1024), 0, s, workspace, g, D, dgamma, dbeta);
     EVP_CHECK_LAUNCH("evp_layernorm_bwd(finalize)");
   }
+  return EVP_OK;
+}
+
+extern "C" int evp_layernorm_bwd_cs(const void *dy, int dy_dtype, const float *x, const float *x2, const float *x3,
+                                    const float *gamma, const float *mean, const float *rstd, const float *gres, int64_t M, int D,
+                                    float *dx, void *dx_lp, float *workspace, void *stream) {
+  EVP_CHECK_ARG(dy && x && gamma && mean && rstd && workspace, EVP_EINVAL, "evp_layernorm_bwd_cs: null pointer");
+  EVP_CHECK_ARG(dx || dx_lp, EVP_EINVAL, "evp_layernorm_bwd_cs: no output requested");
+  EVP_CHECK_ARG(M > 0 && D > 0 && D % 4 == 0 && D <= 4096, EVP_ESHAPE, "evp_layernorm_bwd_cs: need D%%4==0, D<=4096 (D=%d)", D);
+  hipStream_t s = (hipStream_t)stream;
+  const int g = ln_grid(M);
+  const size_t sh = (size_t)ROWS_PER_BLOCK * 3 * D * sizeof(float);
+  DISPATCH_VPL(D, {
+    if (sh > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ln_bwd_kernel<V, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL((ln_bwd_kernel<V, true>), dim3(g), dim3(LN_THREADS), sh, s, dy, dy_dtype, x, x2, x3, gamma, mean, rstd, gres, M, D, dx, dx_lp, workspace);
+  });
+  EVP_CHECK_LAUNCH("evp_layernorm_bwd_cs");
   return EVP_OK;
 }
 

@@ -8,8 +8,9 @@ Precision modes (set with `set_compute_dtype`):
 Every tensor handed to a kernel is allocated by PyTorch; all arithmetic happens in libevtpretrain.so.
 """
 import ctypes as C
-
 import os
+
+import numpy as np
 
 import torch
 
@@ -155,16 +156,60 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype, x2=None, x3=None):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, gres=None, x2=None, x3=None, want_lp=False, params=None):
+# Side information that travels with a residual-stream gradient from the LayerNorm backward that produced it to the
+# transformer block that consumes it next (autograd hands the tensor over, not these): its bf16 copy (the next GEMM's
+# operand, written by the same kernel) and the per-block column sums of it (the proj / fc2 bias gradient). Keyed by the
+# data pointer and validated by (a) a weak reference to the producing tensor -- a dead producer means the address may have
+# been reused -- and (b) its version counter, which views share: where a tensor has several consumers autograd SUMS the
+# incoming gradients and may do so in place into the first arrival, which keeps the pointer and changes the values. A handful
+# of entries at most.
+_grad_side = {}
+_use_grad_side = os.environ.get("EVP_GRAD_SIDE", "1") != "0"
+
+
+def set_grad_side(flag):
+    """A/B switch: bf16 copy + bias column sums of the residual-stream gradient handed from LayerNorm backward to the next
+    block (default) or a cast kernel and a full column sum per use."""
+    global _use_grad_side
+    _use_grad_side = bool(flag)
+
+
+def _side_put(dx, lp, colsum_part):
+    import weakref
+    for k in [k for k, v in _grad_side.items() if v[0]() is None]:
+        del _grad_side[k]
+    while len(_grad_side) >= 8:
+        _grad_side.pop(next(iter(_grad_side)))
+    _grad_side[dx.data_ptr()] = (weakref.ref(dx), dx.numel(), lp, colsum_part, dx._version)
+
+
+def _side_take(g):
+    ent = _grad_side.pop(g.data_ptr(), None)
+    if ent is None or ent[0]() is None or ent[1] != g.numel() or not g.is_contiguous() or g._version != ent[4]:
+        return None, None
+    return ent[2], ent[3]
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, gres=None, x2=None, x3=None, want_lp=False, params=None, side=False):
     """Returns (dx f32, dx_lp bf16|None, dgamma, dbeta). With `params=(weight, bias)` leaf Parameters that may take
     deferred gradients, the per-block dgamma/dbeta partials are queued for the step's grouped column-sum launch
-    instead of being reduced by a kernel of their own, and (dx, dx_lp, None, None) is returned."""
+    instead of being reduced by a kernel of their own, and (dx, dx_lp, None, None) is returned. `side` (deferred mode
+    only): the kernel also leaves per-block column sums of dx, and (bf16 copy, those partials) are registered for whoever
+    receives dx as its incoming gradient (_side_take)."""
     M, D = x.shape
     dx = torch.empty(M, D, dtype=torch.float32, device=x.device)
     dx_lp = torch.empty(M, D, dtype=torch.bfloat16, device=x.device) if want_lp else None
     nb = call("evp_layernorm_bwd_nblk", M)
-    ws = torch.empty(nb, 2 * D, dtype=torch.float32, device=x.device)
     defer = (params is not None and D % 8 == 0 and _deferred.can_defer(params[0]) and _deferred.can_defer(params[1]))
+    if defer and side and _use_grad_side:
+        ws = torch.empty(nb, 3 * D, dtype=torch.float32, device=x.device)
+        call("evp_layernorm_bwd_cs", ptr(_chk(dy)), dt(dy), ptr(x), ptr(x2), ptr(x3), ptr(gamma), ptr(mean), ptr(rstd),
+             ptr(gres), M, D, ptr(dx), ptr(dx_lp), ptr(ws), stream_ptr())
+        _deferred.colsum(params[0], ws[:, :D])
+        _deferred.colsum(params[1], ws[:, D:2 * D])
+        _side_put(dx, dx_lp, ws[:, 2 * D:])
+        return dx, dx_lp, None, None
+    ws = torch.empty(nb, 2 * D, dtype=torch.float32, device=x.device)
     dgamma = dbeta = None
     if not defer:
         dgamma = torch.empty(D, dtype=torch.float32, device=x.device)
@@ -274,7 +319,11 @@ class _DeferredGrads:
         self._pin = {}
         self._capture_pins = []     # pinned tables owned by captured HIP graphs (never rewritten; see _stage)
         self.flat_buffers = []      # flat f32 buffers holding the gradients written by the last flush(es)
-        self.track_flats = False    # set by the data-parallel reducer: without a consumer the list must not grow
+        self._flat_consumer = None  # weakref to the data-parallel reducer: without a live consumer the list must not grow
+
+    def track_flats(self):
+        c = self._flat_consumer
+        return c is not None and c() is not None
 
     def arm(self):
         if not self.armed:
@@ -341,6 +390,8 @@ class _DeferredGrads:
         self.armed = False
         if self.hold:
             return
+        if self.flat_buffers and not self.track_flats():
+            self.flat_buffers = []          # leftovers of a reducer that is gone
         for st in self._build(n_chunks=1, static=False):
             st.run()
 
@@ -389,7 +440,7 @@ class _DeferredGrads:
             for p_, n_ in zip(fresh, sizes):
                 p_.grad = flat[o:o + p_.numel()].view_as(p_)
                 o += n_
-            if static or self.track_flats:      # only a reducer (or a plan being built) takes these; otherwise the
+            if static or self.track_flats():    # only a reducer (or a plan being built) takes these; otherwise the
                 self.flat_buffers.append(flat)  # parameters' .grad views are the only owners and zero_grad frees them
             return flat, {id(p_) for p_ in fresh}
 
@@ -472,6 +523,7 @@ class _DeferredGrads:
                         rows_.append((dy.data_ptr(), x.data_ptr(), gt.data_ptr(), n_out, k_in, rows, n_out, k_in, k_in, acc, cs_acc, cs_ptr, tm, tn))
                     rows_.sort(key=lambda r_: -r_[5])           # longest K first
                     probs = np.zeros(len(rows_), dtype=pdt)
+                    weights = []
                     for i, r_ in enumerate(rows_):
                         probs[i] = r_[:12]
                         tm, tn = r_[12], r_[13]
@@ -479,8 +531,13 @@ class _DeferredGrads:
                         t[..., 0] = i
                         t[..., 1] = np.arange(tm, dtype=np.int32)[None, :]
                         t[..., 2] = np.arange(tn, dtype=np.int32)[:, None]
+                        if _wgrad_xcd_order and T_ == 256:
+                            t = _supertile_major(t, 2, 4)
                         items.append(t.reshape(-1, 4))
+                        weights.append(np.full(tm * tn, float(r_[5]), dtype=np.float64))
                     items = np.concatenate(items, 0)
+                    if _wgrad_xcd_order and T_ == 256:
+                        items = _deal_to_xcds(items, np.concatenate(weights))
                     pt = table(tag + "p", probs.view(np.uint8), dev)
                     it_ = table(tag + "i", items.view(np.uint8).reshape(-1), dev)
                     steps.append(self._Step(entry, pt, it_, int(items.shape[0]), [flat] if flat is not None else [], [],
@@ -516,6 +573,49 @@ class _DeferredGrads:
         return steps
 
 
+def _supertile_major(t, sm, sn):
+    """[tn, tm, 4] tile grid -> the same tiles listed super-tile by super-tile (sn x sm tiles each, tile_m fastest inside):
+    the 8 tiles of a 2 x 4 super-tile read 2 A panels and 4 B panels between them instead of 16."""
+    tn, tm = t.shape[0], t.shape[1]
+    out = []
+    for n0 in range(0, tn, sn):
+        for m0 in range(0, tm, sm):
+            out.append(t[n0:n0 + sn, m0:m0 + sm].reshape(-1, 4))
+    return np.concatenate(out, 0)
+
+
+def _deal_to_xcds(items, work, n_xcd=8):
+    """Workgroups b and b + 8 run on the same XCD (one L2 each; MI355X_MICROARCH.md, workgroup dispatch) and an XCD's CUs
+    take its workgroups in launch order. Cut the item sequence (super-tile major, longest K first) into 8 CONTIGUOUS runs of
+    equal estimated work (tiles x K) and interleave them, items[8 k + x] = run_x[k], so that the ~32 tiles an XCD runs at any
+    moment are neighbouring super-tiles of one problem -- they advance through K in lockstep and find each other's panels in
+    their L2 instead of re-reading them through the Infinity Cache (2.9x over-fetch measured in round 1). Short runs are
+    padded with prob = -1 items, which the kernels skip. Placement is speed only: any assignment gives the same result."""
+    n = items.shape[0]
+    if n < 4 * n_xcd:
+        return items
+    cum = np.cumsum(work)
+    cuts = [0] + [int(np.searchsorted(cum, cum[-1] * (x + 1) / n_xcd, side="left")) + 1 for x in range(n_xcd - 1)] + [n]
+    cuts = [min(max(c, 0), n) for c in cuts]
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    runs = [items[cuts[x]:cuts[x + 1]] for x in range(n_xcd)]
+    longest = max(r.shape[0] for r in runs)
+    out = np.full((longest, n_xcd, 4), -1, dtype=np.int32)
+    for x, r in enumerate(runs):
+        out[:r.shape[0], x] = r
+    return out.reshape(-1, 4)
+
+
+_wgrad_xcd_order = os.environ.get("EVP_WGRAD_XCD", "1") != "0"
+
+
+def set_wgrad_xcd_order(flag):
+    """A/B switch: XCD-aware order of the grouped 256x256 weight-gradient items (default) or the plain problem-major list."""
+    global _wgrad_xcd_order
+    _wgrad_xcd_order = bool(flag)
+
+
 _deferred = _DeferredGrads()
 _use_wgrad256 = os.environ.get("EVP_WGRAD256", "1") != "0"
 
@@ -545,11 +645,13 @@ def build_deferred_plan(n_chunks=4):
     return _deferred.build_plan(n_chunks)
 
 
-def track_deferred_flat_buffers(flag):
-    """Called by the data-parallel reducer: keep the flat gradient buffers of each flush for take_deferred_flat_buffers().
-    Off by default -- without a consumer the list would pin one set of gradient buffers per step."""
-    _deferred.track_flats = bool(flag)
-    if not flag:
+def track_deferred_flat_buffers(consumer):
+    """Called by the data-parallel reducer with itself: while that object is alive the flat gradient buffers of each flush
+    are kept for take_deferred_flat_buffers(). Without a live consumer nothing is retained (the list would otherwise pin one
+    set of gradient buffers per step). Pass None to switch tracking off."""
+    import weakref
+    _deferred._flat_consumer = weakref.ref(consumer) if consumer is not None else None
+    if consumer is None:
         _deferred.flat_buffers = []
 
 
@@ -573,7 +675,7 @@ def _wgrad(dy, x, n_out, k_in, rows, param=None, shape=None, bias_param=None):
     return dw if shape is None else dw.view(shape)
 
 
-def _wgrad_bias(dy, x, n_out, k_in, rows, wparam, bparam, need_w, need_b, dy_f32=None, shape=None):
+def _wgrad_bias(dy, x, n_out, k_in, rows, wparam, bparam, need_w, need_b, dy_f32=None, shape=None, dy_colsum=None):
     """(dW, db) of one Linear. When both can be deferred (bf16 mode, leaf parameters) the bias gradient is attached to the
     weight-gradient problem: the 256x256 grouped kernel sums dy's columns from the A fragments it holds anyway, so dy is
     not read a second time. Otherwise falls back to the separate paths (`dy_f32`: f32 version of dy for the exact sum)."""
@@ -585,6 +687,9 @@ def _wgrad_bias(dy, x, n_out, k_in, rows, wparam, bparam, need_w, need_b, dy_f32
         _deferred.wgrad(wparam, dy, x, n_out, k_in, rows, bparam)
         return None, None
     dw = _wgrad(dy, x, n_out, k_in, rows, wparam, shape) if need_w else None
+    if need_b and dy_colsum is not None and _deferred.can_defer(bparam):
+        _deferred.colsum(bparam, dy_colsum)       # per-block column sums left by the LayerNorm backward: a few rows to add
+        return dw, None
     db = _bgrad(dy_f32 if dy_f32 is not None else dy, bparam) if need_b else None
     return dw, db
 
@@ -651,21 +756,24 @@ class ViTBlockFn(torch.autograd.Function):
         dev = g2.device
         bf = T == torch.bfloat16
         g2 = _chk(g2.contiguous(), torch.float32).view(M, D)
-        g2_lp = cast(g2, T)
+        # bf16 copy and column-sum partials of the incoming gradient, if the LayerNorm backward that made it left them
+        g2_side_lp, g2_cs = _side_take(g2) if bf else (None, None)
+        g2_lp = g2_side_lp if g2_side_lp is not None else cast(g2, T)
         qkvw_, qkvb_, pw_, pb_, f1w_, f1b_, f2w_, f2b_ = ctx.prm
         need = ctx.needs_input_grad
         # MLP
-        dw2, db2 = _wgrad_bias(g2_lp, h_act, D, Hd, M, f2w_, f2b_, need[11], need[12], dy_f32=g2)
+        dw2, db2 = _wgrad_bias(g2_lp, h_act, D, Hd, M, f2w_, f2b_, need[11], need[12], dy_f32=g2, dy_colsum=g2_cs)
         dh_pre = torch.empty(M, Hd, dtype=T, device=dev)
         gemm(g2_lp, w2, dh_pre, M=M, N=Hd, K=D, trans_b=True, ldb=Hd, act=ACT_DGELU, aux=h_pre)
         dw1, db1 = _wgrad_bias(dh_pre, ln2, Hd, D, M, f1w_, f1b_, need[9], need[10])
         dln2 = torch.empty(M, D, dtype=T, device=dev)
         gemm(dh_pre, w1, dln2, M=M, N=D, K=Hd, trans_b=True, ldb=D)
-        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf, params=ctx.nprm[2:])
+        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf, params=ctx.nprm[2:], side=bf)
+        g1_side_lp, g1_cs = _side_take(g1) if bf else (None, None)
         if not bf:
             g1_lp = g1
         # attention
-        dwp, dbp = _wgrad_bias(g1_lp, att, D, D, M, pw_, pb_, need[5], need[6], dy_f32=g1)
+        dwp, dbp = _wgrad_bias(g1_lp, att, D, D, M, pw_, pb_, need[5], need[6], dy_f32=g1, dy_colsum=g1_cs)
         datt = torch.empty(M, D, dtype=T, device=dev)
         gemm(g1_lp, wp, datt, M=M, N=D, K=D, trans_b=True, ldb=D)
         if ctx.fused:
@@ -675,7 +783,8 @@ class ViTBlockFn(torch.autograd.Function):
         dwq, dbq = _wgrad_bias(dqkv, ln1, 3 * D, D, M, qkvw_, qkvb_, need[3], need[4])
         dln1 = torch.empty(M, D, dtype=T, device=dev)
         gemm(dqkv, wq, dln1, M=M, N=D, K=3 * D, trans_b=True, ldb=D)
-        g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1, params=ctx.nprm[:2])
+        # the block below this one takes g0 as ITS incoming gradient: leave it the bf16 copy and the column sums
+        g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1, want_lp=bf, params=ctx.nprm[:2], side=bf)
         return (g0.view(B, N, D), dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None)
 
 
@@ -753,7 +862,8 @@ class LayerNormFn(torch.autograd.Function):
         x2 = rest.pop(0) if ctx.has[0] else None
         x3 = rest.pop(0) if ctx.has[1] else None
         g2d = _chk(g.contiguous(), torch.float32).view(-1, D)
-        dx, _, dgamma, dbeta = layernorm_bwd(g2d, x, gamma, mean, rstd, x2=x2, x3=x3, params=ctx.prm)
+        bf = _compute_dtype == torch.bfloat16
+        dx, _, dgamma, dbeta = layernorm_bwd(g2d, x, gamma, mean, rstd, x2=x2, x3=x3, params=ctx.prm, want_lp=bf, side=bf)
         dx = dx.view(g.shape)
         return dx, (dx if ctx.has[0] else None), (dx if ctx.has[1] else None), dgamma, dbeta, None
 

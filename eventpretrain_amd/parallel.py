@@ -49,6 +49,7 @@ class OverlappedPlan:
         # of idling at a kernel boundary. Each chunk's all-reduce is issued from the stream the chunk ran on.
         self.streams = (torch.cuda.Stream(), torch.cuda.Stream()) if (two_streams and torch.cuda.is_available()) else None
         self.opt, self.update_stream = None, None
+        self.timing = None          # a list: run() appends (event at "all chunks computed", event at "all reduced + updated")
 
     def attach_optimizer(self, opt, params):
         """Run the optimizer update in parts, each right after its gradient buffer has been all-reduced (on a third
@@ -110,6 +111,9 @@ class OverlappedPlan:
                 k += 1
             for s in self.streams:
                 cur.wait_stream(s)
+            if self.timing is not None:
+                t_a = torch.cuda.Event(enable_timing=True)
+                t_a.record(cur)
             if upd is not None:
                 with torch.cuda.stream(upd):
                     if not self.others:
@@ -118,6 +122,10 @@ class OverlappedPlan:
                 cur.wait_stream(upd)
         for w in works:
             w.wait()                                  # stream wait, no host sync
+        if self.timing is not None and self.streams is not None:
+            t_b = torch.cuda.Event(enable_timing=True)
+            t_b.record(torch.cuda.current_stream())
+            self.timing.append((t_a, t_b))
 
 
 class BucketedGradReducer:
@@ -132,7 +140,7 @@ class BucketedGradReducer:
         self.params = [p for p in params if p.requires_grad]
         self.bucket_mb = bucket_mb                    # kept for API compatibility; flat buffers are reduced whole
         self._bucket, self._sig = None, None
-        ops.track_deferred_flat_buffers(True)         # this object consumes them in _collect / make_overlapped_plan
+        ops.track_deferred_flat_buffers(self)         # this object consumes them in _collect / make_overlapped_plan
         if broadcast and dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
             src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
             with torch.no_grad():

@@ -164,6 +164,13 @@ int evp_layernorm_bwd_nblk(int64_t M);
 int evp_layernorm_bwd(const void *dy, int dy_dtype, const float *x, const float *x2, const float *x3,
                       const float *gamma, const float *mean, const float *rstd, const float *gres, int64_t M, int D,
                       float *dx, void *dx_lp, float *dgamma, float *dbeta, float *workspace, void *stream);
+/* The same with a third partial row per block: workspace [nblk][3][D] = {dgamma, dbeta, column sums of the OUTPUT dx}. dx is
+ * the gradient of the f32 residual stream, and its column sum is the bias gradient of the Linear that wrote into the
+ * stream (vit_block.py:139,230: proj / fc2): the grouped column-sum launch then reduces nblk rows instead of re-reading the
+ * whole gradient. No finalize: the caller reduces all three partial rows (evp_colsum_grouped). */
+int evp_layernorm_bwd_cs(const void *dy, int dy_dtype, const float *x, const float *x2, const float *x3, const float *gamma,
+                         const float *mean, const float *rstd, const float *gres, int64_t M, int D, float *dx, void *dx_lp,
+                         float *workspace, void *stream);
 
 /* column sums: out[n] (+)= sum_m x[m,n]  (bias gradients). x dtype [M,N] with ld. workspace float32 [nblk*N],
  * nblk = evp_colsum_nblk(M). */

@@ -491,13 +491,20 @@ def test_overlapped_data_parallel_step_matches_single_rank_graph():
         if created:
             dist.destroy_process_group()
     (l0, w0), (l1, w1) = results
-    assert l0 == pytest.approx(l1, rel=1e-5), (l0, l1)
+    assert l0[0] == pytest.approx(l1[0], rel=1e-6), (l0, l1)      # same weights, same batch: only summation order differs
+    assert l0 == pytest.approx(l1, rel=1e-4), (l0, l1)            # later steps carry the Adam noise described below
     # Adam turns a sign flip of a ~zero gradient element (atomics order in the column sums) into a +-lr step, so single
     # elements may differ by a few lr; per tensor the two trajectories must stay together
     for k in w0:
         if w0[k].numel() > 1:
-            tol = 2e-2 if k.endswith("attn.qkv.bias") else 2e-3      # the key third of qkv.bias has an exactly-zero gradient: pure Adam noise
-            assert (w0[k] - w1[k]).norm().item() <= tol * w0[k].norm().item() + 1e-6, k
+            a0, a1 = w0[k], w1[k]
+            if k.endswith("attn.qkv.bias"):
+                # the key third of qkv.bias has an exactly-zero gradient (softmax is invariant to a shift of the keys): what
+                # reaches Adam is rounding noise whose SIGN decides a full +-lr step per element -- chaotic between any two
+                # summation orders, so it is left out; the query and value thirds are compared like everything else
+                n3 = a0.numel() // 3
+                a0, a1 = torch.cat([a0[:n3], a0[2 * n3:]]), torch.cat([a1[:n3], a1[2 * n3:]])
+            assert (a0 - a1).norm().item() <= 2e-3 * a0.norm().item() + 1e-6, k
 
 
 def test_full_size_step_properties():

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""A/B of whole-step variants in ONE process on ONE device (interleaved rounds; MI355X boards differ by several percent, so
+numbers from different gpurun boxes cannot be compared): each variant = a set of ops switches, its own model + HIP graph.
+usage: ab_step.py [--rounds 4] [--steps 15] variant[,variant...]   variants: base, noside, noxcd, ..."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from eventpretrain_amd import ops  # noqa: E402
+from eventpretrain_amd.engine import GraphedStep  # noqa: E402
+from eventpretrain_amd.model.pretrain import pr_hub_model as hub  # noqa: E402
+from eventpretrain_amd.optim import FusedAdamW  # noqa: E402
+from eventpretrain_amd.testing import make_args  # noqa: E402
+from eventpretrain_amd.utils import lr_decay as lrd  # noqa: E402
+
+VARIANTS = {
+    "base": {},
+    "noside": {"set_grad_side": False},
+    "noxcd": {"set_wgrad_xcd_order": False},
+    "nodefer": {"set_deferred_grads": False},
+    "now256": {"set_wgrad256": False},
+}
+
+
+def apply(cfg):
+    defaults = {"set_grad_side": True, "set_wgrad_xcd_order": True, "set_deferred_grads": True, "set_wgrad256": True}
+    for k, v in {**defaults, **cfg}.items():
+        if hasattr(ops, k):
+            getattr(ops, k)(v)
+
+
+def build(B, cfg):
+    apply(cfg)
+    a = make_args(model_size="base", pr_phase="rec", device="cuda", batch_size=B)
+    torch.manual_seed(1)
+    m = hub.pretrain_hub_model_base_patch16(a, emb_frames_dim=512, queue_length=1024, T=0.07).cuda().train()
+    opt = FusedAdamW(lrd.param_groups_lrd(a, m, 0.05, layer_decay=1), lr=1e-4, betas=(0.9, 0.95))
+    x = torch.randn(B, 5, 224, 224, device="cuda") * 0.5
+    y = torch.randn(B, 1, 224, 224, device="cuda")
+    fwd = lambda mm, xx, yy, noise: mm(xx, yy, is_rec=True, noise=noise)
+    ex = GraphedStep(m, opt, fwd, [x, y], noise_shape=(B, 196), generator=torch.Generator(device="cuda").manual_seed(1), warmup=3)
+    assert ex.note.startswith("hip-graph"), ex.note
+    apply({})
+    return ex
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("variants")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--rounds", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=15)
+    ns = ap.parse_args()
+    ops.set_compute_dtype(torch.bfloat16)
+    names = ns.variants.split(",")
+    exs = {n: build(ns.batch, VARIANTS[n]) for n in names}
+    times = {n: [] for n in names}
+    for r in range(ns.rounds):
+        for n in names:
+            ex = exs[n]
+            for _ in range(3):
+                ex.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(ns.steps):
+                loss = ex.step()
+            torch.cuda.synchronize()
+            times[n].append((time.perf_counter() - t0) / ns.steps * 1e3)
+    for n in names:
+        t = sorted(times[n])
+        print(f"{n:10s} min {t[0]:.3f} ms  median {t[len(t) // 2]:.3f} ms  all {[round(v, 3) for v in times[n]]}  loss {exs[n].loss.item():.4f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
