@@ -40,6 +40,7 @@ SIGNATURES = {
     "evp_gemm": [C.POINTER(GemmDesc), _vp],
     "evp_gemm_grouped_tn_bf16": [_vp, _vp, _i, _vp],
     "evp_gemm_grouped_tn256_bf16": [_vp, _vp, _i, _vp],
+    "evp_gemm_grouped_tn_g4_bf16": [_vp, _vp, _i, _vp],
     "evp_sum_slices_f32": [_vp, _vp, _i, _i64, _i, _vp],
     "evp_gemm_set_variant": [_i],
     "evp_gemm_set_debug_buffer": [_vp],

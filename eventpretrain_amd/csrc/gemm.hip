@@ -1337,6 +1337,264 @@ template <typename TC, int EPI, bool TA, bool TB> int launch256(const evp_gemm_d
 }
 
 
+
+// ---- "G4" weight-gradient body: 256x256 tile, 4 waves, ONE wave per SIMD, v_mfma_f32_32x32x16_bf16 ---------------------
+// C[M][N] (f32) (+)= A^T . B, A stored [K][M], B stored [K][N] (TN), K % 32 == 0, K >= 96.
+// Why a second 256x256 body: the half-tile ring above runs two waves per SIMD through barrier-separated read / MFMA phases
+// and needs ~2.0-2.1 us per 64-deep K tile on the weight-gradient shapes. Here a wave owns 128x128 of the tile in 256
+// accumulator registers (the whole 512-register budget belongs to it), which (a) needs 0.25 fragment reads per MFMA,
+// (b) lets the wave hide its own LDS latency: the fragment reads of K step s+1 are issued in front of the 16 MFMAs of
+// step s, no phase barriers -- ONE barrier per 32-deep stage. Both operands are k-strided, so stages can be 32 k-rows
+// thin without splitting cache lines: A 16 KiB + B 16 KiB per stage, FOUR stages in a ring = three tiles of LDS-DMA in
+// flight (measured: the DMA is hidden completely, tools/native/g4_gemm.hip `tn`: 1.25-1.3 us per 64-deep K tile on the
+// step's weight-gradient shapes, 1186 TFLOP/s at 4096^3 against 849 for the ring). One wave per SIMD only issues the
+// 32x32x16 shape at full rate (16x16x32 needs two waves per SIMD).
+// LDS image [32 k][256 m] bf16 (512-byte rows); ds_read_b64_tr_b16 serves 32 lanes as 4 k-rows x 64 B, so the 64-byte
+// block index is XORed with (k & 3) -- on the LDS-DMA source address and on the read address (same involution).
+// RAW / WAR: a stage is read one barrier after every wave's counted vmcnt proved its own pieces landed; it is re-filled
+// (tile t+3 into the stage of tile t-1) after the barrier that follows every wave's lgkmcnt(0) on its last reads of it.
+template <int OFF> __device__ __forceinline__ u32x2 lds_read_tr_imm(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ void tie2(u32x2 &x) { asm volatile("" : "+v"(x)); }
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ void gemm_g4_tn_body(const GemmParams &p, const int tile_m, const int tile_n) {
+  constexpr int IMG = 32 * 512, STAGE = 2 * IMG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.A), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.B), 0, 0x7FFFFFFF, 0x00020000);
+  const int lda = (int)p.lda, ldb = (int)p.ldb;
+
+  // LDS-DMA: piece = 2 k-rows x 512 B, lane-linear in LDS; this wave's 4 pieces of each operand image
+  int voffA[4], voffB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;
+    const int kr = piece * 2 + (lane >> 5), pos = lane & 31;
+    const int m = (((pos >> 2) ^ (kr & 3)) << 5) + ((pos & 3) << 3);
+    voffA[i] = (m0 + m < p.M) ? (kr * lda + m0 + m) * 2 : (int)0x80000000;
+    voffB[i] = (n0 + m < p.N) ? (kr * ldb + n0 + m) * 2 : (int)0x80000000;
+  }
+  const int kstepA = 32 * lda * 2, kstepB = 32 * ldb * 2;
+  auto dma_piece = [&](int idx, int t) {          // idx 0..7: compile time after unrolling
+    char *stage = smem + (t & 3) * STAGE;
+    if (idx < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void *)(stage + (wave * 4 + idx) * 1024), 16, voffA[idx & 3], t * kstepA, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void *)(stage + IMG + (wave * 4 + (idx & 3)) * 1024), 16, voffB[idx & 3], t * kstepB, 0, 0);
+  };
+
+  // fragment addresses (stage 0, K step 0): lane -> k-row 8h + q (+4 for the second read), 16-lane group `sub`, 4 m at 4 pq
+  const int h = lane >> 5, sub = (lane >> 4) & 1, q = (lane >> 2) & 3, pq = lane & 3;
+  const unsigned smem_base = (unsigned)(uintptr_t)(lds_void *)smem;
+  unsigned aaddr[4], baddr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned lanepart = (unsigned)((8 * h + q) * 512 + (16 * sub + 4 * pq) * 2);
+    aaddr[i] = smem_base + lanepart + (unsigned)((((wm * 4 + i) ^ q) << 6));
+    baddr[i] = smem_base + IMG + lanepart + (unsigned)((((wn * 4 + i) ^ q) << 6));
+  }
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x2 a0[4][2], b0[4][2], a1[4][2], b1[4][2];     // [fragment][k 0..3 / 4..7 of the lane's 8]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) a1[i][e] = b1[i][e] = u32x2{0u, 0u};
+  // bias gradient riding on the weight gradient: colsum[m] = sum_k A[k][m], taken from the A fragments of the wn == 0 waves of
+  // the tile_n == 0 workgroups (every A value is in exactly one of them once); v_dot2 against (1, 1), in the MFMAs' shadow
+  const bool do_colsum = p.colsum != nullptr && tile_n == 0 && wn == 0;
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  auto readsA = [&](u32x2 (&fa)[4][2], unsigned soff, auto ksc) {
+    constexpr int KS = decltype(ksc)::value;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i][0] = lds_read_tr_imm<KS * 8192>(aaddr[i] + soff);
+      fa[i][1] = lds_read_tr_imm<KS * 8192 + 2048>(aaddr[i] + soff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto readsB = [&](u32x2 (&fb)[4][2], unsigned soff, auto ksc) {
+    constexpr int KS = decltype(ksc)::value;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fb[i][0] = lds_read_tr_imm<KS * 8192>(baddr[i] + soff);
+      fb[i][1] = lds_read_tr_imm<KS * 8192 + 2048>(baddr[i] + soff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto tie_all = [&](u32x2 (&fa)[4][2], u32x2 (&fb)[4][2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { tie2(fa[i][0]); tie2(fa[i][1]); tie2(fb[i][0]); tie2(fb[i][1]); }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mfma_block = [&](u32x2 (&fa)[4][2], u32x2 (&fb)[4][2], auto dmac, int tn) {
+    constexpr bool DMA = decltype(dmac)::value;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x4 av = u32x4{fa[i][0][0], fa[i][0][1], fa[i][1][0], fa[i][1][1]};
+        const u32x4 bv = u32x4{fb[j][0][0], fb[j][0][1], fb[j][1][0], fb[j][1][1]};
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, av), acc[i][j], 0, 0, 0);
+        const int qn = j * 4 + i;
+        if constexpr (DMA) {
+          if ((qn & 1) == 1) {
+            dma_piece(qn >> 1, tn);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    if (do_colsum) {
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+      const bf16x2 ones = __builtin_bit_cast(bf16x2, 0x3F803F80u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float c = csum[i];
+        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, fa[i][0][0]), ones, c, false);
+        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, fa[i][0][1]), ones, c, false);
+        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, fa[i][1][0]), ones, c, false);
+        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, fa[i][1][1]), ones, c, false);
+        csum[i] = c;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  const int nk = p.K / 32;                        // >= 3 (launcher)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_piece(i, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_piece(i, 1);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_piece(i, 2);
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // one stage; VM = pieces that may still be in flight at its end (16: two newer tiles, 8: one, 0: none, -1: last stage)
+  auto iteration = [&](auto dmac, auto vmc, int t) {
+    constexpr int VM = decltype(vmc)::value;
+    const unsigned soff = (unsigned)((t & 3) * STAGE);
+    readsA(a0, soff, std::integral_constant<int, 0>{});
+    readsB(b0, soff, std::integral_constant<int, 0>{});
+    mfma_block(a1, b1, std::false_type{}, 0);              // (t-1, K step 1); zeros at t = 0
+    readsA(a1, soff, std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // the 16 reads of K step 0 have landed (reads return in order)
+    readsB(b1, soff, std::integral_constant<int, 1>{});
+    tie_all(a0, b0);
+    mfma_block(a0, b0, dmac, t + 3);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    tie_all(a1, b1);
+    if constexpr (VM == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (VM == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (VM == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (VM >= 0) __builtin_amdgcn_s_barrier();
+  };
+  int t = 0;
+  for (; t + 3 < nk; ++t) iteration(std::true_type{}, std::integral_constant<int, 16>{}, t);
+  iteration(std::false_type{}, std::integral_constant<int, 8>{}, t);
+  iteration(std::false_type{}, std::integral_constant<int, 0>{}, t + 1);
+  iteration(std::false_type{}, std::integral_constant<int, -1>{}, t + 2);
+  mfma_block(a1, b1, std::false_type{}, 0);
+
+  // C[m][n..n+3]: lane m = .. + (lane & 31); register r: n = .. + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)
+  float *C = reinterpret_cast<float *>(p.C);
+  const int mrow = m0 + wm * 128 + (lane & 31), ncol = n0 + wn * 128 + 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mrow + 32 * i;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = ncol + 32 * j + 8 * g;
+        if (n >= p.N) continue;
+        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        float *c = C + (int64_t)m * p.ldc + n;
+        if (n + 3 < p.N) {
+          if (p.accumulate) {
+            const float4 o = *reinterpret_cast<const float4 *>(c);
+            v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w);
+          }
+          *reinterpret_cast<float4 *>(c) = v;
+        } else {
+          const float e[4] = {v.x, v.y, v.z, v.w};
+          for (int u = 0; u < 4 && n + u < p.N; ++u) c[u] = p.accumulate ? c[u] + e[u] : e[u];
+        }
+      }
+  }
+  if (do_colsum) {                               // lanes l and l + 32 hold the two k halves of row (lane & 31)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = csum[i];
+      v += __shfl_xor(v, 32, 64);
+      const int m = mrow + 32 * i;
+      if (lane < 32 && m < p.M) p.colsum[m] = p.colsum_acc ? p.colsum[m] + v : v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gemm_g4_grouped_tn_kernel(const GroupedProblem *__restrict__ probs, const GroupedItem *__restrict__ items) {
+  const GroupedItem it = items[blockIdx.x];
+  if (it.prob < 0) return;                       // padding of the per-XCD item lists
+  const GroupedProblem g = probs[it.prob];
+  GemmParams p;
+  p.M = g.M; p.N = g.N; p.K = g.K;
+  p.A = g.A; p.lda = g.lda; p.sA0 = 0; p.sA1 = 0;
+  p.B = g.B; p.ldb = g.ldb; p.sB0 = 0; p.sB1 = 0;
+  p.C = g.C; p.c_dtype = EVP_F32; p.ldc = g.ldc; p.sC0 = 0; p.sC1 = 0;
+  p.batch1 = 1; p.alpha = 1.0f; p.bias = nullptr; p.act = EVP_ACT_NONE; p.aux = nullptr; p.ldaux = 0;
+  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1; p.dbg = 0; p.dbgbuf = nullptr;
+  p.k_per_split = g.K;
+  p.colsum = g.colsum; p.colsum_acc = g.colsum_accumulate;
+  gemm_g4_tn_body(p, it.tile_m, it.tile_n);
+}
+
+__global__ __launch_bounds__(256) void gemm_g4_tn_kernel(const GemmParams p) {
+  int tile_m, tile_n;
+  map_tile(gridDim.x, blockIdx.x, p.tiles_m, tile_m, tile_n);
+  gemm_g4_tn_body(p, tile_m, tile_n);
+}
+
+static int launch_g4_tn(const evp_gemm_desc *d, hipStream_t s) {
+  GemmParams p;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.A = d->A; p.lda = d->lda; p.sA0 = 0; p.sA1 = 0;
+  p.B = d->B; p.ldb = d->ldb; p.sB0 = 0; p.sB1 = 0;
+  p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = 0; p.sC1 = 0;
+  p.batch1 = 1; p.alpha = 1.0f; p.bias = nullptr; p.act = EVP_ACT_NONE; p.aux = nullptr; p.ldaux = 0;
+  p.residual = nullptr; p.ldres = 0; p.accumulate = d->accumulate; p.dbg = 0; p.dbgbuf = nullptr; p.colsum = nullptr; p.colsum_acc = 0;
+  p.tiles_m = (d->M + 255) / 256;
+  p.splitk = 1; p.k_per_split = d->K;
+  const int tiles_n = (d->N + 255) / 256;
+  constexpr int smem = 4 * 2 * 32 * 512;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_g4_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { evp_set_error("evp_gemm: hipFuncSetAttribute(%d) failed: %s", smem, hipGetErrorString(e)); return EVP_ELAUNCH; }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(gemm_g4_tn_kernel, dim3((unsigned)(p.tiles_m * tiles_n)), dim3(256), smem, s, p);
+  EVP_CHECK_LAUNCH("evp_gemm(g4 tn)");
+  return EVP_OK;
+}
+
 // ---- persistent form of the 128x128x64 bf16 LDS-DMA body ------------------------------------------------------------
 // At this path's shapes (K = 512..3072, 300-1600 tiles) a third of a GEMM's time was per-tile fixed cost: workgroup
 // launch, the first operand loads' latency, the epilogue's stores draining before the workgroup retires. Here 2 x 256
@@ -1744,6 +2002,20 @@ template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(cons
       if (nbz != 1) { evp_set_error("evp_gemm: tile 7 (persistent) takes no batch"); return EVP_ESHAPE; }
       return launch_persist<TC, EPI, TA, TB>(d, s);
     }
+    if (tile == 9) {        // G4 body (weight-gradient layout only): 256x256, one wave per SIMD, 32x32x16
+      if constexpr (TA && TB && EPI == 0 && std::is_same<TC, float>::value) {
+        const int64_t nbz = (int64_t)(d->batch0 > 0 ? d->batch0 : 1) * (d->batch1 > 0 ? d->batch1 : 1);
+        if (nbz != 1 || d->K % 32 != 0 || d->K < 96 || d->bias || d->residual || d->aux || d->alpha != 1.0f || d->splitk > 1 ||
+            d->lda % 8 != 0 || d->ldb % 8 != 0) {
+          evp_set_error("evp_gemm: tile 9 (G4) needs transA, transB, f32 C, K %% 32 == 0, K >= 96, no batch / epilogue extras");
+          return EVP_ESHAPE;
+        }
+        return launch_g4_tn(d, s);
+      } else {
+        evp_set_error("evp_gemm: tile 9 (G4) is built for the weight-gradient layout (transA = transB = 1, f32 C) only");
+        return EVP_EUNSUPPORTED;
+      }
+    }
     if (tile == 6) {
       if (d->K % 64 != 0) { evp_set_error("evp_gemm: tile 6 (256x256 ring) needs K %% 64 == 0 (K=%d)", d->K); return EVP_ESHAPE; }
       return launch256<TC, EPI, TA, TB>(d, s);
@@ -1817,6 +2089,22 @@ extern "C" int evp_gemm_grouped_tn256_bf16(const void *problems, const void *ite
   hipLaunchKernelGGL(k, dim3((unsigned)n_items), dim3(512), smem, (hipStream_t)stream,
                      reinterpret_cast<const GroupedProblem *>(problems), reinterpret_cast<const GroupedItem *>(items));
   EVP_CHECK_LAUNCH("evp_gemm_grouped_tn256_bf16");
+  return EVP_OK;
+}
+
+extern "C" int evp_gemm_grouped_tn_g4_bf16(const void *problems, const void *items, int n_items, void *stream) {
+  EVP_CHECK_ARG(problems && items && n_items > 0, EVP_EINVAL, "evp_gemm_grouped_tn_g4_bf16: bad argument");
+  auto k = gemm_g4_grouped_tn_kernel;
+  constexpr int smem = 4 * 2 * 32 * 512;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_gemm_grouped_tn_g4_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)n_items), dim3(256), smem, (hipStream_t)stream,
+                     reinterpret_cast<const GroupedProblem *>(problems), reinterpret_cast<const GroupedItem *>(items));
+  EVP_CHECK_LAUNCH("evp_gemm_grouped_tn_g4_bf16");
   return EVP_OK;
 }
 

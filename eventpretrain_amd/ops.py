@@ -479,7 +479,11 @@ class _DeferredGrads:
                     cuts = sorted(set(min(max(c, 0), len(big)) for c in cuts))
                     for c in range(len(cuts) - 1):
                         if cuts[c + 1] > cuts[c]:
-                            groups.append(("w256r%dc%d" % (r, c), big[cuts[c]:cuts[c + 1]], 256, "evp_gemm_grouped_tn256_bf16"))
+                            part_ = big[cuts[c]:cuts[c + 1]]
+                            # G4 body (one wave per SIMD, 32-deep stages): K % 32 == 0 holds for every `big_` problem (K % 64)
+                            entry_ = "evp_gemm_grouped_tn_g4_bf16" if (_use_wgrad_g4 and all(it[5] >= 96 for it in part_)) else \
+                                "evp_gemm_grouped_tn256_bf16"
+                            groups.append(("w256r%dc%d" % (r, c), part_, 256, entry_))
                 if small:
                     groups.append(("w128r%d" % r, small, 128, "evp_gemm_grouped_tn_bf16"))
                 for tag, part, T_, entry in groups:
@@ -608,6 +612,15 @@ def _deal_to_xcds(items, work, n_xcd=8):
 
 
 _wgrad_xcd_order = os.environ.get("EVP_WGRAD_XCD", "1") != "0"
+_use_wgrad_g4 = os.environ.get("EVP_WGRAD_G4", "1") != "0"
+
+
+def set_wgrad_g4(flag):
+    """A/B switch: grouped 256x256 weight gradients on the G4 body (one wave per SIMD, 32x32x16; default) or on the 8-wave
+    half-tile ring."""
+    global _use_wgrad_g4
+    _use_wgrad_g4 = bool(flag)
+
 
 
 def set_wgrad_xcd_order(flag):

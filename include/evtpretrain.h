@@ -117,7 +117,7 @@ typedef struct {
   void *aux; int64_t ldaux;            /* element type = c_dtype; batch strides = C's */
   const float *residual; int64_t ldres; /* batch strides = C's */
   int accumulate;
-  int tile;                             /* 0 auto, 1 = 128x128, 2 = 64x64, 6 = 256x256 ring (bf16, K % 64 == 0), 12 = stream-K 128x128 */
+  int tile;                             /* 0 auto, 1 = 128x128, 2 = 64x64, 6 = 256x256 ring (bf16, K % 64 == 0), 9 = G4 256x256 (bf16 TN, f32 C, K % 32 == 0), 12 = stream-K 128x128 */
   int splitk;                           /* 0 auto, n = cut K into n slices summed with f32 atomics (plain f32 C only) */
   /* Optional stream-K workspace (bf16, transA = 0, no batch): device memory, >= 4096 + 65536 * 2 * CUs bytes, its first
    * 4096 bytes zeroed ONCE by the caller (the kernel leaves them zero). Used by tile = 12 only (the stream-K form of the
@@ -140,6 +140,11 @@ int evp_gemm_grouped_tn_bf16(const void *problems, const void *items, int n_item
  * A non-NULL `colsum` (float32 [M_g]) also receives colsum[m] (+)= sum_k A_g[k][m] -- the bias gradient db = sum over
  * rows of dY of the same Linear -- computed from the A fragments already in registers (no second pass over dY). */
 int evp_gemm_grouped_tn256_bf16(const void *problems, const void *items, int n_items, void *stream);
+/* Same tables (256x256 items), every K_g a multiple of 32 and >= 96: the "G4" body -- 4 waves, one per SIMD, each holding
+ * 128x128 of the tile in 256 accumulator registers (v_mfma_f32_32x32x16_bf16), 32-deep stages in a four-slot LDS-DMA ring,
+ * one barrier per stage. The default for the step's weight gradients (dW = dY^T X of every nn.Linear on the path,
+ * model/sub_module/vit_block.py:131-143,225-231). Items with prob < 0 are skipped (padding of per-XCD lists). */
+int evp_gemm_grouped_tn_g4_bf16(const void *problems, const void *items, int n_items, void *stream);
 /* out[i] (+)= sum_s ws[s*numel + i], float32, numel % 4 == 0: reduction of split-K partials when a long-K problem was
  * entered into the grouped launch as several K-slice problems writing to a workspace (ConvViT stage 1: K = B*56*56). */
 int evp_sum_slices_f32(const float *ws, float *out, int n_slices, int64_t numel, int accumulate, void *stream);

@@ -184,14 +184,17 @@ def test_argument_errors_raise():
         ops.gemm(a.cpu(), a.cpu(), torch.zeros(8, 8), M=8, N=8, K=12)              # no CPU path
 
 
-def test_grouped_tn256_with_fused_column_sums_exact():
-    """evp_gemm_grouped_tn256_bf16: several dW = dY^T X problems in one launch of the 256x256 ring kernel, with the bias
+@pytest.mark.parametrize("entry", ["evp_gemm_grouped_tn256_bf16", "evp_gemm_grouped_tn_g4_bf16"])
+def test_grouped_tn256_with_fused_column_sums_exact(entry):
+    """evp_gemm_grouped_tn256_bf16 / evp_gemm_grouped_tn_g4_bf16 (8-wave ring and G4 one-wave-per-SIMD bodies, same
+    tables): several dW = dY^T X problems in one launch of a 256x256-tile kernel, with the bias
     gradient (column sums of dY) produced by the same kernel; small-integer data, so every result is exact. Covers ragged
     M / N (not multiples of 256), accumulate into an existing dW / db, and a problem without column sums."""
     import numpy as np
     from eventpretrain_amd._lib import call, stream_ptr
     g = torch.Generator(device="cuda").manual_seed(11)
-    specs = [(768, 512, 1280, True, False), (304, 264, 192, True, True), (256, 256, 64, False, False), (2304, 768, 6272, True, False)]
+    specs = [(768, 512, 1280, True, False), (304, 264, 192, True, True), (256, 256, 128 if "g4" in entry else 64, False, False),
+             (2304, 768, 6272, True, False), (520, 776, 96, True, True)]
     pdt = np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i4"), ("N", "<i4"), ("K", "<i4"), ("lda", "<i4"),
                     ("ldb", "<i4"), ("ldc", "<i4"), ("acc", "<i4"), ("cacc", "<i4"), ("colsum", "<u8")])
     probs = np.zeros(len(specs), dtype=pdt)
@@ -206,9 +209,11 @@ def test_grouped_tn256_with_fused_column_sums_exact():
         for tn in range((N + 255) // 256):
             for tm in range((M + 255) // 256):
                 items.append((i, tm, tn, 0))
+    items.insert(3, (-1, 0, 0, 0))          # padding items (per-XCD list layout) are skipped
+    items.append((-1, 0, 0, 0))
     pt = torch.from_numpy(probs.view(np.uint8)).cuda()
     it = torch.tensor(items, dtype=torch.int32, device="cuda")
-    call("evp_gemm_grouped_tn256_bf16", pt.data_ptr(), it.data_ptr(), len(items), stream_ptr())
+    call(entry, pt.data_ptr(), it.data_ptr(), len(items), stream_ptr())
     torch.cuda.synchronize()
     for dy, x, dw, db, want_cs, acc in keep:
         ref_w = dy.float().t() @ x.float() + (3.0 if acc else 0.0)
@@ -217,6 +222,29 @@ def test_grouped_tn256_with_fused_column_sums_exact():
             assert torch.equal(db, dy.float().sum(0) + (5.0 if acc else 0.0))
         else:
             assert torch.equal(db, torch.full_like(db, 5.0))
+
+
+def test_g4_tn_tile_exact_and_random():
+    """evp_gemm tile 9: the G4 body as a plain TN GEMM -- exact on small integers (ragged M / N, K = 96 .. 6272, accumulate),
+    and within f32-accumulation tolerance of float64 on random data."""
+    g = torch.Generator().manual_seed(3)
+    for M, N, K in [(256, 256, 96), (300, 520, 160), (768, 3072, 6272), (1000, 264, 1056)]:
+        a = torch.randint(-3, 4, (K, M), generator=g).to(torch.bfloat16)
+        b = torch.randint(-3, 4, (K, N), generator=g).to(torch.bfloat16)
+        ref = a.double().t() @ b.double()
+        out = torch.full((M, N), 2.0, device="cuda")
+        ops.gemm(a.cuda(), b.cuda(), out, M=M, N=N, K=K, trans_a=True, trans_b=True, lda=M, ldb=N, tile=9)
+        assert torch.equal(out.cpu().double(), ref), (M, N, K)
+        ops.gemm(a.cuda(), b.cuda(), out, M=M, N=N, K=K, trans_a=True, trans_b=True, lda=M, ldb=N, tile=9, accumulate=True)
+        assert torch.equal(out.cpu().double(), 2 * ref), (M, N, K, "accumulate")
+    a = torch.randn(2048, 520, generator=g).to(torch.bfloat16)
+    b = torch.randn(2048, 392, generator=g).to(torch.bfloat16)
+    out = torch.empty(520, 392, device="cuda")
+    ops.gemm(a.cuda(), b.cuda(), out, M=520, N=392, K=2048, trans_a=True, trans_b=True, lda=520, ldb=392, tile=9)
+    ref = a.double().t() @ b.double()
+    assert (out.cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() * 45
+    with pytest.raises(Exception):
+        ops.gemm(a.cuda(), b.cuda(), out, M=520, N=392, K=2048, lda=2048, ldb=2048, tile=9)      # not the TN layout
 
 
 @pytest.mark.parametrize("tb", [False, True])

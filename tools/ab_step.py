@@ -23,11 +23,12 @@ VARIANTS = {
     "noxcd": {"set_wgrad_xcd_order": False},
     "nodefer": {"set_deferred_grads": False},
     "now256": {"set_wgrad256": False},
+    "nog4": {"set_wgrad_g4": False},
 }
 
 
 def apply(cfg):
-    defaults = {"set_grad_side": True, "set_wgrad_xcd_order": True, "set_deferred_grads": True, "set_wgrad256": True}
+    defaults = {"set_grad_side": True, "set_wgrad_xcd_order": True, "set_deferred_grads": True, "set_wgrad256": True, "set_wgrad_g4": True}
     for k, v in {**defaults, **cfg}.items():
         if hasattr(ops, k):
             getattr(ops, k)(v)
@@ -70,6 +71,8 @@ def main():
                 loss = ex.step()
             torch.cuda.synchronize()
             times[n].append((time.perf_counter() - t0) / ns.steps * 1e3)
+            if not torch.isfinite(ex.loss).all():
+                print(f"NON-FINITE loss in variant {n}, round {r}", flush=True)
     for n in names:
         t = sorted(times[n])
         print(f"{n:10s} min {t[0]:.3f} ms  median {t[len(t) // 2]:.3f} ms  all {[round(v, 3) for v in times[n]]}  loss {exs[n].loss.item():.4f}", flush=True)

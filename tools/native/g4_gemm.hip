@@ -230,6 +230,197 @@ __global__ __launch_bounds__(256) void g4_kernel(const G4Params p) {
   g4_body<NJ, F32OUT, MODE>(p);
 }
 
+
+// ================================================================================================================ TN
+// C[M][N] (f32) = A^T . B with A stored [K][M], B stored [K][N] (the weight-gradient layout: A = dY, B = X, K = tokens).
+// Same 4-wave / 32x32x16 structure on a 256x256 tile. Both operands are k-strided, so a K tile can be as thin as we like
+// without splitting cache lines: stages of 32 k-rows (A 16 KiB + B 16 KiB), FOUR of them in a ring -> three tiles of
+// LDS-DMA in flight, one barrier per stage (32 MFMAs). Fragments come through ds_read_b64_tr_b16 (two per fragment).
+// LDS image [32 k][256 m], 512-byte rows; a 32-lane read group touches 4 k-rows x 64 B, so the 64-byte block index is
+// XORed with (k & 3) (on the DMA source side and on the read side).
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+template <int OFF> __device__ __forceinline__ u32x2 lds_read_tr(unsigned addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
+  return v;
+}
+__device__ __forceinline__ void tie2(u32x2 &x) { asm volatile("" : "+v"(x)); }
+
+struct G4TNParams {
+  int M, N, K;
+  const bf16_t *A; int lda;
+  const bf16_t *B; int ldb;
+  float *C; int ldc;
+  int tiles_m, tiles_n;
+};
+
+template <int MODE>
+__device__ __forceinline__ void g4tn_body(const G4TNParams &p, const int tile_m, const int tile_n) {
+  constexpr int IMG = 32 * 512, STAGE = 2 * IMG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.A), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.B), 0, 0x7FFFFFFF, 0x00020000);
+
+  // LDS-DMA: piece = 2 k-rows x 512 B, lane-linear in LDS; this wave's 4 pieces of each operand image
+  int voffA[4], voffB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;
+    const int kr = piece * 2 + (lane >> 5), pos = lane & 31;
+    const int m = (((pos >> 2) ^ (kr & 3)) << 5) + ((pos & 3) << 3);
+    voffA[i] = (m0 + m < p.M) ? (kr * p.lda + m0 + m) * 2 : (int)0x80000000;
+    voffB[i] = (n0 + m < p.N) ? (kr * p.ldb + n0 + m) * 2 : (int)0x80000000;
+  }
+  const int kstepA = 32 * p.lda * 2, kstepB = 32 * p.ldb * 2;
+  auto dma_piece = [&](int idx, int t) {          // idx 0..7 (compile time after unrolling)
+    char *stage = smem + (t & 3) * STAGE;
+    if (idx < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void *)(stage + (wave * 4 + idx) * 1024), 16, voffA[idx & 3], t * kstepA, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void *)(stage + IMG + (wave * 4 + (idx & 3)) * 1024), 16, voffB[idx & 3], t * kstepB, 0, 0);
+  };
+
+  // fragment addresses (stage 0, K step 0): lane -> k-row 8h + q (+4 for the second read), 16-lane group sub, 4 m at 4p
+  const int h = lane >> 5, sub = (lane >> 4) & 1, q = (lane >> 2) & 3, pq = lane & 3;
+  const unsigned smem_base = (unsigned)(uintptr_t)(lds_void *)smem;
+  unsigned aaddr[4], baddr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned lanepart = (unsigned)((8 * h + q) * 512 + (16 * sub + 4 * pq) * 2);
+    aaddr[i] = smem_base + lanepart + (unsigned)((((wm * 4 + i) ^ q) << 6));
+    baddr[i] = smem_base + IMG + lanepart + (unsigned)((((wn * 4 + i) ^ q) << 6));
+  }
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x2 a0[4][2], b0[4][2], a1[4][2], b1[4][2];     // [fragment][k half-group 0..3 / 4..7]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) a1[i][e] = b1[i][e] = u32x2{0u, 0u};
+
+  auto readsA = [&](u32x2 (&fa)[4][2], unsigned soff, auto ksc) {
+    constexpr int KS = decltype(ksc)::value;
+    if constexpr (MODE == 3) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i][0] = lds_read_tr<KS * 8192>(aaddr[i] + soff);
+      fa[i][1] = lds_read_tr<KS * 8192 + 2048>(aaddr[i] + soff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto readsB = [&](u32x2 (&fb)[4][2], unsigned soff, auto ksc) {
+    constexpr int KS = decltype(ksc)::value;
+    if constexpr (MODE == 3) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fb[i][0] = lds_read_tr<KS * 8192>(baddr[i] + soff);
+      fb[i][1] = lds_read_tr<KS * 8192 + 2048>(baddr[i] + soff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto tie_all = [&](u32x2 (&fa)[4][2], u32x2 (&fb)[4][2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { tie2(fa[i][0]); tie2(fa[i][1]); tie2(fb[i][0]); tie2(fb[i][1]); }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mfma_block = [&](u32x2 (&fa)[4][2], u32x2 (&fb)[4][2], auto dmac, int tn) {
+    constexpr bool DMA = decltype(dmac)::value && MODE != 1;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x4 av = u32x4{fa[i][0][0], fa[i][0][1], fa[i][1][0], fa[i][1][1]};
+        const u32x4 bv = u32x4{fb[j][0][0], fb[j][0][1], fb[j][1][0], fb[j][1][1]};
+        if constexpr (MODE != 2)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, av), acc[i][j], 0, 0, 0);
+        const int qn = j * 4 + i;
+        if constexpr (DMA) {
+          if ((qn & 1) == 1) {
+            dma_piece(qn >> 1, tn);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  const int nk = p.K / 32;
+  // prologue: tiles 0..2
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dma_piece(i, 0);
+  if (nk > 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_piece(i, 1);
+  }
+  if (nk > 2) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_piece(i, 2);
+  }
+  if (nk > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // one stage; VM = pieces that may still be in flight at its end (16: two newer tiles, 8: one, 0: none, -1: last stage)
+  auto iteration = [&](auto dmac, auto vmc, int t) {
+    constexpr int VM = decltype(vmc)::value;
+    const unsigned soff = (unsigned)((t & 3) * STAGE);
+    readsA(a0, soff, std::integral_constant<int, 0>{});
+    readsB(b0, soff, std::integral_constant<int, 0>{});
+    mfma_block(a1, b1, std::false_type{}, 0);              // (t-1, K step 1); zeros at t = 0
+    readsA(a1, soff, std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // the 16 reads of K step 0 have landed
+    readsB(b1, soff, std::integral_constant<int, 1>{});
+    tie_all(a0, b0);
+    mfma_block(a0, b0, dmac, t + 3);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    tie_all(a1, b1);
+    if constexpr (VM == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (VM == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (VM == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (VM >= 0) __builtin_amdgcn_s_barrier();
+  };
+  // nk >= 3 (the launcher's precondition): the main loop keeps three tiles in flight, the last three stages drain
+  int t = 0;
+  for (; t + 3 < nk; ++t) iteration(std::true_type{}, std::integral_constant<int, 16>{}, t);
+  iteration(std::false_type{}, std::integral_constant<int, 8>{}, t);
+  iteration(std::false_type{}, std::integral_constant<int, 0>{}, t + 1);
+  iteration(std::false_type{}, std::integral_constant<int, -1>{}, t + 2);
+  mfma_block(a1, b1, std::false_type{}, 0);
+
+  // C[m][n..n+3]: lane m = .. + (lane & 31); reg r: n = .. + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)
+  const int mrow = m0 + wm * 128 + (lane & 31), ncol = n0 + wn * 128 + 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mrow + 32 * i;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = ncol + 32 * j + 8 * g;
+        if (n + 3 >= p.N) continue;
+        *reinterpret_cast<float4 *>(p.C + (int64_t)m * p.ldc + n) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+      }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void g4tn_kernel(const G4TNParams p) {
+  const int t_lin = xcd_renumber(gridDim.x, blockIdx.x);
+  g4tn_body<MODE>(p, t_lin / p.tiles_n, t_lin % p.tiles_n);
+}
+
 // ------------------------------------------------------------------------------------------------------------ host
 static inline bf16_t f2bf(float f) {
   uint32_t u;
@@ -277,6 +468,73 @@ static float run_nj(int nj, int mode, const G4Params &p, int reps, hipEvent_t e0
   }
 }
 
+template <int MODE> static float run_tn(const G4TNParams &p, int reps, hipEvent_t e0, hipEvent_t e1) {
+  constexpr int smem = 4 * 2 * 32 * 512;
+  void (*k)(const G4TNParams) = g4tn_kernel<MODE>;
+  hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  G4TNParams q = p;
+  q.tiles_m = (p.M + 255) / 256;
+  q.tiles_n = (p.N + 255) / 256;
+  const dim3 grid(q.tiles_m * q.tiles_n);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, grid, dim3(256), smem, 0, q);
+  hipEventRecord(e0);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, grid, dim3(256), smem, 0, q);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { printf("launch error: %s\n", hipGetErrorString(e)); exit(2); }
+  return ms / reps * 1e3f;
+}
+
+static int main_tn(hipEvent_t e0, hipEvent_t e1) {
+  struct Shape { const char *name; int M, N, K; };
+  std::vector<Shape> shapes = {{"check", 520, 264, 160},          {"enc.qkv", 2304, 768, 6272}, {"enc.proj", 768, 768, 6272},
+                               {"enc.fc1", 3072, 768, 6272},      {"enc.fc2", 768, 3072, 6272}, {"dec.qkv", 1536, 512, 12544},
+                               {"dec.fc1", 2048, 512, 12544},     {"dec.fc2", 512, 2048, 12544}, {"sq4096", 4096, 4096, 4096}};
+  int bad_total = 0;
+  for (const Shape &s : shapes) {
+    const size_t na = (size_t)s.K * s.M, nb = (size_t)s.K * s.N, nc = (size_t)s.M * s.N;
+    std::vector<bf16_t> ha(na), hb(nb);
+    std::vector<float> hc(nc);
+    for (auto &v : ha) v = f2bf((float)(rand() & 0xFFFFFF) / 8388608.f - 1.f);
+    for (auto &v : hb) v = f2bf((float)(rand() & 0xFFFFFF) / 8388608.f - 1.f);
+    bf16_t *da, *db;
+    float *dc;
+    hipMalloc(&da, na * 2); hipMalloc(&db, nb * 2); hipMalloc(&dc, nc * 4);
+    hipMemcpy(da, ha.data(), na * 2, hipMemcpyHostToDevice);
+    hipMemcpy(db, hb.data(), nb * 2, hipMemcpyHostToDevice);
+    hipMemset(dc, 0xFF, nc * 4);
+    G4TNParams p{s.M, s.N, s.K, da, s.M, db, s.N, dc, s.N, 0, 0};
+    const int reps = (double)s.M * s.N * s.K > 3e10 ? 5 : 20;
+    const float us = run_tn<0>(p, reps, e0, e1);
+    hipMemcpy(hc.data(), dc, nc * 4, hipMemcpyDeviceToHost);
+    int bad = 0;
+    const size_t nchk = nc <= 400000 ? nc : 3000;
+    for (size_t c = 0; c < nchk; ++c) {
+      const size_t e = nc <= 400000 ? c : ((size_t)rand() * 2654435761u + c * 7919) % nc;
+      const int m = (int)(e / s.N), n = (int)(e % s.N);
+      double ref = 0;
+      for (int k = 0; k < s.K; ++k) ref += (double)bf2f(ha[(size_t)k * s.M + m]) * bf2f(hb[(size_t)k * s.N + n]);
+      const double got = hc[e];
+      if (!(fabs(got - ref) <= 1e-3 * fabs(ref) + 2e-3 * sqrt((double)s.K))) {
+        if (bad < 3) printf("\n  TN MISMATCH m=%d n=%d got %g ref %g", m, n, got, ref);
+        ++bad;
+      }
+    }
+    bad_total += bad;
+    const int tiles = ((s.M + 255) / 256) * ((s.N + 255) / 256);
+    printf("TN %-8s %5dx%5dx%5d %4dt %8.1fus %6.0fTF %6.2fus/K64%s", s.name, s.M, s.N, s.K, tiles, us, 2.0 * s.M * s.N * s.K / us * 1e-6,
+           us / (s.K / 64.0) / ((tiles + 255) / 256), bad ? " BAD" : "");
+    if (s.K >= 4096) printf("   ablation: noDMA %.1f noMFMA %.1f noREAD %.1f", run_tn<1>(p, 5, e0, e1), run_tn<2>(p, 5, e0, e1), run_tn<3>(p, 5, e0, e1));
+    printf("\n");
+    fflush(stdout);
+    hipFree(da); hipFree(db); hipFree(dc);
+  }
+  return bad_total;
+}
+
 int main(int argc, char **argv) {
   struct Shape { const char *name; int M, N, K; };
   std::vector<Shape> shapes = {
@@ -288,6 +546,11 @@ int main(int argc, char **argv) {
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   srand(1);
+  if (argc > 1 && !strcmp(argv[1], "tn")) {
+    const int bad = main_tn(e0, e1);
+    printf(bad ? "FAILED: %d mismatches\n" : "checks OK\n", bad);
+    return bad ? 1 : 0;
+  }
   int bad_total = 0;
   for (const Shape &s : shapes) {
     const size_t na = (size_t)s.M * s.K, nb = (size_t)s.N * s.K, nc = (size_t)s.M * s.N;
