@@ -307,7 +307,11 @@ def main():
     from eventpretrain_amd.engine import GraphedStep
     use_graph = (not args.no_graph) and graphable       # the Swin step plans its windows on the host per step: eager
     n_warm_eager = min(args.warmup, 3) if use_graph else 0
-    if phase == "rec":
+    if phase == "rec" and not graphable:
+        # Swin: mask noise drawn on the host (seeded per rank), so the window plan needs no device->host read-back
+        hgen = torch.Generator().manual_seed(100 + rank)
+        fwd, noise_shape = (lambda m, x, y, noise: m(x, y, is_rec=True, noise=torch.rand(args.batch, cells, generator=hgen))), None
+    elif phase == "rec":
         fwd, noise_shape = (lambda m, x, y, noise: m(x, y, is_rec=True, noise=noise)), (args.batch, cells)
     else:
         fwd, noise_shape = (lambda m, x, y, noise: m(x, y)), None
@@ -391,7 +395,8 @@ def main():
         orig_call = _ops.call
 
         GROUPED = {"evp_gemm_grouped_tn_bf16": ("gemm_grouped_tn_kernel<128,128>", 128),
-                   "evp_gemm_grouped_tn256_bf16": ("gemm256_grouped_tn_kernel (256x256 ring)", 256)}
+                   "evp_gemm_grouped_tn256_bf16": ("gemm256_grouped_tn_kernel (256x256 ring)", 256),
+                   "evp_gemm_grouped_tn_g4_bf16": ("gemm_g4_grouped_tn_kernel (256x256, one wave per SIMD, 32x32x16)", 256)}
 
         def timed_call(name, *a_):
             if name not in GROUPED:
@@ -412,7 +417,8 @@ def main():
         def counting_flush():
             for (_, _, _, n_out, k_in, rows, _bp) in _ops._deferred.w:
                 big = _ops._use_wgrad256 and rows % 64 == 0 and n_out >= 256 and k_in >= 256      # the routing rule of flush()
-                name = "evp_gemm_grouped_tn256_bf16" if big else "evp_gemm_grouped_tn_bf16"
+                name = ("evp_gemm_grouped_tn_g4_bf16" if (_ops._use_wgrad_g4 and rows >= 96) else "evp_gemm_grouped_tn256_bf16") if big \
+                    else "evp_gemm_grouped_tn_bf16"
                 T_ = GROUPED[name][1]
                 g_ = grouped.setdefault(name, {})
                 g_["flops"] = g_.get("flops", 0.0) + 2.0 * n_out * k_in * rows

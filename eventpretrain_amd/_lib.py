@@ -96,6 +96,7 @@ SIGNATURES = {
     "evp_swin_fuse_gather_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "evp_swin_group_windows": [_vp, _i, _i, _vp, _vp, _vp],
     "evp_view_augment_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "evp_frame_augment_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "evp_token_mean_fwd": [_vp, _i, _i, _i, _vp, _vp],
     "evp_token_mean_bwd": [_vp, _i, _i, _i, _vp, _vp],
     "evp_abi_version": [],

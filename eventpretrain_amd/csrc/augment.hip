@@ -39,3 +39,72 @@ extern "C" int evp_view_augment_f32(const float *in, const int32_t *params, floa
   EVP_CHECK_LAUNCH("evp_view_augment_f32");
   return EVP_OK;
 }
+
+
+// ---- difference-map target: crop -> BICUBIC resize -> horizontal flip -> (negate on time flip) --------------------------
+// dataset/augmentation/view_augment.py:79-89 `frame_augment` (same seed as evg_augment, so the same crop box and flip
+// coin; the time-flip flag is handed over from evg_augment). F.interpolate(mode='bicubic', align_corners=None) on the
+// cropped frame = ATen upsample_bicubic2d: src = (dst + 0.5) * (in / out) - 0.5 (f32), taps at floor(src) - 1 .. + 2 with
+// clamped indices, cubic-convolution weights with A = -0.75, the x pass summed first and then the y pass, all in f32.
+__device__ __forceinline__ void cubic_coeffs(float t, float (&c)[4]) {
+  const float A = -0.75f;
+  float x = t + 1.0f;
+  c[0] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+  x = t;
+  c[1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+  x = 1.0f - t;
+  c[2] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
+  x = 2.0f - t;
+  c[3] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+}
+// params[b] = {x0, y0, w, h, hflip, tflip}
+__global__ __launch_bounds__(256) void frame_augment_kernel(const float *__restrict__ in, const int32_t *__restrict__ params,
+                                                            float *__restrict__ out, int C, int Hin, int Win, int Hout, int Wout) {
+  const int b = blockIdx.z, y = blockIdx.y;
+  const int32_t *pr = params + (int64_t)b * 6;
+  const int x0 = pr[0], y0 = pr[1], w = pr[2], h = pr[3], hflip = pr[4], tflip = pr[5];
+  const float sy = (float)h / (float)Hout, sx = (float)w / (float)Wout;
+  const float ry = sy * ((float)y + 0.5f) - 0.5f;
+  const float fy = floorf(ry);
+  const int iy = (int)fy;
+  float cy[4];
+  cubic_coeffs(ry - fy, cy);
+  const float sgn = tflip ? -1.0f : 1.0f;
+  for (int x = blockIdx.x * 256 + threadIdx.x; x < Wout; x += gridDim.x * 256) {
+    const int xr = hflip ? Wout - 1 - x : x;          // the flip acts on the resized frame
+    const float rx = sx * ((float)xr + 0.5f) - 0.5f;
+    const float fx = floorf(rx);
+    const int ix = (int)fx;
+    float cx[4];
+    cubic_coeffs(rx - fx, cx);
+    int xs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int xi = ix - 1 + i;
+      xs[i] = x0 + (xi < 0 ? 0 : (xi > w - 1 ? w - 1 : xi));
+    }
+    for (int c = 0; c < C; ++c) {
+      const float *src = in + ((int64_t)b * C + c) * Hin * Win;
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int yj = iy - 1 + j;
+        const float *row = src + (int64_t)(y0 + (yj < 0 ? 0 : (yj > h - 1 ? h - 1 : yj))) * Win;
+        const float rv = row[xs[0]] * cx[0] + row[xs[1]] * cx[1] + row[xs[2]] * cx[2] + row[xs[3]] * cx[3];
+        acc += rv * cy[j];
+      }
+      out[(((int64_t)b * C + c) * Hout + y) * Wout + x] = sgn * acc;
+    }
+  }
+}
+
+extern "C" int evp_frame_augment_f32(const float *in, const int32_t *params, float *out, int B, int C, int Hin, int Win, int Hout,
+                                     int Wout, void *stream) {
+  EVP_CHECK_ARG(in && params && out, EVP_EINVAL, "evp_frame_augment_f32: null pointer");
+  EVP_CHECK_ARG(B > 0 && C > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && B <= 65535 && Hout <= 65535, EVP_ESHAPE,
+                "evp_frame_augment_f32: bad shape (B=%d C=%d %dx%d -> %dx%d)", B, C, Hin, Win, Hout, Wout);
+  const dim3 grid((unsigned)((Wout + 255) / 256), (unsigned)Hout, (unsigned)B);
+  hipLaunchKernelGGL(frame_augment_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, params, out, C, Hin, Win, Hout, Wout);
+  EVP_CHECK_LAUNCH("evp_frame_augment_f32");
+  return EVP_OK;
+}

@@ -72,3 +72,26 @@ def evg_augment_batch(voxels, params, size, negate=None, out=None):
         negate = C in (5, 6)
     call("evp_view_augment_f32", ptr(voxels), ptr(params), ptr(out), B, C, H, W, Ho, Wo, int(bool(negate)), stream_ptr())
     return out
+
+
+def frame_augment_batch(frames, params, size, out=None):
+    """Difference-map targets of the batch (reference view_augment.py:79-89 `frame_augment`): frames float32 [B,C,H,W] on the
+    GPU, params int32 [B,6] -- THE SAME rows that went to evg_augment_batch (the reference re-seeds numpy with the sample's
+    seed, so the crop box and the flip coin repeat; column 5 is evg_augment's time-flip flag, which negates the frame) ->
+    float32 [B,C,size[0],size[1]], bicubic (ATen upsample_bicubic2d, align_corners=False)."""
+    _lib.require_device()
+    if not frames.is_cuda or frames.dtype != torch.float32 or not frames.is_contiguous():
+        raise _lib.EvpError("frame_augment_batch: frames must be a contiguous float32 tensor in device memory")
+    B, C, H, W = frames.shape
+    if not torch.is_tensor(params):
+        p = np.ascontiguousarray(params, dtype=np.int32).reshape(B, 6)
+        if ((p[:, 0] < 0) | (p[:, 1] < 0) | (p[:, 2] < 1) | (p[:, 3] < 1) | (p[:, 0] + p[:, 2] > W) | (p[:, 1] + p[:, 3] > H)).any():
+            raise ValueError("frame_augment_batch: crop box outside the frame")
+        params = torch.from_numpy(p).to(frames.device, non_blocking=True)
+    if params.dtype != torch.int32 or tuple(params.shape) != (B, 6) or not params.is_contiguous():
+        raise ValueError("frame_augment_batch: params must be int32 [B,6]")
+    Ho, Wo = int(size[0]), int(size[1])
+    if out is None:
+        out = torch.empty(B, C, Ho, Wo, dtype=torch.float32, device=frames.device)
+    call("evp_frame_augment_f32", ptr(frames), ptr(params), ptr(out), B, C, H, W, Ho, Wo, stream_ptr())
+    return out

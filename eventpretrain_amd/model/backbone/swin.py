@@ -129,8 +129,23 @@ class SwinTransformer(nn.Module):
         eps = self.norm_layer.eps
         dev = x.device
         if mask:
+            # The window plan is host work and depends on the visibility pattern of sample 0 (swin.py:151). With the random
+            # strategy the noise is therefore drawn on the HOST (or taken from a CPU tensor the caller passes): the pattern
+            # is known before anything is launched and the step has no device->host read-back; the device gets the same
+            # noise by an asynchronous copy and computes the ids with the usual kernel. Device-resident noise (explicit
+            # CUDA tensor, density strategies) keeps the one read-back of the 49-float mask row.
+            vis_cells = None
+            if noise is None and self.args.masking_strategy == "random":
+                noise = torch.rand(x.shape[0], self.num_patches)
+            if noise is not None and not noise.is_cuda:
+                n0 = noise[0].detach().float().numpy()
+                keep = int(self.num_patches * (1 - self.mask_ratio))
+                vis_cells = np.zeros(self.num_patches, dtype=bool)
+                vis_cells[np.argsort(n0, kind="stable")[:keep]] = True      # same order as the kernel: value, then index
+                noise = noise.to(dev, non_blocking=True)
             ids_keep, mask_t, ids_restore = self.random_masking(x, noise)
-            vis_cells = mask_t[0].detach().cpu().numpy() == 0          # the one host read-back of the step
+            if vis_cells is None:
+                vis_cells = mask_t[0].detach().cpu().numpy() == 0      # the one host read-back of the step
             plan = self._pattern_plan(vis_cells, dev)
             outs, attn = self._run_stages(x, plan, True)
             emb_stage4 = outs[-1][0]

@@ -394,6 +394,12 @@ int evp_swin_group_windows(const int32_t *counts, int n_windows, int cap, int32_
  * decisions are the caller's: a box with 0 <= x0, x0 + w <= Win, 0 <= y0, y0 + h <= Hin); out float32 [B,C,Hout,Wout]. */
 int evp_view_augment_f32(const float *in, const int32_t *params, float *out, int B, int C, int Hin, int Win, int Hout,
                          int Wout, int negate_on_time_flip, void *stream);
+/* Difference-map target of the same sample (reference dataset/augmentation/view_augment.py:79-89 `frame_augment`: view_crop
+ * -> view_resize(mode='bicubic') -> view_horizontal_flip -> negate when evg_augment time-flipped): same params rows as
+ * evp_view_augment_f32 (the reference re-seeds numpy with the same seed, so crop box and flip coin are the voxel grid's;
+ * params[5] carries evg_augment's time-flip flag). Bicubic = ATen upsample_bicubic2d, align_corners = False, A = -0.75. */
+int evp_frame_augment_f32(const float *in, const int32_t *params, float *out, int B, int C, int Hin, int Win, int Hout, int Wout,
+                          void *stream);
 
 /* ------------------------------------------------------------------------------------------------ K23 token mean pool
  * Classification fine-tuning head (model/finetune_cls/ft_cls_hub_model.py:136): out[b,:] = mean_n x[b,n,:] for float32

@@ -101,3 +101,19 @@ def events_reshape(events, sensor_w, sensor_h, input_w, input_h):
     out[:, 0] *= (input_w / sensor_w)
     out[:, 1] *= (input_h / sensor_h)
     return out
+
+
+def frame_transform(frame, params, out_hw):
+    """frame float32 [C,H,W] -> [C,Ho,Wo] as view_augment.py:79-89 `frame_augment` transforms it given the decisions
+    (x0, y0, w, h, hflip, tflip): crop box, F.interpolate(mode='bicubic') -- the very ATen op the reference calls, on the CPU --,
+    horizontal flip, negation when the voxel grid was time-flipped."""
+    import torch
+    import torch.nn.functional as F
+    x0, y0, w, h, hflip, tflip = params
+    t = torch.from_numpy(np.ascontiguousarray(frame[:, y0:y0 + h, x0:x0 + w], dtype=np.float32)).unsqueeze(0)
+    t = F.interpolate(t, (int(out_hw[0]), int(out_hw[1])), None, "bicubic", None).squeeze(0)
+    if hflip:
+        t = torch.flip(t, dims=[2])
+    if tflip:
+        t = -t
+    return t.numpy()

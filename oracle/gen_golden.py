@@ -547,6 +547,31 @@ def gen_augment():
     save("evg_augment", **out)
 
 
+def gen_frameaug():
+    """frame_augment of the reference itself (view_augment.py:79-89) under np.random.seed(seed), with the time-flip flag its
+    evg_augment returns for the same seed (as pr_n_imagenet_dataset.py calls the pair): sensor-shaped and input-shaped frames."""
+    _ref()
+    from dataset.augmentation.view_augment import evg_augment, frame_augment
+    out = {}
+    cases = [("a", 31, (1, 224, 224), 224), ("b", 32, (1, 120, 160), 224), ("c", 33, (1, 64, 64), 64), ("d", 34, (3, 96, 128), 64),
+             ("e", 35, (1, 260, 346), 224)]
+    for tag, seed, shp, S in cases:
+        a = make_args(crop_min=0.8, input_size=S)
+        a.num_bins = 5
+        f = det_normalish(f"aug.frame.{tag}", shp)
+        _, tflag = evg_augment(a, det_normalish(f"aug.framevox.{tag}", (5,) + shp[1:]), size=(S, S), seed=seed)
+        res = frame_augment(a, f.clone(), seed=seed, time_flip_flag=tflag).contiguous()
+        out[f"{tag}_seed"], out[f"{tag}_shape"], out[f"{tag}_size"] = np.array(seed), np.array(shp), np.array(S)
+        out[f"{tag}_tflip"] = np.array(int(tflag))
+        if res.numel() <= 30000:
+            out[f"{tag}_out"] = res
+        else:
+            out[f"{tag}_checksums"] = checksums(res)
+            out[f"{tag}_sample"] = res.flatten()[::7].clone()
+    out["tags"] = np.array(json.dumps([c[0] for c in cases]))
+    save("frame_augment", **out)
+
+
 def gen_evaug():
     """events_augment -> events_reshape -> events_to_voxel_grid of the reference itself (events_augment.py:80-86, :22-26,
     pr_n_imagenet_dataset.py:84-87) on seeded sensor-shaped clips; the fixture keeps the clip seeds, the augmented event
@@ -802,7 +827,7 @@ def gen_swin_base():
 
 GENS = dict(voxel=gen_voxel, pos=gen_pos, mask=gen_mask, tiny=lambda: gen_composed("tiny"), small=gen_small,
             base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall, swin=gen_swin, swincon=gen_swincon, augment=gen_augment, evaug=gen_evaug, ftcls=gen_ftcls,
-            density=gen_density, autocast=gen_autocast, conbase=gen_con_base, swinbase=gen_swin_base)
+            frameaug=gen_frameaug, density=gen_density, autocast=gen_autocast, conbase=gen_con_base, swinbase=gen_swin_base)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

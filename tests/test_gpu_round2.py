@@ -368,3 +368,62 @@ def test_stage_checkpoint_with_old_norm_keys_reproduces_con_fixture(tmp_path):
     ops.set_compute_dtype(torch.float32)
     loss = m(x, clip)[0]
     assert abs(loss.item() - float(d["loss"])) <= F32_LOSS_RTOL * abs(float(d["loss"]))
+
+
+# ------------------------------------------------------------------------------------------------------- Swin: host-side noise
+def test_swin_host_noise_equals_device_noise():
+    """Mask noise given as a CPU tensor: the window plan is made from it on the host (no device->host read-back), the device
+    receives the same noise -- loss, mask and ids equal those of the device-noise path."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
+    from eventpretrain_amd.testing import det_fill_module_, det_uniform, make_args
+    d = load_golden("rec_swin_tiny")
+    cfg = jl(d["cfg"])
+    a = make_args(model_size="tiny", pr_phase="rec", backbone_type="swin", device="cuda")
+    m = hub.pretrain_hub_model_swin_tiny_patch16(a, emb_frames_dim=512, queue_length=1024, T=0.07)
+    det_fill_module_(m)
+    m = m.cuda().train()
+    x, y, noise = rec_inputs("swin", cfg)
+    ops.set_compute_dtype(torch.float32)
+    with torch.no_grad():
+        o_dev = m(x.cuda(), y.cuda(), is_rec=True, noise=noise.cuda())
+        o_host = m(x.cuda(), y.cuda(), is_rec=True, noise=noise)
+    assert o_dev[0].item() == o_host[0].item()
+    assert torch.equal(o_dev[11], o_host[11]) and torch.equal(o_dev[12], o_host[12])
+    assert abs(o_host[0].item() - float(d["loss"])) <= F32_LOSS_RTOL * abs(float(d["loss"]))
+    # default draw (random strategy): host noise, runs and differs from call to call
+    with torch.no_grad():
+        l1, l2 = m(x.cuda(), y.cuda(), is_rec=True)[0].item(), m(x.cuda(), y.cuda(), is_rec=True)[0].item()
+    assert math.isfinite(l1) and math.isfinite(l2) and l1 != l2
+
+
+# ------------------------------------------------------------------------------------------------------- frame_augment
+def test_frame_augment_kernel_vs_reference():
+    """evp_frame_augment_f32 (crop -> bicubic -> h-flip -> negate on time flip) against the reference's own frame_augment
+    outputs with the decisions drawn from RandomState(seed) in the reference's order: crop / flip placement exact, the bicubic
+    values within 1e-5 (f32 cubic-convolution sums in another order than ATen's), and against the oracle on random boxes."""
+    from eventpretrain_amd.dataset.augmentation.view_augment import draw_evg_params, frame_augment_batch
+    from eventpretrain_amd.testing import det_normalish
+    from oracle import augment_oracle as ao
+    d = load_golden("frame_augment")
+    for tag in jl(d["tags"]):
+        shp, S, seed = tuple(int(v) for v in d[f"{tag}_shape"]), int(d[f"{tag}_size"]), int(d[f"{tag}_seed"])
+        f = det_normalish(f"aug.frame.{tag}", shp)
+        prm = draw_evg_params(np.random.RandomState(seed), shp[1], shp[2], 0.8)
+        assert prm[5] == int(d[f"{tag}_tflip"])
+        out = frame_augment_batch(f.unsqueeze(0).cuda(), np.array([prm]), (S, S)).cpu().numpy()[0]
+        if f"{tag}_out" in d.files:
+            assert np.abs(out - d[f"{tag}_out"]).max() <= 1e-5, tag
+        else:
+            assert np.abs(out.reshape(-1)[::7] - d[f"{tag}_sample"]).max() <= 1e-5, tag
+    rng = np.random.default_rng(4)
+    B, C, H, W = 8, 1, 120, 160
+    x = torch.from_numpy(rng.standard_normal((B, C, H, W)).astype(np.float32))
+    prm = np.zeros((B, 6), dtype=np.int32)
+    for i in range(B):
+        w, h = int(rng.integers(2, W + 1)), int(rng.integers(2, H + 1))
+        prm[i] = (int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1)), w, h, i & 1, (i >> 1) & 1)
+    for size in ((224, 224), (48, 80)):
+        out = frame_augment_batch(x.cuda(), prm, size).cpu().numpy()
+        for i in range(B):
+            assert np.abs(out[i] - ao.frame_transform(x[i].numpy(), tuple(prm[i]), size)).max() <= 2e-5, (size, i)

@@ -493,3 +493,22 @@ def test_autocast_fixture_is_bf16_class():
     for tag in ("tiny", "small", "base"):
         f = float(load_golden(f"rec_{tag}")["loss"])
         assert abs(float(a[f"{tag}_loss"]) - f) / f <= 1e-2, tag
+
+
+def test_frame_augment_matches_reference():
+    """Target-side view augmentation (view_augment.py:79-89): the oracle's decisions (same legacy stream as evg_augment) and
+    its crop / bicubic / flip / negate transform against the reference's own frame_augment under np.random.seed (bit-exact:
+    same ATen bicubic op on the CPU)."""
+    from oracle import augment_oracle as ao
+    from eventpretrain_amd.testing import det_normalish
+    d = load_golden("frame_augment")
+    for tag in jl(d["tags"]):
+        shp, S, seed = tuple(int(v) for v in d[f"{tag}_shape"]), int(d[f"{tag}_size"]), int(d[f"{tag}_seed"])
+        f = det_normalish(f"aug.frame.{tag}", shp).numpy()
+        prm = ao.draw_evg_params(np.random.RandomState(seed), shp[1], shp[2], 0.8)
+        assert prm[5] == int(d[f"{tag}_tflip"])
+        out = ao.frame_transform(f, prm, (S, S))
+        if f"{tag}_out" in d.files:
+            assert np.array_equal(out, d[f"{tag}_out"]), tag
+        else:
+            assert np.array_equal(out.reshape(-1)[::7], d[f"{tag}_sample"]), tag
