@@ -1465,11 +1465,14 @@ __device__ __forceinline__ void gemm_g4_tn_body(const GemmParams &p, const int t
       const bf16x2 ones = __builtin_bit_cast(bf16x2, 0x3F803F80u);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        // (pairs taken with shufflevector from the 8-element fragment: bit-casting single dwords made hipcc 7.2 feed the
+        // same dword to several dot instructions -- the ring body above hit the same miscompile)
+        const bf16x8 f = __builtin_bit_cast(bf16x8, u32x4{fa[i][0][0], fa[i][0][1], fa[i][1][0], fa[i][1][1]});
         float c = csum[i];
-        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, fa[i][0][0]), ones, c, false);
-        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, fa[i][0][1]), ones, c, false);
-        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, fa[i][1][0]), ones, c, false);
-        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, fa[i][1][1]), ones, c, false);
+        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), ones, c, false);
+        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), ones, c, false);
+        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), ones, c, false);
+        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), ones, c, false);
         csum[i] = c;
       }
     }
