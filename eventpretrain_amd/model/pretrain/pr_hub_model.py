@@ -78,14 +78,40 @@ class PrHubModel(nn.Module):
         m = None if self.mask_ratio == 0 else mask.contiguous()
         return ops.RecLossFn.apply(reconstruct_pred, sub_frame, m, self.patch_size, self.norm_pix_loss)
 
+    # ------------------------------------------------------------------------------------------------ queue under DDP
+    def queue_policy(self):
+        """How the MoCo queue is kept across data-parallel ranks (args.queue_policy):
+          "all_gather" (default when args.distributed): every rank enqueues the keys of ALL ranks (contrastive-key all-gather
+                        over xGMI), so the queues stay identical without any broadcast and hold world x B new keys per step;
+          "rank0_broadcast": what the reference actually does -- DistributedDataParallel re-broadcasts module buffers from
+                        rank 0 at every forward (main_pretrain.py:319, broadcast_buffers default), so every rank's queue,
+                        pointer and BatchNorm statistics are overwritten by rank 0's before use and only rank 0's keys survive;
+          "local": no communication (single process, or deliberately independent queues)."""
+        pol = getattr(self.args, "queue_policy", None)
+        if pol is None:
+            pol = "all_gather" if (self.args.distributed and _dist_ready()) else "local"
+        if pol not in ("all_gather", "rank0_broadcast", "local"):
+            raise ValueError("queue_policy must be all_gather, rank0_broadcast or local")
+        return pol if _dist_ready() else "local"
+
+    @torch.no_grad()
+    def _sync_buffers_from_rank0(self):
+        """The reference-faithful mode's per-forward buffer broadcast (collective C2 in SURVEY.md 2.2)."""
+        import torch.distributed as dist
+        for b in self.buffers():
+            dist.broadcast(b, src=0)
+
     @torch.no_grad()
     def _dequeue_and_enqueue(self, keys):
         """queue[:, :, ptr:ptr+B] = keys^T with all three dims reversed ((B,L,C) -> (C,L,B)), pointer advances
         modulo the queue length (pr_hub_model.py:112-122). The pointer stays in its device buffer: the kernel reads it
-        and a one-thread kernel advances it, so the step has no host read-back (and can be captured in a HIP graph)."""
+        and a one-thread kernel advances it, so the step has no host read-back (and can be captured in a HIP graph).
+        Under the "all_gather" policy `keys` are first gathered from every rank (rank order), so B is world x local B."""
+        if self.queue_policy() == "all_gather":
+            keys = concat_all_gather(keys)
         B = keys.shape[0]
         if self.queue_length % B:
-            raise AssertionError("queue_length must be a multiple of the batch size")
+            raise AssertionError("queue_length must be a multiple of the (gathered) batch size")
         ops.enqueue_keys_dev(self.queue, keys, self.queue_ptr)
 
     def contrastive_loss_queue(self, emb_h, clip_emb):
@@ -112,6 +138,8 @@ class PrHubModel(nn.Module):
             reconstruct_loss = self.reconstruct_loss(reconstruct_pred, supp_data, mask)
             return reconstruct_loss, emb_l1, emb_l2, emb_lh, reconstruct_pred, mask, ids_restore
 
+        if self.queue_policy() == "rank0_broadcast":
+            self._sync_buffers_from_rank0()
         if swin_:
             _, _, _, _, emb_h, attn = self.backbone(events_voxel_grid)
         else:
@@ -133,6 +161,11 @@ class PrHubModel(nn.Module):
         else:
             contrastive_loss = self.contrastive_loss(emb_h_proj, clip_emb_proj)
         return contrastive_loss, emb_h_org, emb_h_proj, clip_emb_org, clip_emb_proj, attn
+
+
+def _dist_ready():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 @torch.no_grad()

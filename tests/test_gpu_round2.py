@@ -427,3 +427,49 @@ def test_frame_augment_kernel_vs_reference():
         out = frame_augment_batch(x.cuda(), prm, size).cpu().numpy()
         for i in range(B):
             assert np.abs(out[i] - ao.frame_transform(x[i].numpy(), tuple(prm[i]), size)).max() <= 2e-5, (size, i)
+
+
+# ------------------------------------------------------------------------------------------------------- multi-GPU form, con phase
+def test_overlapped_data_parallel_con_step_matches_single_rank_graph():
+    """The N-rank form of the graphed step (forward+backward graph -> chunked weight gradients interleaved with RCCL all-reduces
+    -> AdamW per reduced buffer) for the CONTRASTIVE stage (MoCo heads with BatchNorm, queue InfoNCE + enqueue inside the graph)
+    on a one-rank RCCL group: same losses, queue and pointer as the single-graph form."""
+    import os
+    import torch.distributed as dist
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.engine import GraphedStep
+    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
+    from eventpretrain_amd.optim import FusedAdamW
+    from eventpretrain_amd.parallel import BucketedGradReducer
+    from eventpretrain_amd.testing import det_fill_module_, det_normalish, make_args
+    from eventpretrain_amd.utils import lr_decay as lrd
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29542")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    results = []
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        x = (det_normalish("dpc.voxels", (32, 5, 224, 224)) * 0.5).cuda()
+        clip = det_normalish("dpc.clip", (32, 197, 512)).cuda()
+        for multi in (False, True):
+            a = make_args(model_size="small", pr_phase="con", use_queue=True, mask_ratio=0.0, device="cuda")
+            m = hub.pretrain_hub_model_small_patch16(a, emb_frames_dim=512, queue_length=64, T=0.07)
+            det_fill_module_(m)
+            m = m.cuda().train()
+            opt = FusedAdamW(lrd.param_groups_lrd(a, m, a.weight_decay, layer_decay=1), lr=1e-4, betas=(0.9, 0.95))
+            red = BucketedGradReducer.for_module(m) if multi else None
+            ex = GraphedStep(m, opt, lambda mm, xx, cc, noise: mm(xx, cc), [x, clip], noise_shape=None, reducer=red, warmup=2, wgrad_chunks=3)
+            assert ex.note.startswith("hip-graph"), ex.note
+            losses = [ex.step().item() for _ in range(3)]
+            torch.cuda.synchronize()
+            results.append((losses, m.queue.detach().clone(), int(m.queue_ptr)))
+    finally:
+        ops.set_compute_dtype(torch.float32)
+        if created:
+            dist.destroy_process_group()
+    (l0, q0, p0), (l1, q1, p1) = results
+    assert l0[0] == pytest.approx(l1[0], rel=1e-6) and l0 == pytest.approx(l1, rel=2e-4), (l0, l1)
+    assert p0 == p1 == (3 * 32) % 64
+    assert (q0 - q1).norm().item() <= 2e-3 * q0.norm().item()
