@@ -38,6 +38,11 @@ class ConvBlock(nn.Module):
         """Reference layout: x (B, C, H, W); mask (B, 1, H, W) keep factors (1 = keep) or None."""
         B, C_, H, W = x.shape
         t = x.permute(0, 2, 3, 1).reshape(B, H * W, C_).contiguous()
+        coarse = None
         if mask is not None:
-            raise NotImplementedError("pass the coarse mask to forward_tokens(); a dense keep map is not taken here")
-        return self.forward_tokens(t, H, W).reshape(B, H, W, C_).permute(0, 3, 1, 2)
+            # reference conv_block.py:41-44 multiplies conv1's output by this map; the kernel's mask argument is "1 = removed"
+            # at mask_scale x mask_scale cells, so a dense keep map k enters as 1 - k at scale 1 (exact for 0 / 1 maps)
+            if tuple(mask.shape) != (B, 1, H, W):
+                raise ValueError("ConvBlock.forward: mask must be (B, 1, H, W)")
+            coarse = (1.0 - mask.float()).reshape(B, H * W).contiguous()
+        return self.forward_tokens(t, H, W, coarse, 1).reshape(B, H, W, C_).permute(0, 3, 1, 2)

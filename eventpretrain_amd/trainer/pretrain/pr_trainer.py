@@ -76,6 +76,19 @@ def pr_con_one_epoch(args, model, data_loader, optimizer, epoch, loss_scaler, lo
                  lambda x, y: model(x, y), vis_hook, step_executor)
 
 
+def pr_con_n_one_epoch(args, model, preprocess, clip_model, data_loader, optimizer, epoch, loss_scaler, log_writer=None,
+                       vis_hook=None):
+    """Contrastive epoch with the CLIP image branch evaluated on the fly (reference trainer/pretrain/pr_trainer.py:158-223):
+    batches carry the pre-processed RGB image instead of stored CLIP tokens, `clip_model.encode_image(image)` supplies the
+    (B, 197, 512) token tensor. The CLIP encoder itself is the caller's frozen module (out of scope here: SURVEY.md 8c takes the
+    CLIP branch as an input tensor); `preprocess` is accepted for signature compatibility and unused, as in the reference."""
+    def forward(x, image):
+        with torch.no_grad():
+            clip_emb = clip_model.encode_image(image).to(args.device, non_blocking=True).float()
+        return model(x, clip_emb)
+    return _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, "contrastive_loss", forward, vis_hook)
+
+
 def pr_rec_and_con_one_epoch(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer=None, vis_hook=None):
     """Joint epoch (reference trainer/pretrain/pr_trainer.py:225-304): one masked-modeling forward and one contrastive
     forward per batch, the two losses summed before the single backward."""

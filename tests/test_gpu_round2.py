@@ -473,3 +473,60 @@ def test_overlapped_data_parallel_con_step_matches_single_rank_graph():
     assert l0[0] == pytest.approx(l1[0], rel=1e-6) and l0 == pytest.approx(l1, rel=2e-4), (l0, l1)
     assert p0 == p1 == (3 * 32) % 64
     assert (q0 - q1).norm().item() <= 2e-3 * q0.norm().item()
+
+
+# ------------------------------------------------------------------------------------------------------- ConvBlock drop-in call
+def test_conv_block_forward_with_dense_keep_map():
+    """ConvBlock.forward(x, mask) with the reference's (B,1,H,W) keep map (conv_block.py:41-51) against the oracle."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.model.sub_module.conv_block import ConvBlock
+    from eventpretrain_amd.testing import det_fill_module_, det_normalish
+    from oracle import model_oracle as mo
+    blk = ConvBlock(input_size=64, kernel_size=5, mlp_ratio=4.)
+    det_fill_module_(blk)
+    blk = blk.cuda()
+    x = det_normalish("cb.x", (2, 64, 28, 28))
+    keep = (det_normalish("cb.keep", (2, 1, 7, 7)) > 0).float().repeat_interleave(4, 2).repeat_interleave(4, 3)
+    ops.set_compute_dtype(torch.float32)
+    sd = {"b." + k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    for m in (None, keep):
+        got = blk(x.cuda(), None if m is None else m.cuda()).cpu()
+        ref = mo.conv_block(sd, "b.", x, m)
+        assert torch.allclose(got, ref, atol=2e-5, rtol=1e-5), (m is None, (got - ref).abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------------- con epoch loops
+def test_con_epoch_loops_run_and_agree():
+    """pr_con_one_epoch (stored CLIP tokens) and pr_con_n_one_epoch (tokens from clip_model.encode_image on the fly) on the same
+    two batches from the same start: same per-epoch statistics; the queue pointer has advanced by 2 x B."""
+    from types import SimpleNamespace
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
+    from eventpretrain_amd.optim import FusedAdamW
+    from eventpretrain_amd.testing import det_fill_module_, det_normalish, make_args
+    from eventpretrain_amd.trainer.pretrain.pr_trainer import pr_con_n_one_epoch, pr_con_one_epoch
+    from eventpretrain_amd.utils import lr_decay as lrd
+    from eventpretrain_amd.utils.misc import NativeScalerWithGradNormCount
+    ops.set_compute_dtype(torch.float32)
+    xs = [det_normalish(f"ce.vox.{i}", (2, 5, 224, 224)) * 0.5 for i in range(2)]
+    clips = [det_normalish(f"ce.clip.{i}", (2, 197, 512)) for i in range(2)]
+    images = [torch.full((2, 3, 8, 8), float(i)) for i in range(2)]
+    clip_model = SimpleNamespace(encode_image=lambda im: clips[int(im[0, 0, 0, 0].item())].to(im.device))
+    stats = []
+    for variant in ("con", "con-n"):
+        a = make_args(model_size="small", pr_phase=variant, use_queue=True, mask_ratio=0.0, device="cuda", lr=1e-4, min_lr=1e-4,
+                      warmup_epochs=0, epochs=1, accum_iter=1, print_freq=100, backward=True, visualize=False, test_experiment=False)
+        m = hub.pretrain_hub_model_small_patch16(a, emb_frames_dim=512, queue_length=8, T=0.07)
+        det_fill_module_(m)
+        m = m.cuda().train()
+        opt = FusedAdamW(lrd.param_groups_lrd(a, m, 0.05, layer_decay=1), lr=1e-4, betas=(0.9, 0.95))
+        if variant == "con":
+            loader = [dict(events_voxel_grid=xs[i], clip_emb=clips[i], image_name=["n"] * 2) for i in range(2)]
+            st = pr_con_one_epoch(a, m, loader, opt, 0, NativeScalerWithGradNormCount())
+        else:
+            loader = [dict(events_voxel_grid=xs[i], image=images[i], image_name=["n"] * 2) for i in range(2)]
+            st = pr_con_n_one_epoch(a, m, None, clip_model, loader, opt, 0, NativeScalerWithGradNormCount())
+        assert int(m.queue_ptr) == 4
+        stats.append(st)
+    assert stats[0]["contrastive_loss"] == pytest.approx(stats[1]["contrastive_loss"], rel=1e-6)
+    assert math.isfinite(stats[0]["contrastive_loss"])
