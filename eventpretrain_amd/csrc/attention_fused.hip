@@ -12,6 +12,8 @@
 // Replaces model/sub_module/vit_block.py:134-140 (scores, softmax, probs @ v) and its autograd backward.
 #include "evp_common.h"
 
+#include <stdlib.h>
+
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) short i16x8;
@@ -23,9 +25,16 @@ static unsigned long long *g_attn_dbg = nullptr;   // measurement aid, see evp_a
 namespace {
 
 // ---- LDS image of a [rows][DH] bf16 array: 16-byte chunks, XOR-swizzled for 128-byte rows ---------------------------
+// d_h = 32 (64-byte rows, four rows per 256-byte bank row): unswizzled, every ds_read_b128 fragment read and every transposed
+// read met a second row on the same banks -- rocprofv3 counted 42 % of the LDS cycles of the decoder's backward as bank
+// conflicts (profiles/r02_pmc_sq_kernels.json). The chunk index is XORed with g((row >> 2) & 3), g = {0, 2, 3, 1}: the four
+// 16-lane groups of a ds_read_b128 (rows 0-3 / 12-15 at chunk c with rows 4-11 at chunk c+1, and so on) and the 8 rows x 32 B
+// of a ds_read_b64_tr_b16 half-wave then fall on 16 distinct 16-byte slots.
 template <int DH> __device__ __forceinline__ int img_off(int row, int chunk) {
   if (DH == 64) return row * 128 + ((chunk ^ (row & 7)) << 4);
-  return row * 64 + (chunk << 4);
+  const int x = (row >> 2) & 3;
+  const int g = (((x >> 1) ^ x) & 1) << 1 | (x >> 1);
+  return row * 64 + ((chunk ^ g) << 4);
 }
 // fragment with the 16 rows [rb, rb+16) on the lanes and 8 consecutive d (k-step ks of 32) per lane: ds_read_b128
 template <int DH> __device__ __forceinline__ bf16x8 frag_rows(const char *img, int rb, int ks, int lane) {
@@ -76,14 +85,14 @@ __device__ __forceinline__ void stage_head(const bf16_t *src, int64_t tok, int N
 // Batched form: every thread first ISSUES all its 16-byte loads of all NA arrays (NA * PER independent loads in
 // flight), then parks them in LDS. The loop form above costs one exposed HBM round trip per iteration and array --
 // about 12 (forward) / 25 (backward) serial round trips per workgroup before the first MFMA.
-template <int DH, int NP, int NA> struct HeadStage {
-  static constexpr int CPR = DH / 8, TOTAL = NP * CPR, PER = (TOTAL + 255) / 256;
+template <int DH, int NP, int NA, int NTHR = 256> struct HeadStage {
+  static constexpr int CPR = DH / 8, TOTAL = NP * CPR, PER = (TOTAL + NTHR - 1) / NTHR;
   uint4 r[NA][PER];
   __device__ __forceinline__ void load(const bf16_t *const (&src)[NA], const int64_t (&tok)[NA], int N, int tid) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int c = tid + i * 256, row = c / CPR, ch = c % CPR;
-      const bool ok = (TOTAL % 256 == 0 || c < TOTAL) && row < N;
+      const int c = tid + i * NTHR, row = c / CPR, ch = c % CPR;
+      const bool ok = (TOTAL % NTHR == 0 || c < TOTAL) && row < N;
 #pragma unroll
       for (int a = 0; a < NA; ++a)
         r[a][i] = ok ? *reinterpret_cast<const uint4 *>(src[a] + (int64_t)row * tok[a] + ch * 8) : make_uint4(0, 0, 0, 0);
@@ -92,8 +101,8 @@ template <int DH, int NP, int NA> struct HeadStage {
   __device__ __forceinline__ void store(int a, char *img, int tid) const {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int c = tid + i * 256, row = c / CPR, ch = c % CPR;
-      if (TOTAL % 256 == 0 || c < TOTAL) *reinterpret_cast<uint4 *>(img + img_off<DH>(row, ch)) = r[a][i];
+      const int c = tid + i * NTHR, row = c / CPR, ch = c % CPR;
+      if (TOTAL % NTHR == 0 || c < TOTAL) *reinterpret_cast<uint4 *>(img + img_off<DH>(row, ch)) = r[a][i];
     }
   }
 };
@@ -110,8 +119,8 @@ template <int DH> __device__ __forceinline__ void head_of_block(int bid, int nbl
 
 // ---------------------------------------------------------------------------------------------------- forward
 // NT = number of 16-wide score tiles (NP = 16*NT rows in LDS, NT even)
-template <int DH, int NT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t *qkv, bf16_t *out, float *lse, bf16_t *probs, int N, int heads,
+template <int DH, int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16_t *qkv, bf16_t *out, float *lse, bf16_t *probs, int N, int heads,
                                                        float scale, int64_t ldp, unsigned long long *dbg) {
   unsigned long long t0 = 0, t1 = 0;
   if (dbg) t0 = __builtin_readcyclecounter();
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t *qkv, bf16_t
   const int64_t C = (int64_t)heads * DH, tok = 3 * C;
   const bf16_t *base = qkv + (int64_t)b * N * tok + (int64_t)h * DH;
   {
-    HeadStage<DH, NP, 3> st;
+    HeadStage<DH, NP, 3, 64 * NW> st;
     const bf16_t *const src[3] = {base, base + C, base + 2 * C};
     const int64_t toks[3] = {tok, tok, tok};
     st.load(src, toks, N, tid);
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t *qkv, bf16_t
   if (dbg) t1 = __builtin_readcyclecounter();
   const float c2 = scale * 1.44269504088896340736f;   // exp(x*scale) = exp2(x*c2)
 
-  for (int strip = wave; strip * 16 < N; strip += 4) {
+  for (int strip = wave; strip * 16 < N; strip += NW) {
     bf16x8 qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_rows<DH>(Qs, strip * 16, ks, lane);
@@ -201,14 +210,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t *qkv, bf16_t
   }
   if (dbg && (threadIdx.x & 63) == 0) {
     const unsigned long long t2 = __builtin_readcyclecounter();
-    dbg[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + 0] = t1 - t0;     // staging
-    dbg[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + 1] = t2 - t1;     // strips of this wave
+    if ((threadIdx.x >> 6) < 4) {
+      dbg[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + 0] = t1 - t0;     // staging
+      dbg[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + 1] = t2 - t1;     // strips of this wave
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------------- backward
-template <int DH, int NT>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse,
+template <int DH, int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse,
                                                        bf16_t *dqkv, int N, int heads, float scale) {
   constexpr int NP = 16 * NT, IMG = NP * DH * 2, KS = DH / 32, DT = DH / 16, CH = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -224,15 +235,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *qkv, const 
   {
     // Q, K, V, dO and O in one batch of loads; O is only needed for delta[q] = sum_d dO[q,d] * O[q,d], formed from the
     // staged registers (the DH/8 consecutive threads that share a row meet with shuffles)
-    using ST = HeadStage<DH, NP, 5>;
+    using ST = HeadStage<DH, NP, 5, 64 * NW>;
+    constexpr int NTHR = 64 * NW;
     ST st;
     const bf16_t *const src[5] = {base, base + C, base + 2 * C, go, oo};
     const int64_t toks[5] = {tok, tok, tok, C, C};
     st.load(src, toks, N, tid);
-    float lv[(NP + 255) / 256];
+    float lv[(NP + NTHR - 1) / NTHR];
 #pragma unroll
-    for (int i = 0; i < (NP + 255) / 256; ++i) {
-      const int r = tid + i * 256;
+    for (int i = 0; i < (NP + NTHR - 1) / NTHR; ++i) {
+      const int r = tid + i * NTHR;
       lv[i] = (r < N) ? lse[(int64_t)bh * N + r] : INFINITY;      // exp(-inf) = 0 on the padded queries
     }
     st.store(0, Qs, tid);
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *qkv, const 
     st.store(3, Gs, tid);
 #pragma unroll
     for (int i = 0; i < ST::PER; ++i) {
-      const int c = tid + i * 256, row = c / ST::CPR, ch = c % ST::CPR;
+      const int c = tid + i * NTHR, row = c / ST::CPR, ch = c % ST::CPR;
       const uint32_t aw[4] = {st.r[3][i].x, st.r[3][i].y, st.r[3][i].z, st.r[3][i].w};
       const uint32_t ow[4] = {st.r[4][i].x, st.r[4][i].y, st.r[4][i].z, st.r[4][i].w};
       float d = 0.f;
@@ -251,11 +263,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *qkv, const 
              __uint_as_float(aw[e] & 0xFFFF0000u) * __uint_as_float(ow[e] & 0xFFFF0000u);
 #pragma unroll
       for (int o = 1; o < ST::CPR; o <<= 1) d += __shfl_xor(d, o, 64);
-      if (ch == 0 && (ST::TOTAL % 256 == 0 || c < ST::TOTAL)) Ds[row] = d;
+      if (ch == 0 && (ST::TOTAL % NTHR == 0 || c < ST::TOTAL)) Ds[row] = d;
     }
 #pragma unroll
-    for (int i = 0; i < (NP + 255) / 256; ++i) {
-      const int r = tid + i * 256;
+    for (int i = 0; i < (NP + NTHR - 1) / NTHR; ++i) {
+      const int r = tid + i * NTHR;
       if (r < NP) Ls[r] = lv[i];
     }
   }
@@ -263,7 +275,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *qkv, const 
   const float c2 = scale * 1.44269504088896340736f, l2e = 1.44269504088896340736f;
 
   // ---- pass 1, query on the lane: dQ ----
-  for (int strip = wave; strip * 16 < N; strip += 4) {
+  for (int strip = wave; strip * 16 < N; strip += NW) {
     bf16x8 qf[KS], gf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -319,7 +331,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *qkv, const 
 
   // ---- pass 2, key on the lane: dK, dV ---- (strips dealt to the waves in the opposite order of pass 1: with 13 strips
   // the wave that took four in pass 1 takes three here)
-  for (int strip = 3 - wave; strip * 16 < N; strip += 4) {
+  for (int strip = NW - 1 - wave; strip * 16 < N; strip += NW) {
     bf16x8 kf[KS], vf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -375,12 +387,39 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t *qkv, const 
   }
 }
 
+// Waves per workgroup. Measured on MI355X (dec shape B=64, 16 heads, N=196, d_h=32; tools/attn_bench.py, one box): the
+// backward (two passes of dependent MFMA -> softmax algebra -> MFMA chains, latency-bound at two waves per SIMD) runs 62.9 us
+// with 4 waves and 47.2 us with 8; the forward 25.5 us with 4 and 32.2 us with 8 (its 13 strips split worse over 8 waves and
+// its staging phase is the larger share). Hence 4 forward / 8 backward; EVP_ATTN_FWD_WAVES / EVP_ATTN_BWD_WAVES override (4, 8;
+// backward also 16).
+static int g_attn_fwd_waves = 0, g_attn_bwd_waves = 0;
+static inline int env_waves(const char *name, int dflt) {
+  const char *e = getenv(name);
+  if (!e) return dflt;
+  const int v = atoi(e);
+  return (v == 4 || v == 8 || v == 16) ? v : dflt;
+}
+static inline int attn_fwd_waves() {
+  if (g_attn_fwd_waves == 0) { g_attn_fwd_waves = env_waves("EVP_ATTN_FWD_WAVES", 4); if (g_attn_fwd_waves == 16) g_attn_fwd_waves = 8; }
+  return g_attn_fwd_waves;
+}
+static inline int attn_bwd_waves() {
+  if (g_attn_bwd_waves == 0) g_attn_bwd_waves = env_waves("EVP_ATTN_BWD_WAVES", 8);
+  return g_attn_bwd_waves;
+}
+
 template <int DH, int NT>
 int launch_fwd(const bf16_t *qkv, bf16_t *out, float *lse, bf16_t *probs, int B, int N, int heads, float scale, int64_t ldp, hipStream_t s) {
   constexpr int smem = 3 * 16 * NT * DH * 2;
-  auto k = attn_fwd_kernel<DH, NT>;
-  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  hipLaunchKernelGGL(k, dim3(B * heads), dim3(256), smem, s, qkv, out, lse, probs, N, heads, scale, ldp, g_attn_dbg);
+  if (attn_fwd_waves() == 8) {
+    auto k = attn_fwd_kernel<DH, NT, 8>;
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(k, dim3(B * heads), dim3(512), smem, s, qkv, out, lse, probs, N, heads, scale, ldp, g_attn_dbg);
+  } else {
+    auto k = attn_fwd_kernel<DH, NT, 4>;
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(k, dim3(B * heads), dim3(256), smem, s, qkv, out, lse, probs, N, heads, scale, ldp, g_attn_dbg);
+  }
   EVP_CHECK_LAUNCH("evp_attention_fused_fwd");
   return EVP_OK;
 }
@@ -388,9 +427,14 @@ template <int DH, int NT>
 int launch_bwd(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse, bf16_t *dqkv, int B, int N, int heads, float scale,
                hipStream_t s) {
   constexpr int smem = 4 * 16 * NT * DH * 2 + 2 * 16 * NT * 4;
-  auto k = attn_bwd_kernel<DH, NT>;
-  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  hipLaunchKernelGGL(k, dim3(B * heads), dim3(256), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale);
+  auto go = [&](auto kfn, int nthr) {
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(kfn, dim3(B * heads), dim3(nthr), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale);
+  };
+  const int nw = attn_bwd_waves();
+  if (nw == 16) go(attn_bwd_kernel<DH, NT, 16>, 1024);
+  else if (nw == 8) go(attn_bwd_kernel<DH, NT, 8>, 512);
+  else go(attn_bwd_kernel<DH, NT, 4>, 256);
   EVP_CHECK_LAUNCH("evp_attention_fused_bwd");
   return EVP_OK;
 }
