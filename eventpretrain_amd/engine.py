@@ -30,9 +30,10 @@ class GraphedStep:
         dev = self.inputs[0].device
         self.gen = generator if generator is not None else torch.Generator(device=dev)
         self.noise = torch.empty(*noise_shape, device=dev) if noise_shape is not None else None
-        self.graph = self.graph2 = self.plan = None
+        self.graph = self.graph0 = self.graph2 = self.plan = None
         self.parts = False
         self.loss = None
+        self._tables_read = None       # event: the last replay's H2D nodes have read the pinned scalar tables
         self.note = "eager"
         self.multi = reducer is not None
         self.wgrad_chunks = int(wgrad_chunks)
@@ -110,12 +111,19 @@ class GraphedStep:
                     out = self.forward(self.model, *self.inputs, self.noise)
                     out[0].backward()
                     if not self.multi:
-                        self.opt.refresh()
+                        self.opt.refresh(scalars=False)
                         self.opt.launch()
                     self.loss = out[0].detach()
                     del out
             finally:
                 ops.hold_deferred_grads(False)
+            if not self.multi:
+                # the per-step scalar tables (lr, weight decay, bias corrections) travel in a graph of their own, replayed in
+                # FRONT of the step: the host may then prepare step N+1 as soon as step N has started (see step())
+                g0 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g0, stream=side, capture_error_mode="thread_local"):
+                    self.opt.upload_scalars()
+                self.graph0 = g0
             self.graph, self.note = g1, "hip-graph"
             if self.multi:
                 # chunked weight-gradient launches interleaved with their all-reduces (parallel.OverlappedPlan)
@@ -138,7 +146,7 @@ class GraphedStep:
                              "computes, AdamW per reduced buffer" % self.wgrad_chunks) if self.parts else \
                             ("hip-graph (fwd+bwd) + %d weight-gradient chunks overlapped with RCCL all-reduce + hip-graph (AdamW)" % self.wgrad_chunks)
         except Exception as e:               # keep training; say what happened
-            self.graph = self.graph2 = self.plan = None
+            self.graph = self.graph0 = self.graph2 = self.plan = None
             self.note = "eager (graph capture failed: %r)" % (e,)
             self.opt.zero_grad(set_to_none=True)
             ops.flush_deferred_grads()
@@ -165,13 +173,29 @@ class GraphedStep:
         if self.graph is None:
             return self.eager_step()
         self._draw_noise()
+        # The captured H2D nodes read the optimizer's pinned scalar tables when the REPLAY runs, not when it is queued: a host
+        # that is a step ahead would hand step N the learning rate / bias corrections of step N+1. Wait until the replay that
+        # read them last has passed that point. One GPU: the tables are read by graph0 at the START of a step, so the host
+        # still queues step N+1 while step N runs; N GPUs: by graph2, behind forward + backward.
+        if self._tables_read is not None:
+            self._tables_read.synchronize()
         self.opt.stage_scalars()
+        if self.graph0 is not None:
+            self.graph0.replay()
+            self._mark_tables_read()
         self.graph.replay()
         if self.plan is not None:
             if self.parts:
                 self.graph2.replay()         # this step's lr / bias-correction tables -> device
+                self._mark_tables_read()
                 self.plan.run()              # weight gradients, all-reduces and the update, part by part
             else:
                 self.plan.run()
                 self.graph2.replay()
+                self._mark_tables_read()
         return self.loss
+
+    def _mark_tables_read(self):
+        if self._tables_read is None:
+            self._tables_read = torch.cuda.Event()
+        self._tables_read.record()

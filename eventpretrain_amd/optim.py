@@ -84,11 +84,12 @@ class FusedAdamW(torch.optim.Optimizer):
         T["group_of"] = np.array([gi for gi, _ in act], dtype=np.int64)
         return T
 
-    def refresh(self, advance=True):
+    def refresh(self, advance=True, scalars=True):
         """Host side of a step: (re)build tables if the set of parameters with gradients changed, bump the step
         counter, stage gradient pointers / lr / weight decay / bias corrections into pinned host tables and enqueue
         their (tiny) H2D copies. Called inside a HIP-graph capture, the copies become graph nodes that re-read the
-        pinned tables at every replay; `stage_scalars()` then updates lr / bias corrections before each replay."""
+        pinned tables at every replay; `stage_scalars()` then updates lr / bias corrections before each replay.
+        `scalars=False`: pointer tables only (the scalar tables travel in a graph of their own, `upload_scalars`)."""
         from . import ops
         ops.flush_deferred_grads()      # normally already done by the end-of-backward callback
         act = self._active()
@@ -107,10 +108,20 @@ class FusedAdamW(torch.optim.Optimizer):
             ng[i] = g.data_ptr()
             sh = getattr(p, "_evp_lp", None)
             nl[i] = sh.data_ptr() if (sh is not None and getattr(p, "_evp_lp_version", -1) == p._version) else 0
-        self.stage_scalars(advance)
-        for k in ("grads", "lp", "wd", "lr", "hyper"):
+        if scalars:
+            self.stage_scalars(advance)
+        for k in ("grads", "lp") + (("wd", "lr", "hyper") if scalars else ()):
             T[k].copy_(T["h_" + k], non_blocking=True)
         return True
+
+    def upload_scalars(self):
+        """The H2D copies of the per-step scalar tables (lr, weight decay, bias corrections) on their own, for a step executor
+        that captures them as a separate graph in front of the step (`refresh(scalars=False)` then leaves them out)."""
+        T = self._tabs
+        if T is None:
+            raise _lib.EvpError("upload_scalars: no tables yet (run refresh() once)")
+        for k in ("wd", "lr", "hyper"):
+            T[k].copy_(T["h_" + k], non_blocking=True)
 
     def stage_scalars(self, advance=True):
         """Write this step's lr / weight decay / bias corrections into the pinned host tables (no device work)."""

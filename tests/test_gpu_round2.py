@@ -336,6 +336,39 @@ def test_captured_graph_survives_later_eager_steps_and_second_capture():
         ops.set_compute_dtype(torch.float32)
 
 
+def test_host_running_ahead_of_the_device_keeps_each_steps_own_lr():
+    """The graph's H2D nodes read the optimizer's pinned lr / bias-correction tables when a replay RUNS. With a different
+    learning rate every step, 12 steps queued back to back (host far ahead of the device) must end with bit-identical weights
+    to the same 12 steps with a device synchronisation after each."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.engine import GraphedStep
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        fwd = lambda mm, xx, yy, noise: mm(xx, yy, is_rec=True, noise=noise)
+        finals = []
+        for lockstep in (True, False):
+            a, m, opt, x, y = _tiny_setup()
+            ex = GraphedStep(m, opt, fwd, [x, y], noise_shape=(2, 16), generator=torch.Generator(device="cuda").manual_seed(3), warmup=2)
+            assert ex.note.startswith("hip-graph"), ex.note
+            torch.cuda.synchronize()
+            if not lockstep:                   # keep the device busy so that the host really is several replays ahead
+                big = torch.empty(64 << 20, device="cuda")
+                for _ in range(40):
+                    big.normal_()
+            for i in range(12):
+                for g in opt.param_groups:
+                    g["lr"] = 1e-3 * (1 + i) * g.get("lr_scale", 1.0)
+                ex.step()
+                if lockstep:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            finals.append([p.detach().clone() for p in m.parameters()])
+        for p0, p1 in zip(*finals):
+            assert torch.equal(p0, p1)
+    finally:
+        ops.set_compute_dtype(torch.float32)
+
+
 # ------------------------------------------------------------------------------------------------------- stage hand-off
 def test_stage_checkpoint_with_old_norm_keys_reproduces_con_fixture(tmp_path):
     """main_pretrain.py:265-279: a checkpoint of the MM stage names the backbone's final norm `norm_l_h` (and carries the
