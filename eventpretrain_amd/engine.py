@@ -34,6 +34,7 @@ class GraphedStep:
         self.parts = False
         self.loss = None
         self._tables_read = None       # event: the last replay's H2D nodes have read the pinned scalar tables
+        self.guard_tables = True       # False only for A/B timing of the guard itself (tools/ab_step.py)
         self.note = "eager"
         self.multi = reducer is not None
         self.wgrad_chunks = int(wgrad_chunks)
@@ -177,7 +178,7 @@ class GraphedStep:
         # that is a step ahead would hand step N the learning rate / bias corrections of step N+1. Wait until the replay that
         # read them last has passed that point. One GPU: the tables are read by graph0 at the START of a step, so the host
         # still queues step N+1 while step N runs; N GPUs: by graph2, behind forward + backward.
-        if self._tables_read is not None:
+        if self._tables_read is not None and self.guard_tables:
             self._tables_read.synchronize()
         self.opt.stage_scalars()
         if self.graph0 is not None:

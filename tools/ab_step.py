@@ -24,6 +24,7 @@ VARIANTS = {
     "nodefer": {"set_deferred_grads": False},
     "now256": {"set_wgrad256": False},
     "nog4": {"set_wgrad_g4": False},
+    "noguard": {"_guard_tables": False},     # host free to run ahead (the scalar-table race the guard closes)
 }
 
 
@@ -45,6 +46,7 @@ def build(B, cfg):
     fwd = lambda mm, xx, yy, noise: mm(xx, yy, is_rec=True, noise=noise)
     ex = GraphedStep(m, opt, fwd, [x, y], noise_shape=(B, 196), generator=torch.Generator(device="cuda").manual_seed(1), warmup=3)
     assert ex.note.startswith("hip-graph"), ex.note
+    ex.guard_tables = cfg.get("_guard_tables", True)
     apply({})
     return ex
 
