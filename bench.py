@@ -305,18 +305,22 @@ def main():
     # replay. With N > 1 the collectives stay outside the graphs: [forward+backward graph] -> in-place RCCL all-reduce of
     # the flat gradient buffers -> [AdamW graph].
     from eventpretrain_amd.engine import GraphedStep
-    use_graph = (not args.no_graph) and graphable       # the Swin step plans its windows on the host per step: eager
+    is_swin = not graphable      # CONFIGS' flag: the Swin step's launch geometry follows the mask pattern
+    use_graph = not args.no_graph
     n_warm_eager = min(args.warmup, 3) if use_graph else 0
-    if phase == "rec" and not graphable:
-        # Swin: mask noise drawn on the host (seeded per rank), so the window plan needs no device->host read-back
-        hgen = torch.Generator().manual_seed(100 + rank)
-        fwd, noise_shape = (lambda m, x, y, noise: m(x, y, is_rec=True, noise=torch.rand(args.batch, cells, generator=hgen))), None
-    elif phase == "rec":
+    step_prepare = None
+    if phase == "rec":
         fwd, noise_shape = (lambda m, x, y, noise: m(x, y, is_rec=True, noise=noise)), (args.batch, cells)
+        if is_swin:
+            # Swin: the window plan is host work per pattern. The noise is drawn on the HOST (seeded per rank), the backbone's
+            # fixed-shape plan tables are refreshed by one H2D copy before each replay (SwinTransformer.enable_static_plan), so
+            # ONE captured graph serves every pattern; a pattern that overflows the fixed group count runs that step eagerly.
+            step_prepare = model.backbone.enable_static_plan(device)
     else:
         fwd, noise_shape = (lambda m, x, y, noise: m(x, y)), None
     executor = GraphedStep(model, opt, fwd, [vox, tgt], noise_shape=noise_shape, generator=gen, reducer=reducer, use_graph=use_graph,
-                           warmup=max(n_warm_eager, 2), wgrad_chunks=args.wgrad_chunks)
+                           warmup=max(n_warm_eager, 2), wgrad_chunks=args.wgrad_chunks, step_prepare=step_prepare,
+                           host_generator=torch.Generator().manual_seed(100 + rank))
     graph_note = executor.note
     step, eager_step = executor.step, executor.eager_step
     loss = None
@@ -351,7 +355,7 @@ def main():
                    "name": args.config, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                    "mask_ratio": 0.5 if phase == "rec" else 0.0,
                    "params_M": sum(p.numel() for p in model.parameters()) / 1e6},
-        "final_loss": final_loss, "launch_mode": graph_note,
+        "final_loss": final_loss, "launch_mode": graph_note, "eager_fallback_steps": executor.eager_fallbacks,
     }
     if headline:
         result["step_tflops_per_gpu"] = fl_sample * args.batch / (ms * 1e-3) / 1e12

@@ -253,7 +253,7 @@ extern "C" int evp_unpatchify_nhwc(const void *dcols, int dtype, const int64_t *
   EVP_CHECK_ARG(n_keep > 0 && n_keep <= L && (ids_keep || n_keep == L), EVP_ESHAPE, "evp_unpatchify_nhwc: bad n_keep");
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate && n_keep < L) {
-    hipError_t e = hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * H * W * C, s);
+    hipError_t e = evp_zero_async(dx, sizeof(float) * (size_t)B * H * W * C, s);
     EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_unpatchify_nhwc: memset failed: %s", hipGetErrorString(e));
   }
   const int64_t rows = (int64_t)B * n_keep;

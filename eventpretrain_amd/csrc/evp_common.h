@@ -87,3 +87,27 @@ __device__ __forceinline__ float dgelu_f(float x) {
 }
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- zero fill as a KERNEL ------------------------------------------------------------------------------------------------
+// Accumulate-by-atomics outputs (split-K partial sums, column sums, the relative-position table gradient, scatter targets) are
+// cleared by a kernel launch, not by hipMemsetAsync: inside a captured HIP graph the memset NODES of this ROCm release were
+// observed not to take effect reliably on replay (the second replay of a Swin f32 step added its atomics onto whatever the
+// graph's memory pool had left there: non-finite gradients in exactly the outputs cleared by memset nodes, first replay fine).
+// A kernel node has ordinary stream-order semantics. Dwords; pitch/width in bytes, both multiples of 4.
+namespace {
+__global__ __launch_bounds__(256) void evp_zero_kernel(uint32_t *p, int64_t pitch_dw, int64_t width_dw, int64_t total) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int64_t r = e / width_dw, c = e - r * width_dw;
+  p[r * pitch_dw + c] = 0u;
+}
+inline hipError_t evp_zero2d_async(void *p, size_t pitch_bytes, size_t width_bytes, size_t rows, hipStream_t s) {
+  if (width_bytes == 0 || rows == 0) return hipSuccess;
+  if ((pitch_bytes | width_bytes | (size_t)(uintptr_t)p) & 3) return hipErrorInvalidValue;
+  const int64_t total = (int64_t)(width_bytes / 4) * (int64_t)rows;
+  hipLaunchKernelGGL(evp_zero_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (uint32_t *)p, (int64_t)(pitch_bytes / 4),
+                     (int64_t)(width_bytes / 4), total);
+  return hipGetLastError();
+}
+inline hipError_t evp_zero_async(void *p, size_t bytes, hipStream_t s) { return evp_zero2d_async(p, bytes, bytes, 1, s); }
+}  // namespace

@@ -1010,7 +1010,7 @@ int launch(const evp_gemm_desc *d, hipStream_t s) {
     p.splitk = splitk;
   }
   if (splitk > 1 && !d->accumulate) {
-    hipError_t e = hipMemset2DAsync(d->C, (size_t)d->ldc * 4, 0, (size_t)d->N * 4, (size_t)d->M, s);
+    hipError_t e = evp_zero2d_async(d->C, (size_t)d->ldc * 4, (size_t)d->N * 4, (size_t)d->M, s);
     if (e != hipSuccess) { evp_set_error("evp_gemm: memset for split-K failed: %s", hipGetErrorString(e)); return EVP_ELAUNCH; }
   }
   constexpr int smem = STAGES * (Img<T, TA, BM, BK>::BYTES + Img<T, TB, BN, BK>::BYTES);

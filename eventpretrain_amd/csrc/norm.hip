@@ -1,6 +1,7 @@
 // Row-wise (LayerNorm family) and column-wise (bias-gradient, BatchNorm) reductions for gfx950.
 // All HBM-bound: one 64-lane wave owns one row, holds it in registers as float4 chunks (lane-strided, so every
 // wave-instruction moves 1 KiB contiguous), reduces with cross-lane shuffles, writes once.
+#include <cstdlib>
 #include "evp_common.h"
 
 namespace {
@@ -222,7 +223,17 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize(const float *part, int n
   }
 }
 
-static inline int ln_grid(int64_t M, int cap = LN_MAX_BLOCKS) {
+// backward grid cap; EVP_LN_BWD_BLOCKS overrides it for A/B runs (read once)
+static inline int ln_bwd_cap() {
+  static const int v = [] {
+    const char *e = getenv("EVP_LN_BWD_BLOCKS");
+    const int n = e ? atoi(e) : 0;
+    return n >= 64 && n <= 8192 ? n : LN_MAX_BLOCKS;
+  }();
+  return v;
+}
+static inline int ln_grid(int64_t M, int cap = 0) {
+  if (cap <= 0) cap = ln_bwd_cap();
   int64_t g = (M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
   if (g > cap) g = cap;
   if (g < 1) g = 1;
@@ -592,7 +603,7 @@ extern "C" int evp_colsum(const void *x, int x_dtype, int64_t M, int N, int64_t 
   EVP_CHECK_ARG(x && out, EVP_EINVAL, "evp_colsum: null pointer");
   EVP_CHECK_ARG(M > 0 && N > 0 && ld >= N && ld % 8 == 0, EVP_ESHAPE, "evp_colsum: bad shape (ld must be a multiple of 8)");
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * N, s);
+  hipError_t e = evp_zero_async(out, sizeof(float) * N, s);
   EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_colsum: memset failed: %s", hipGetErrorString(e));
   dim3 grid((N + 127) / 128, evp_colsum_nblk(M));
   if (x_dtype == EVP_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t *)x, M, N, ld, out);

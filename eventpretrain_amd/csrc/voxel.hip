@@ -370,7 +370,7 @@ extern "C" int evp_voxel_scatter_scaled_f32(const double *events, const int64_t 
   EVP_CHECK_ARG(((uintptr_t)events & 15) == 0, EVP_EINVAL, "evp_voxel_scatter_f32: events must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   if (algo == 1) {
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)n_clips * bins * H * W, s);
+    hipError_t e = evp_zero_async(out, sizeof(float) * (size_t)n_clips * bins * H * W, s);
     EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_voxel_scatter_f32: memset failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(voxel_atomic_kernel, dim3(64, n_clips), dim3(256), 0, s, events, clip_offsets, bins, H, W, is_txyp, scale_x,
                        scale_y, out);

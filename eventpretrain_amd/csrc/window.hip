@@ -190,7 +190,7 @@ extern "C" int evp_window_attention_bwd(const void *qkv, const float *table, con
   EVP_CHECK_ARG(qkv && table && rel && out && dout && dqkv && dtable, EVP_EINVAL, "evp_window_attention_bwd: null pointer");
   const size_t smem = (size_t)(4 * N * WA_LD + N * N + N + R) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(dtable, 0, (size_t)R * H * sizeof(float), st);
+  hipError_t e = evp_zero_async(dtable, (size_t)R * H * sizeof(float), st);
   EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_window_attention_bwd: memset: %s", hipGetErrorString(e));
   const dim3 grid((unsigned)(Bg * H));
   if (dtype == EVP_F32) {

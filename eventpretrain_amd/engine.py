@@ -21,15 +21,27 @@ from . import ops
 
 class GraphedStep:
     def __init__(self, model, optimizer, forward, static_inputs, noise_shape=None, generator=None, reducer=None,
-                 use_graph=True, warmup=2, wgrad_chunks=4):
+                 use_graph=True, warmup=2, wgrad_chunks=4, step_prepare=None, host_generator=None):
         """forward(model, *static_inputs, noise) -> tuple whose first item is the loss. `static_inputs`: device tensors
         with the batch's shapes (overwritten by `step(...)` when new data is passed). `noise_shape`: (B, L) of the
-        masking noise, or None when the model draws none (density masking, contrastive stage)."""
+        masking noise, or None when the model draws none (density masking, contrastive stage).
+        `step_prepare(noise_cpu) -> bool` (models whose launch geometry depends on the noise: the Swin backbone's window
+        plan, `SwinTransformer.enable_static_plan`): the noise is then drawn on the HOST (`host_generator`), handed to the
+        hook before anything is launched and copied to the static device buffer; False = the captured graph cannot serve
+        this step, which then runs eagerly with the same noise."""
         self.model, self.opt, self.forward, self.reducer = model, optimizer, forward, reducer
         self.inputs = [t for t in static_inputs]
         dev = self.inputs[0].device
         self.gen = generator if generator is not None else torch.Generator(device=dev)
         self.noise = torch.empty(*noise_shape, device=dev) if noise_shape is not None else None
+        self.step_prepare = step_prepare
+        self.host_gen = host_generator if host_generator is not None else torch.Generator()
+        if step_prepare is not None:
+            if self.noise is None:
+                raise ValueError("step_prepare needs noise_shape")
+            self._noise_pins = [torch.empty(*noise_shape).pin_memory() for _ in range(3)]
+            self._noise_events, self._noise_turn, self._noise_cpu = [None] * 3, 0, None
+        self.eager_fallbacks = 0
         self.graph = self.graph0 = self.graph2 = self.plan = None
         self.parts = False
         self.loss = None
@@ -43,12 +55,30 @@ class GraphedStep:
 
     # ------------------------------------------------------------------------------------------------ eager form
     def _draw_noise(self):
-        if self.noise is not None:
+        """-> True when the (static-shape) launch sequence can serve this step's noise."""
+        if self.noise is None:
+            return True
+        if self.step_prepare is None:
             self.noise.copy_(torch.rand(self.noise.shape, device=self.noise.device, generator=self.gen))
+            return True
+        t = self._noise_turn
+        self._noise_turn = (t + 1) % len(self._noise_pins)
+        if self._noise_events[t] is not None:
+            self._noise_events[t].synchronize()        # the H2D copy that last read this pinned buffer has run
+        pin = self._noise_pins[t]
+        torch.rand(pin.shape, generator=self.host_gen, out=pin)
+        self._noise_cpu = pin
+        ok = bool(self.step_prepare(pin))
+        self.noise.copy_(pin, non_blocking=True)
+        ev = self._noise_events[t] or torch.cuda.Event()
+        ev.record()
+        self._noise_events[t] = ev
+        return ok
 
     def eager_step(self):
-        self._draw_noise()
-        out = self.forward(self.model, *self.inputs, self.noise)
+        ok = self._draw_noise()
+        # not ok: the model's own host path plans for exactly this noise (a CPU tensor tells it to)
+        out = self.forward(self.model, *self.inputs, self.noise if ok else self._noise_cpu.clone())
         out[0].backward()
         if self.reducer is not None:
             self.reducer.finish()
@@ -63,7 +93,7 @@ class GraphedStep:
         params = [p for p in self.model.parameters()]
         snap = dict(params=[p.detach().clone() for p in params],
                     buffers=[(b, b.detach().clone()) for b in self.model.buffers()],
-                    step=self.opt._step, gen=self.gen.get_state(), moments={})
+                    step=self.opt._step, gen=self.gen.get_state(), host_gen=self.host_gen.get_state(), moments={})
         for p in params:
             st = self.opt.state.get(p, {})
             if "exp_avg" in st:
@@ -88,6 +118,7 @@ class GraphedStep:
                     st["exp_avg_sq"].zero_()
         self.opt._step = snap["step"]
         self.gen.set_state(snap["gen"])
+        self.host_gen.set_state(snap["host_gen"])
         ops.refresh_lp_shadows(self.model.parameters())
 
     def _capture(self, warmup):
@@ -104,6 +135,15 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         try:
+            if self.step_prepare is not None:
+                # the capture needs a step the fixed launch shape can serve: draw until one fits (the noise stream is put back)
+                with torch.cuda.stream(side):
+                    for _ in range(64):
+                        if self._draw_noise():
+                            break
+                    else:
+                        raise RuntimeError("step_prepare refused 64 noise draws in a row: nothing to capture")
+                side.synchronize()
             g1 = torch.cuda.CUDAGraph()
             # thread_local: RCCL's watchdog thread polls its events while this thread captures
             ops.hold_deferred_grads(self.multi)      # N ranks: the grouped weight-gradient launches stay out of the graph
@@ -126,6 +166,10 @@ class GraphedStep:
                     self.opt.upload_scalars()
                 self.graph0 = g0
             self.graph, self.note = g1, "hip-graph"
+            # what an eager fall-back step must put back: the captured gradient tensors and the optimizer's pointer tables
+            self._static_grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]
+            T = self.opt._tabs
+            self._ptr_tables = (T, T["n_grads"].copy(), T["n_lp"].copy()) if T is not None else None
             if self.multi:
                 # chunked weight-gradient launches interleaved with their all-reduces (parallel.OverlappedPlan)
                 with torch.cuda.stream(side):
@@ -173,7 +217,8 @@ class GraphedStep:
                 dst.copy_(src, non_blocking=True)
         if self.graph is None:
             return self.eager_step()
-        self._draw_noise()
+        if not self._draw_noise():
+            return self._eager_fallback()
         # The captured H2D nodes read the optimizer's pinned scalar tables when the REPLAY runs, not when it is queued: a host
         # that is a step ahead would hand step N the learning rate / bias corrections of step N+1. Wait until the replay that
         # read them last has passed that point. One GPU: the tables are read by graph0 at the START of a step, so the host
@@ -194,6 +239,31 @@ class GraphedStep:
                 self.plan.run()
                 self.graph2.replay()
                 self._mark_tables_read()
+        return self.loss
+
+    def _eager_fallback(self):
+        """One step outside the captured graph (the step's launch geometry does not fit it), leaving the graph usable: the
+        eager backward must not accumulate into the captured gradient tensors, and the optimizer's eager refresh() rewrites
+        the pinned pointer tables the graph's H2D nodes re-read -- both are put back."""
+        if self.multi:
+            raise RuntimeError("eager fall-back inside a data-parallel graphed step is not supported")
+        self.eager_fallbacks += 1
+        torch.cuda.current_stream().synchronize()
+        self.opt.zero_grad(set_to_none=True)
+        out = self.forward(self.model, *self.inputs, self._noise_cpu.clone())
+        out[0].backward()
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        torch.cuda.current_stream().synchronize()
+        for p, g in self._static_grads:
+            p.grad = g
+        if self._ptr_tables is not None and self.opt._tabs is self._ptr_tables[0]:
+            T, ng, nl = self._ptr_tables
+            T["n_grads"][:] = ng
+            T["n_lp"][:] = nl
+        else:
+            raise RuntimeError("the optimizer rebuilt its tables during an eager fall-back step; re-capture the executor")
+        self.loss.copy_(out[0].detach())
         return self.loss
 
     def _mark_tables_read(self):

@@ -96,16 +96,19 @@ class TokenLayout:
     """Host description of a sparse token set: `coords` int64 [n,2] (row, col) in row-major order and the boolean
     visibility map `vis` [res*res] it was cut from. What the reference carries as (coords, patch_mask) tensors."""
 
-    def __init__(self, coords, vis, res):
+    def __init__(self, coords, vis, res, coords_dev=None):
         self.coords = np.ascontiguousarray(coords, dtype=np.int64)
         self.vis = np.ascontiguousarray(vis, dtype=bool)
         self.res = int(res)
+        self.coords_dev = coords_dev      # int64 [1,n,2] already in device memory (static plan), else made on demand
 
     @property
     def n(self):
         return self.coords.shape[0]
 
     def coords_tensor(self, device):
+        if self.coords_dev is not None:
+            return self.coords_dev
         return torch.from_numpy(self.coords).unsqueeze(0).to(device)
 
     def mask_tensor(self, device):
@@ -231,6 +234,10 @@ def group_windows(group_size, num_ele_win):
     return sizes[:ng.value].tolist(), groups
 
 
+class PlanOverflow(Exception):
+    """A visibility pattern needs more window groups than a fixed-shape plan was sized for."""
+
+
 class GroupingModule:
     """Packs the visible tokens of the (shifted) windows into equally sized groups, or -- for at most 2*ws*ws tokens --
     keeps them as one group under a mask (swin_block.py:350-466). `prepare` is host work on the token coordinates and
@@ -263,8 +270,13 @@ class GroupingModule:
         out += ws - 1
         return out
 
-    def plan(self, coords, num_tokens):
-        """coords int64 [n,2] (host). -> dict of host arrays (see prepare)."""
+    def plan(self, coords, num_tokens, fixed=None):
+        """coords int64 [n,2] (host). -> dict of host arrays (see prepare).
+        `fixed=(group_size, n_groups)`: a plan of that exact shape for ANY pattern (what a captured HIP graph needs): the
+        knapsack packs into groups of `group_size` instead of the pattern's largest window population, and the group list is
+        padded with empty groups (every slot a masked copy of token 0, exactly how the reference pads a partly filled
+        group, swin_block.py:418-452). Masked pairs get -100 before the softmax, so the result differs from the
+        pattern-sized plan only by f32 summation order. Raises PlanOverflow when the pattern needs more groups."""
         coords = np.asarray(coords, dtype=np.int64).reshape(-1, 2)
         wid = self._window_id(coords)
         ws = self.window_size
@@ -277,9 +289,15 @@ class GroupingModule:
         swid = wid[order]
         starts = np.nonzero(np.r_[True, swid[1:] != swid[:-1]])[0]
         counts = np.diff(np.r_[starts, swid.shape[0]])
-        gs = int(min(ws * ws, counts.max()))
+        gs = int(min(ws * ws, counts.max())) if fixed is None else int(fixed[0])
+        if counts.max() > gs:
+            raise PlanOverflow(f"a window holds {int(counts.max())} tokens, fixed group size is {gs}")
         sizes, groups = group_windows(gs, counts)
         ng = len(groups)
+        if fixed is not None:
+            if ng > int(fixed[1]):
+                raise PlanOverflow(f"pattern needs {ng} groups, the fixed plan has {int(fixed[1])}")
+            ng = int(fixed[1])
         slot_tok = np.full((ng, gs), -1, dtype=np.int64)
         slot_wid = np.full((ng, gs), -1, dtype=np.int64)
         for g, wins in enumerate(groups):
@@ -310,6 +328,14 @@ class GroupingModule:
             self.idx_shuffle, self.idx_shuffle_adj = _dev_i32(p["gather"], device), _dev_i32(p["gather_adj"], device)
             self.idx_unshuffle, self.idx_unshuffle_adj = _dev_i32(p["scatter"], device), _dev_i32(p["scatter_adj"], device)
         return self.rel
+
+    def bind(self, mode, group_size, n_groups, rel, tables=None):
+        """Use tables that already live in device memory (a static plan's views: fixed addresses, refreshed by one H2D copy
+        per step) instead of uploading fresh ones."""
+        self._mode, self.group_size, self.n_groups, self.rel = mode, int(group_size), int(n_groups), rel
+        if mode == "grouping":
+            self.idx_shuffle, self.idx_shuffle_adj, self.idx_unshuffle, self.idx_unshuffle_adj = tables
+        return self
 
     def group(self, x):
         if self._mode == "grouping":

@@ -563,3 +563,52 @@ def test_con_epoch_loops_run_and_agree():
         stats.append(st)
     assert stats[0]["contrastive_loss"] == pytest.approx(stats[1]["contrastive_loss"], rel=1e-6)
     assert math.isfinite(stats[0]["contrastive_loss"])
+
+
+# ------------------------------------------------------------------------------------------- accumulators under replay
+def test_graph_replay_clears_its_atomic_accumulators():
+    """Outputs that kernels accumulate into with atomics (split-K weight gradient, column sums, the relative-position table
+    gradient) must be cleared by something that re-runs on every HIP-graph replay. They used to be cleared by hipMemsetAsync,
+    whose graph nodes were not reliable on replay (non-finite Swin gradients on the second replay); now a kernel does it.
+    Here the captured outputs are poisoned with NaN between replays."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.ops import call, dt, ptr, stream_ptr
+    torch.manual_seed(0)
+    M, n_out, k_in = 3528, 96, 384                      # few output tiles, long K: the launcher splits K and adds with atomics
+    dy = torch.randn(M, n_out, device="cuda")
+    x = torch.randn(M, k_in, device="cuda")
+    Bg, nG, N, H, R = 4, 2, 49, 3, 169
+    qkv = torch.randn(Bg * N, 3 * H * 32, device="cuda") * 0.3
+    table = torch.randn(R, H, device="cuda") * 0.1
+    rel = torch.randint(-1, R, (nG, N, N), device="cuda", dtype=torch.int32)
+    dout = torch.randn(Bg * N, H * 32, device="cuda")
+
+    def work():
+        dw = ops._wgrad(dy, x, n_out, k_in, M)
+        cs = ops.colsum(dy)
+        att = torch.empty(Bg * N, H * 32, device="cuda")
+        call("evp_window_attention_fwd", ptr(qkv), ptr(table), ptr(rel), ptr(att), 0, Bg, nG, N, H, R, 32 ** -0.5, dt(qkv), stream_ptr())
+        dqkv = torch.empty_like(qkv)
+        dtable = torch.empty(R, H, device="cuda")
+        call("evp_window_attention_bwd", ptr(qkv), ptr(table), ptr(rel), ptr(att), ptr(dout), ptr(dqkv), ptr(dtable), Bg, nG, N, H, R,
+             32 ** -0.5, dt(qkv), stream_ptr())
+        return dw, cs, dtable
+
+    want = [t.clone() for t in work()]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        work()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        outs = work()
+    for rep in range(3):
+        for t in outs:
+            t.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        for t, w, name in zip(outs, want, ("split-K weight gradient", "column sums", "relative-position table gradient")):
+            assert torch.isfinite(t).all(), (name, rep)
+            assert torch.allclose(t, w, rtol=1e-4, atol=1e-4 * w.abs().max().item()), (name, rep)

@@ -306,3 +306,70 @@ def test_swin_trainer_epoch_runs_and_learns():
         ops.set_compute_dtype(torch.float32)
     print(f"[swin-tiny] trainer loss {first:.4f} -> {last:.4f}")
     assert math.isfinite(last) and last < first
+
+
+# ------------------------------------------------------------------------------------------- fixed-shape plan + HIP graph
+def test_swin_static_plan_equals_pattern_plan_against_reference():
+    """The fixed-shape window tables (group size 49, padded group list; what a captured graph needs) give the reference's
+    step: same fixture, same tolerances as the pattern-sized plan -- and the two plans agree with each other to f32
+    summation order."""
+    from eventpretrain_amd import ops
+    d = load_golden("rec_swin_tiny")
+    x, y, noise = rec_inputs("swin", jl(d["cfg"]))
+    ops.set_compute_dtype(torch.float32)
+    res = {}
+    for mode in ("pattern", "static"):
+        a, m = _swin_hub()
+        if mode == "static":
+            prepare = m.backbone.enable_static_plan("cuda")
+            assert prepare(noise) is True
+        out = m(x.cuda(), y.cuda(), is_rec=True, noise=noise.cuda())
+        out[0].backward()
+        torch.cuda.synchronize()
+        res[mode] = (out[0].item(), out[10].detach().cpu(), {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None},
+                     [c.cpu() for c in out[6:10]])
+    for mode in res:
+        assert abs(res[mode][0] - float(d["loss"])) / abs(float(d["loss"])) <= F32_LOSS_RTOL, mode
+    assert abs(res["static"][0] - res["pattern"][0]) <= 1e-6 * abs(res["pattern"][0])
+    assert torch.allclose(res["static"][1], res["pattern"][1], atol=1e-5, rtol=1e-5)
+    for c, k in zip(res["static"][3], ("coords_l1", "coords_l2", "coords_l3", "coords_l4")):
+        assert np.array_equal(c.numpy(), d[k]), k
+    for n, g in res["pattern"][2].items():
+        gs = res["static"][2][n]
+        assert torch.allclose(gs, g, atol=1e-7 + 1e-4 * g.abs().max().item(), rtol=1e-4), n
+
+
+@pytest.mark.parametrize("slack", [1.25, 1.05, 0.9])
+def test_swin_graphed_step_follows_eager_trajectory(slack):
+    """ONE captured graph serves every mask pattern (tables refreshed by an H2D copy per step); patterns that need more
+    groups than the fixed shape holds (slack 1.05: about a third of them) run eagerly in between without disturbing the
+    graph; when NO pattern fits (0.9) the executor says so and stays eager. Either way the losses follow the plain eager executor's from the same start and noise stream."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.engine import GraphedStep
+    from eventpretrain_amd.optim import FusedAdamW
+    from eventpretrain_amd.utils import lr_decay as lrd
+    d = load_golden("rec_swin_tiny")
+    x, y, _ = rec_inputs("swin", jl(d["cfg"]))
+    B = x.shape[0]
+    ops.set_compute_dtype(torch.float32)
+    fwd = lambda mm, xx, yy, noise: mm(xx, yy, is_rec=True, noise=noise)
+    runs, notes = {}, {}
+    for mode in ("eager", "graph"):
+        a, m = _swin_hub()
+        opt = FusedAdamW(lrd.param_groups_lrd(a, m, 0.05, layer_decay=1), lr=1e-3, betas=(0.9, 0.95))
+        prepare = m.backbone.enable_static_plan("cuda", slack=slack) if mode == "graph" else (lambda n: False)
+        ex = GraphedStep(m, opt, fwd, [x.cuda(), y.cuda()], noise_shape=(B, 49), use_graph=(mode == "graph"), warmup=2,
+                         step_prepare=prepare, host_generator=torch.Generator().manual_seed(77))
+        if mode == "graph" and slack > 1.0:
+            assert ex.note.startswith("hip-graph"), ex.note
+        elif mode == "graph":
+            assert ex.note.startswith("eager (graph capture failed"), ex.note      # no pattern fits: nothing to capture
+        runs[mode] = [ex.step().item() for _ in range(12)]
+        notes[mode] = (ex.eager_fallbacks, getattr(m.backbone, "_static_plan", None))
+    assert runs["graph"] == pytest.approx(runs["eager"], rel=2e-5), (runs, notes)
+    fallbacks, sp = notes["graph"]
+    if slack >= 1.25:
+        assert fallbacks == 0 and sp.overflows == 0
+    if 1.0 < slack < 1.25:
+        assert 0 < fallbacks < 12, fallbacks
+    print(f"[swin graph] slack {slack}: {fallbacks} eager fall-back steps of 12, plan loads {sp.loads}")

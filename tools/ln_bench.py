@@ -1,46 +1,41 @@
 #!/usr/bin/env python3
-"""LayerNorm forward / backward at the step's shapes: device time (HIP graph of 20 calls, so the Python/ctypes launch
-cost does not hide the kernels) and algorithmic HBM rate."""
+"""Probe (not part of the product): LayerNorm backward (evp_layernorm_bwd_cs: dx f32 + bf16 copy + three partial rows per block)
+at the step's two shapes, HIP-event timed. EVP_LN_BWD_BLOCKS=<n> changes the grid cap (default 1024).
+usage: ln_bench.py"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from eventpretrain_amd import ops  # noqa: E402
+from eventpretrain_amd.ops import call, ptr, dt, stream_ptr  # noqa: E402
 
 
-def graph_time(fn, n=20, reps=10):
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        for _ in range(3):
-            fn()
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side):
-        for _ in range(n):
-            fn()
-    g.replay()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        g.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / (n * reps)
+def main():
+    for name, M, D in (("enc", 6272, 768), ("dec", 12544, 512)):
+        dy = torch.randn(M, D, device="cuda")
+        x = torch.randn(M, D, device="cuda")
+        gres = torch.randn(M, D, device="cuda")
+        gamma = torch.randn(D, device="cuda")
+        mean, rstd = x.mean(1), 1.0 / x.std(1)
+        dx = torch.empty_like(x)
+        lp = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+        nb = call("evp_layernorm_bwd_nblk", M)
+        ws = torch.empty(nb, 3 * D, device="cuda")
+        run = lambda: call("evp_layernorm_bwd_cs", ptr(dy), dt(dy), ptr(x), 0, 0, ptr(gamma), ptr(mean), ptr(rstd), ptr(gres), M, D,
+                           ptr(dx), ptr(lp), ptr(ws), stream_ptr())
+        for _ in range(5):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 50 * 1e3
+        byt = M * D * (4 + 4 + 4 + 4 + 2) + nb * 3 * D * 4
+        print(f"{name} M={M} D={D} blocks={nb}: {us:6.1f} us  {byt / us * 1e-6:5.2f} TB/s algorithmic", flush=True)
 
 
 if __name__ == "__main__":
-    for M, D in ((6272, 768), (12544, 512)):
-        x = torch.randn(M, D, device="cuda")
-        g = torch.randn(D, device="cuda")
-        b = torch.randn(D, device="cuda")
-        gres = torch.randn(M, D, device="cuda")
-        y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6, torch.bfloat16)
-        dy = torch.randn(M, D, device="cuda").bfloat16()
-        tf = graph_time(lambda: ops.layernorm_fwd(x, g, b, 1e-6, torch.bfloat16))
-        tb = graph_time(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, gres=gres, want_lp=True))
-        bf = M * D * (4 + 2)
-        bb = M * D * (2 + 4 + 4 + 4 + 2)
-        print(f"LN {M}x{D}: fwd {tf * 1e6:6.1f} us ({bf / tf / 1e12:.2f} TB/s)   bwd+finalize {tb * 1e6:6.1f} us ({bb / tb / 1e12:.2f} TB/s)", flush=True)
+    main()

@@ -140,12 +140,13 @@ template <bool KC, int F> struct Operand {
 };
 
 // MODE bits: 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no barrier, 16 no vmcnt wait, 32 no lgkmcnt wait, 64 no C store,
-// 128 accumulator with n on the lane (dword stores of two full 128-byte lines) instead of m on the lane (16-byte pieces of 64 rows)
+// 128 accumulator with n on the lane (dword stores of two full 128-byte lines) instead of m on the lane (16-byte pieces of 64 rows),
+// 256 bf16 C (8-byte stores, m on the lane), 512 THREE-stage ring (a 256x128 tile then needs 72 KiB: two workgroups per CU)
 template <bool AKC, bool BKC, int FI, int FJ, int MODE>
 __device__ __forceinline__ void g4x_body(const GxParams &p, const int tile_m, const int tile_n) {
   using OA = Operand<AKC, FI>;
   using OB = Operand<BKC, FJ>;
-  constexpr int STAGE = OA::IMG + OB::IMG, NP = FI + FJ, NMF = FI * FJ;
+  constexpr int STAGE = OA::IMG + OB::IMG, NP = FI + FJ, NMF = FI * FJ, NST = (MODE & 512) ? 3 : 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,7 +161,7 @@ __device__ __forceinline__ void g4x_body(const GxParams &p, const int tile_m, co
   ob.init(lane, wave, wn, n0, p.N, p.ldb, smem_base + OA::IMG);
 
   auto dma_piece = [&](int idx, int t) {          // idx 0..NP-1 (compile time after unrolling)
-    char *stage = smem + (t & 3) * STAGE;
+    char *stage = smem + ((unsigned)t % (unsigned)NST) * STAGE;
     if (idx < FI) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void *)(stage + (wave * FI + idx) * 1024), 16, oa.voff[idx < FI ? idx : 0], t * oa.kstep, 0, 0);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void *)(stage + OA::IMG + (wave * FJ + (idx - FI)) * 1024), 16, ob.voff[idx >= FI ? idx - FI : 0], t * ob.kstep, 0, 0);
   };
@@ -209,14 +210,16 @@ __device__ __forceinline__ void g4x_body(const GxParams &p, const int tile_m, co
   for (int i = 0; i < NP; ++i) dma_piece(i, 0);
 #pragma unroll
   for (int i = 0; i < NP; ++i) dma_piece(i, 1);
+  if constexpr (NST == 4) {
 #pragma unroll
-  for (int i = 0; i < NP; ++i) dma_piece(i, 2);
-  wait_vm<2 * NP>();
+    for (int i = 0; i < NP; ++i) dma_piece(i, 2);
+  }
+  wait_vm<(NST - 2) * NP>();
   __builtin_amdgcn_s_barrier();
 
   auto iteration = [&](auto dmac, auto vmc, int t) {
     constexpr int VM = decltype(vmc)::value;
-    const unsigned soff = (unsigned)((t & 3) * STAGE);
+    const unsigned soff = ((unsigned)t % (unsigned)NST) * (unsigned)STAGE;
     if constexpr (!(MODE & 4)) {
       oa.template read<0>(a0, soff);
       ob.template read<0>(b0, soff);
@@ -231,7 +234,7 @@ __device__ __forceinline__ void g4x_body(const GxParams &p, const int tile_m, co
     }
     __builtin_amdgcn_sched_barrier(0);
     tie_all(a0, b0);
-    mfma_block(a0, b0, dmac, t + 3);
+    mfma_block(a0, b0, dmac, t + NST - 1);
     if constexpr (!(MODE & 32)) wait_lgkm<0>();
     tie_all(a1, b1);
     if constexpr (!(MODE & 16)) {
@@ -243,10 +246,10 @@ __device__ __forceinline__ void g4x_body(const GxParams &p, const int tile_m, co
   };
   // nk >= 3 (precondition): the main loop keeps three stages in flight, the last three stages drain
   int t = 0;
-  for (; t + 3 < nk; ++t) iteration(std::true_type{}, std::integral_constant<int, 2>{}, t);
-  iteration(std::false_type{}, std::integral_constant<int, 1>{}, t);
-  iteration(std::false_type{}, std::integral_constant<int, 0>{}, t + 1);
-  iteration(std::false_type{}, std::integral_constant<int, -1>{}, t + 2);
+  for (; t + NST - 1 < nk; ++t) iteration(std::true_type{}, std::integral_constant<int, NST - 2>{}, t);
+  if constexpr (NST == 4) iteration(std::false_type{}, std::integral_constant<int, 1>{}, t++);
+  iteration(std::false_type{}, std::integral_constant<int, 0>{}, t);
+  iteration(std::false_type{}, std::integral_constant<int, -1>{}, t + 1);
   mfma_block(a1, b1, std::false_type{}, 0);
 
   if constexpr (MODE & 64) {
@@ -273,6 +276,26 @@ __device__ __forceinline__ void g4x_body(const GxParams &p, const int tile_m, co
           if (n < p.N) p.C[(int64_t)m * p.ldc + n] = acc[i][j][r];
         }
       }
+  } else if constexpr (MODE & 256) {
+    const int mrow = m0 + wm * 32 * FI + (lane & 31), ncol = n0 + wn * 32 * FJ + 4 * (lane >> 5);
+    bf16_t *Cb = reinterpret_cast<bf16_t *>(p.C);
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+      const int m = mrow + 32 * i;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < FJ; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = ncol + 32 * j + 8 * g;
+          if (n + 3 >= p.N) continue;
+          typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (__bf16)acc[i][j][4 * g + e];
+          *reinterpret_cast<bf16x4 *>(Cb + (int64_t)m * p.ldc + n) = o;
+        }
+    }
   } else {
     // C[m][n..n+3]: lane m = .. + (lane & 31); reg r: n = .. + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)
     const int mrow = m0 + wm * 32 * FI + (lane & 31), ncol = n0 + wn * 32 * FJ + 4 * (lane >> 5);
@@ -313,7 +336,7 @@ static inline float bf2f(bf16_t h) {
 }
 
 template <bool AKC, bool BKC, int FI, int FJ, int MODE> static float run(const GxParams &p, int reps, hipEvent_t e0, hipEvent_t e1) {
-  constexpr int smem = 4 * (64 * FI + 64 * FJ) * 64;
+  constexpr int smem = ((MODE & 512) ? 3 : 4) * (64 * FI + 64 * FJ) * 64;
   void (*k)(const GxParams) = g4x_kernel<AKC, BKC, FI, FJ, MODE>;
   hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   GxParams q = p;
@@ -373,7 +396,10 @@ template <bool AKC, bool BKC, int FI, int FJ> static int sweep(const char *tag, 
     const int tiles = ((s.M + 64 * FI - 1) / (64 * FI)) * ((s.N + 64 * FJ - 1) / (64 * FJ));
     printf("%s %dx%d %-9s %5dx%5dx%5d %4dt %8.1fus %6.0fTF %6.2fus/K64/round%s", tag, 64 * FI, 64 * FJ, s.name, s.M, s.N, s.K, tiles, us,
            2.0 * s.M * s.N * s.K / us * 1e-6, us / (s.K / 64.0) / ((tiles + 255) / 256), bad ? " BAD" : "");
-    printf("  [m-on-lane store %.1f, no store %.1f]", run<AKC, BKC, FI, FJ, 0>(p, reps, e0, e1), run<AKC, BKC, FI, FJ, 64>(p, reps, e0, e1));
+    printf("  [f32 m-on-lane %.1f, no store %.1f, bf16 C %.1f", run<AKC, BKC, FI, FJ, 0>(p, reps, e0, e1), run<AKC, BKC, FI, FJ, 64>(p, reps, e0, e1),
+           run<AKC, BKC, FI, FJ, 256>(p, reps, e0, e1));
+    if constexpr (FI * FJ <= 8) printf(", 3-stage ring 2 WG/CU: bf16 C %.1f, no store %.1f", run<AKC, BKC, FI, FJ, 256 + 512>(p, reps, e0, e1), run<AKC, BKC, FI, FJ, 64 + 512>(p, reps, e0, e1));
+    printf("]");
     if (s.K >= 4096)
       printf("\n   ablation (results invalid by construction): noDMA %.1f noMFMA %.1f noREAD %.1f noBARRIER %.1f noVMWAIT %.1f noLGKMWAIT %.1f noBAR+noVM+noLGKM %.1f "
              "MFMAonly %.1f MFMA+BARRIER %.1f",
