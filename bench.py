@@ -215,10 +215,15 @@ def cpu_baseline(cfgs, n_threads, Bc=16, n_steps=6):
                        "B=%d, %d steps, %.1f s" % (Bc, n_steps, dt_))
 
 
+_PMC_CONFIG_OK = True      # the committed counters are of the headline workload: other --config runs report traffic null
+
+
 def pmc_traffic(kernel_key):
     """HBM-side bytes per launch of a kernel from the committed PMC summary (profiles/r01_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the guide's gfx950 correction), or None. bench.py cannot collect
     PMC counters itself; the figure is from the same command profiled offline."""
+    if not _PMC_CONFIG_OK and "voxel" not in kernel_key:
+        return None
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
@@ -293,6 +298,8 @@ def main():
     gen = torch.Generator(device=device).manual_seed(100 + rank)     # seed + rank, as main_pretrain.py:174
     L = model.backbone.num_patches
     label, _bb, _size, phase, _fac, _supp, cells, graphable = CONFIGS[args.config]
+    global _PMC_CONFIG_OK
+    _PMC_CONFIG_OK = args.config == "vit_base_rec" and args.batch == 64 and args.dtype == "bf16"
 
     def barrier():
         if multi:
