@@ -91,6 +91,11 @@ SIGNATURES = {
     "evp_enqueue_keys_dev": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "evp_window_attention_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
     "evp_window_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "evp_window_attention_fused_np": [_i],
+    "evp_window_bias_build": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "evp_window_attention_fused_fwd": [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
+    "evp_window_attention_fused_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
+    "evp_window_bias_reduce": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "evp_gather_rows_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "evp_swin_fuse_gather_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "evp_swin_fuse_gather_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -102,7 +107,8 @@ SIGNATURES = {
     "evp_abi_version": [],
 }
 _OTHER_RESTYPE = {"evp_last_error": C.c_char_p, "evp_target_arch": C.c_char_p}
-_NO_STATUS = {"evp_dwconv5x5_bwd_nslab", "evp_gemm_set_variant", "evp_attention_fused_supported", "evp_layernorm_bwd_nblk", "evp_colsum_nblk", "evp_batchnorm_nblk", "evp_abi_version"}
+_NO_STATUS = {"evp_dwconv5x5_bwd_nslab", "evp_gemm_set_variant", "evp_attention_fused_supported", "evp_layernorm_bwd_nblk", "evp_colsum_nblk", "evp_batchnorm_nblk", "evp_abi_version",
+              "evp_window_attention_fused_np"}
 
 _lib = None
 

@@ -119,9 +119,13 @@ template <int DH> __device__ __forceinline__ void head_of_block(int bid, int nbl
 
 // ---------------------------------------------------------------------------------------------------- forward
 // NT = number of 16-wide score tiles (NP = 16*NT rows in LDS, NT even)
-template <int DH, int NT, int NW>
+// BIAS (windowed attention, model/sub_module/swin_block.py:135-158): logits = q.k*scale + addm[group][head][query][key], where
+// addm holds the gathered relative-position bias, or -100 for the pairs the reference masks (tokens of different windows, padding
+// slots); group = batch index % nG; addm is [nG][heads][NP][NP] f32 (evp_window_bias_build).
+template <int DH, int NT, int NW, bool BIAS = false>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16_t *qkv, bf16_t *out, float *lse, bf16_t *probs, int N, int heads,
-                                                       float scale, int64_t ldp, unsigned long long *dbg) {
+                                                       float scale, int64_t ldp, unsigned long long *dbg, const float *addm,
+                                                       int nG) {
   unsigned long long t0 = 0, t1 = 0;
   if (dbg) t0 = __builtin_readcyclecounter();
   constexpr int NP = 16 * NT, IMG = NP * DH * 2, KS = DH / 32, DT = DH / 16;
@@ -163,6 +167,18 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16_t *qkv, bf
     // raw v_exp_f32 (arguments are <= 0: no overflow, underflow to 0 is the wanted result) and with the key mask applied
     // only to the tiles that reach past N.
     f32x4 mx4 = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if constexpr (BIAS) {
+      // logits in log2 units: X = S*scale*log2(e) + addm*log2(e); rows of addm are NP floats, this lane's query row
+      const float *arow = addm + ((int64_t)((b % nG) * heads + h) * NP + (strip * 16 + li)) * NP + 4 * g;
+      const f32x4 c2b = f32x4{c2, c2, c2, c2};
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float4 a = *reinterpret_cast<const float4 *>(arow + 16 * t);
+        const f32x4 al = f32x4{a.x * 1.44269504088896340736f, a.y * 1.44269504088896340736f, a.z * 1.44269504088896340736f,
+                               a.w * 1.44269504088896340736f};
+        S[t] = __builtin_elementwise_fma(S[t], c2b, al);
+      }
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (16 * t + 15 >= N) {               // wave-uniform: only the last one or two tiles
@@ -175,8 +191,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16_t *qkv, bf
     float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float nm = -mx * c2;
-    const f32x4 c2v = f32x4{c2, c2, c2, c2}, nmv = f32x4{nm, nm, nm, nm};
+    const float nm = BIAS ? -mx : -mx * c2;
+    const float cm = BIAS ? 1.0f : c2;
+    const f32x4 c2v = f32x4{cm, cm, cm, cm}, nmv = f32x4{nm, nm, nm, nm};
     f32x4 sum4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -189,7 +206,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16_t *qkv, bf
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     const int q = strip * 16 + li;
-    if (g == 0 && q < N && lse) lse[(int64_t)bh * N + q] = mx * scale + logf(sum);
+    if (g == 0 && q < N && lse) lse[(int64_t)bh * N + q] = (BIAS ? mx * 0.69314718055994530942f : mx * scale) + logf(sum);
 #pragma unroll
     for (int t = 0; t < NT; ++t) S[t] = S[t] * inv;
     if (probs && q < N) {
@@ -218,9 +235,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16_t *qkv, bf
 }
 
 // ---------------------------------------------------------------------------------------------------- backward
-template <int DH, int NT, int NW>
+// BIAS: addm as in the forward, addmT its transpose per (group, head) ([key][query]: the key-on-lane pass reads 4 consecutive
+// queries), dA [nG][heads][NP][NP] f32 (zeroed by the caller) receives d logits summed over the batch with f32 atomics.
+template <int DH, int NT, int NW, bool BIAS = false>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse,
-                                                       bf16_t *dqkv, int N, int heads, float scale) {
+                                                       bf16_t *dqkv, int N, int heads, float scale, const float *addm,
+                                                       const float *addmT, float *dA, int nG) {
   constexpr int NP = 16 * NT, IMG = NP * DH * 2, KS = DH / 32, DT = DH / 16, CH = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *Qs = smem, *Ks = smem + IMG, *Vs = smem + 2 * IMG, *Gs = smem + 3 * IMG;   // Gs = dO
@@ -288,6 +308,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16_t *qkv, co
     f32x4 accq[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) accq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t arow = BIAS ? ((int64_t)((b % nG) * heads + h) * NP + q) * NP + 4 * g : 0;
     // key tiles in chunks of CH (even): only CH score tiles are live at a time, dQ accumulates across chunks
 #pragma unroll 1
     for (int c0 = 0; c0 < NT; c0 += CH) {
@@ -304,12 +325,29 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16_t *qkv, co
           }
           // dS = P * (dP - delta) * scale on the whole tile (packed f32 math, raw v_exp_f32); keys past N only exist in
           // the last one or two tiles
-          f32x4 pv = __builtin_elementwise_fma(s, c2q, nlq);
+          f32x4 pv;
+          if constexpr (BIAS) {
+            const float4 a = *reinterpret_cast<const float4 *>(addm + arow + 16 * t);
+            const f32x4 al = f32x4{a.x * l2e, a.y * l2e, a.z * l2e, a.w * l2e};
+            pv = __builtin_elementwise_fma(s, c2q, al + nlq);
+          } else {
+            pv = __builtin_elementwise_fma(s, c2q, nlq);
+          }
           pv = f32x4{__builtin_amdgcn_exp2f(pv[0]), __builtin_amdgcn_exp2f(pv[1]), __builtin_amdgcn_exp2f(pv[2]), __builtin_amdgcn_exp2f(pv[3])};
           if (16 * t + 15 >= N) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (16 * t + 4 * g + r >= N) pv[r] = 0.f;
+          }
+          if constexpr (BIAS) {
+            // d logits (unscaled) of this (query, 4 keys) piece, summed over the batch in dA
+            const f32x4 dl = pv * (dp - dqv);
+            if (q < N) {
+              float *da = dA + arow + 16 * t;
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (16 * t + 4 * g + r < N) unsafeAtomicAdd(da + r, dl[r]);
+            }
           }
           P[tt] = pv * ((dp - dqv) * scv);
         }
@@ -358,7 +396,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16_t *qkv, co
           const float4 dl = *reinterpret_cast<const float4 *>(Ds + 16 * t + 4 * g);
           const f32x4 nl = f32x4{-lq.x * l2e, -lq.y * l2e, -lq.z * l2e, -lq.w * l2e}, dlv = f32x4{dl.x, dl.y, dl.z, dl.w};
           const f32x4 c2k = f32x4{c2, c2, c2, c2}, sck = f32x4{scale, scale, scale, scale};
-          f32x4 pv = __builtin_elementwise_fma(s, c2k, nl);        // padded queries carry lse = +inf -> p = 0
+          f32x4 addl = f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (BIAS) {
+            const float4 a = *reinterpret_cast<const float4 *>(addmT + ((int64_t)((b % nG) * heads + h) * NP + (strip * 16 + li)) * NP + 16 * t + 4 * g);
+            addl = f32x4{a.x * l2e, a.y * l2e, a.z * l2e, a.w * l2e};
+          }
+          f32x4 pv = __builtin_elementwise_fma(s, c2k, nl + addl);        // padded queries carry lse = +inf -> p = 0
           pv = f32x4{__builtin_amdgcn_exp2f(pv[0]), __builtin_amdgcn_exp2f(pv[1]), __builtin_amdgcn_exp2f(pv[2]), __builtin_amdgcn_exp2f(pv[3])};
           P[tt] = pv;
           dS[tt] = pv * ((dp - dlv) * sck);
@@ -414,11 +457,11 @@ int launch_fwd(const bf16_t *qkv, bf16_t *out, float *lse, bf16_t *probs, int B,
   if (attn_fwd_waves() == 8) {
     auto k = attn_fwd_kernel<DH, NT, 8>;
     if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(k, dim3(B * heads), dim3(512), smem, s, qkv, out, lse, probs, N, heads, scale, ldp, g_attn_dbg);
+    hipLaunchKernelGGL(k, dim3(B * heads), dim3(512), smem, s, qkv, out, lse, probs, N, heads, scale, ldp, g_attn_dbg, (const float *)nullptr, 1);
   } else {
     auto k = attn_fwd_kernel<DH, NT, 4>;
     if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(k, dim3(B * heads), dim3(256), smem, s, qkv, out, lse, probs, N, heads, scale, ldp, g_attn_dbg);
+    hipLaunchKernelGGL(k, dim3(B * heads), dim3(256), smem, s, qkv, out, lse, probs, N, heads, scale, ldp, g_attn_dbg, (const float *)nullptr, 1);
   }
   EVP_CHECK_LAUNCH("evp_attention_fused_fwd");
   return EVP_OK;
@@ -429,7 +472,8 @@ int launch_bwd(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const f
   constexpr int smem = 4 * 16 * NT * DH * 2 + 2 * 16 * NT * 4;
   auto go = [&](auto kfn, int nthr) {
     if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(kfn, dim3(B * heads), dim3(nthr), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale);
+    hipLaunchKernelGGL(kfn, dim3(B * heads), dim3(nthr), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale, (const float *)nullptr,
+                       (const float *)nullptr, (float *)nullptr, 1);
   };
   const int nw = attn_bwd_waves();
   if (nw == 16) go(attn_bwd_kernel<DH, NT, 16>, 1024);
@@ -438,6 +482,72 @@ int launch_bwd(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const f
   EVP_CHECK_LAUNCH("evp_attention_fused_bwd");
   return EVP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------- windowed attention
+// addm[g][h][i][j] = rel[g][i][j] >= 0 ? table[rel][h] : -100 (swin_block.py:135-158: gathered relative-position bias; the pairs the
+// reference masks -- other window, padding slot -- carry index -1), and its transpose per (g, h); NP x NP planes, zero outside N x N.
+__global__ __launch_bounds__(256) void win_bias_build_kernel(const float *__restrict__ table, const int32_t *__restrict__ rel, float *__restrict__ addm,
+                                                             float *__restrict__ addmT, int nG, int N, int NP, int H, int64_t total) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int j = (int)(e % NP);
+  const int i = (int)((e / NP) % NP);
+  const int h = (int)((e / ((int64_t)NP * NP)) % H);
+  const int g = (int)(e / ((int64_t)NP * NP * H));
+  float v = 0.f;
+  if (i < N && j < N) {
+    const int r = rel[((int64_t)g * N + i) * N + j];
+    v = r >= 0 ? table[(int64_t)r * H + h] : -100.0f;
+  }
+  addm[e] = v;
+  addmT[(((int64_t)g * H + h) * NP + j) * NP + i] = v;
+}
+
+// dtable[r][h] += sum over (g, i, j) with rel[g][i][j] == r of dA[g][h][i][j]: one workgroup per (group, head), the table
+// privatised in LDS, at most R global atomics per workgroup (dtable zeroed by the launcher)
+__global__ __launch_bounds__(256) void win_bias_reduce_kernel(const float *__restrict__ dA, const int32_t *__restrict__ rel, float *__restrict__ dtable,
+                                                              int N, int NP, int H, int R) {
+  extern __shared__ float tab[];
+  const int g = blockIdx.x / H, h = blockIdx.x % H;
+  for (int r = threadIdx.x; r < R; r += 256) tab[r] = 0.f;
+  __syncthreads();
+  const float *plane = dA + (int64_t)blockIdx.x * NP * NP;
+  for (int e = threadIdx.x; e < N * N; e += 256) {
+    const int i = e / N, j = e - i * N;
+    const int r = rel[(int64_t)g * N * N + e];
+    if (r >= 0) atomicAdd(&tab[r], plane[i * NP + j]);
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < R; r += 256) {
+    const float t = tab[r];
+    if (t != 0.f) unsafeAtomicAdd(dtable + (int64_t)r * H + h, t);
+  }
+}
+
+template <int NT>
+int launch_win_fwd(const bf16_t *qkv, const float *addm, bf16_t *out, float *lse, int Bg, int nG, int N, int heads, float scale, hipStream_t s) {
+  constexpr int smem = 3 * 16 * NT * 32 * 2;
+  auto k = attn_fwd_kernel<32, NT, 4, true>;
+  hipLaunchKernelGGL(k, dim3(Bg * heads), dim3(256), smem, s, qkv, out, lse, (bf16_t *)nullptr, N, heads, scale, (int64_t)0,
+                     (unsigned long long *)nullptr, addm, nG);
+  EVP_CHECK_LAUNCH("evp_window_attention_fused_fwd");
+  return EVP_OK;
+}
+template <int NT>
+int launch_win_bwd(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse, const float *addm, const float *addmT, bf16_t *dqkv,
+                   float *dA, int Bg, int nG, int N, int heads, float scale, hipStream_t s) {
+  constexpr int smem = 4 * 16 * NT * 32 * 2 + 2 * 16 * NT * 4;
+  constexpr int NW = NT <= 4 ? 4 : 8;          // one 16-query strip per wave: no more waves than strips
+  auto k = attn_bwd_kernel<32, NT, NW, true>;
+  hipLaunchKernelGGL(k, dim3(Bg * heads), dim3(64 * NW), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale, addm, addmT, dA, nG);
+  EVP_CHECK_LAUNCH("evp_window_attention_fused_bwd");
+  return EVP_OK;
+}
+#define DISPATCH_WIN_NT(CALL)                         \
+  if (N <= 32) { constexpr int NTV = 2; CALL; }       \
+  else if (N <= 64) { constexpr int NTV = 4; CALL; }  \
+  else if (N <= 96) { constexpr int NTV = 6; CALL; }  \
+  else { constexpr int NTV = 8; CALL; }
 
 #define DISPATCH_NT(DHV, CALL)                                                  \
   if (N <= 32) { constexpr int NTV = 2; constexpr int DHC = DHV; CALL; }        \
@@ -475,4 +585,58 @@ extern "C" int evp_attention_fused_bwd(const void *qkv, const void *out, const v
   hipStream_t s = (hipStream_t)stream;
   if (dh == 64) { DISPATCH_NT(64, return (launch_bwd<DHC, NTV>((const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, B, N, heads, scale, s))) }
   DISPATCH_NT(32, return (launch_bwd<DHC, NTV>((const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, B, N, heads, scale, s)))
+}
+
+// ---------------------------------------------------------------------------------------------------- windowed attention (MFMA)
+// The Swin blocks' attention on grouped tokens (model/sub_module/swin_block.py:113-162) on the fused kernels above: d_h = 32, a
+// group of N <= 128 tokens per workgroup, logits = q.k*scale + relative-position bias, -100 on the pairs the reference masks.
+// Replaces the f32 LDS kernels of window.hip in bf16 mode (those remain the f32 parity path and serve the blocks that return
+// their probabilities).
+extern "C" int evp_window_attention_fused_np(int N) { return N <= 32 ? 32 : N <= 64 ? 64 : N <= 96 ? 96 : 128; }
+
+extern "C" int evp_window_bias_build(const float *table, const int32_t *rel, int nG, int N, int heads, int R, float *addm, float *addmT,
+                                     void *stream) {
+  EVP_CHECK_ARG(table && rel && addm && addmT, EVP_EINVAL, "evp_window_bias_build: null pointer");
+  EVP_CHECK_ARG(nG > 0 && N > 0 && N <= 128 && heads > 0 && R > 0, EVP_ESHAPE, "evp_window_bias_build: bad shape (N=%d)", N);
+  const int NP = evp_window_attention_fused_np(N);
+  const int64_t total = (int64_t)nG * heads * NP * NP;
+  hipLaunchKernelGGL(win_bias_build_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, rel, addm, addmT, nG, N,
+                     NP, heads, total);
+  EVP_CHECK_LAUNCH("evp_window_bias_build");
+  return EVP_OK;
+}
+
+extern "C" int evp_window_attention_fused_fwd(const void *qkv, const float *addm, int Bg, int nG, int N, int heads, float scale, void *out,
+                                              float *lse, void *stream) {
+  EVP_CHECK_ARG(qkv && addm && out && lse, EVP_EINVAL, "evp_window_attention_fused_fwd: null pointer");
+  EVP_CHECK_ARG(Bg > 0 && nG > 0 && Bg % nG == 0 && N > 0 && N <= 128 && heads > 0, EVP_ESHAPE,
+                "evp_window_attention_fused_fwd: bad shape (Bg=%d nG=%d N=%d)", Bg, nG, N);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_WIN_NT(return (launch_win_fwd<NTV>((const bf16_t *)qkv, addm, (bf16_t *)out, lse, Bg, nG, N, heads, scale, s)))
+}
+
+extern "C" int evp_window_attention_fused_bwd(const void *qkv, const void *out, const void *dout, const float *lse, const float *addm,
+                                              const float *addmT, int Bg, int nG, int N, int heads, float scale, void *dqkv, float *dA,
+                                              void *stream) {
+  EVP_CHECK_ARG(qkv && out && dout && lse && addm && addmT && dqkv && dA, EVP_EINVAL, "evp_window_attention_fused_bwd: null pointer");
+  EVP_CHECK_ARG(Bg > 0 && nG > 0 && Bg % nG == 0 && N > 0 && N <= 128 && heads > 0, EVP_ESHAPE,
+                "evp_window_attention_fused_bwd: bad shape (Bg=%d nG=%d N=%d)", Bg, nG, N);
+  hipStream_t s = (hipStream_t)stream;
+  const int NP = evp_window_attention_fused_np(N);
+  hipError_t e = evp_zero_async(dA, (size_t)nG * heads * NP * NP * sizeof(float), s);
+  EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_window_attention_fused_bwd: clearing dA failed: %s", hipGetErrorString(e));
+  DISPATCH_WIN_NT(return (launch_win_bwd<NTV>((const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, addm, addmT, (bf16_t *)dqkv, dA, Bg,
+                                              nG, N, heads, scale, s)))
+}
+
+extern "C" int evp_window_bias_reduce(const float *dA, const int32_t *rel, int nG, int N, int heads, int R, float *dtable, void *stream) {
+  EVP_CHECK_ARG(dA && rel && dtable, EVP_EINVAL, "evp_window_bias_reduce: null pointer");
+  EVP_CHECK_ARG(nG > 0 && N > 0 && N <= 128 && heads > 0 && R > 0 && R <= 4096, EVP_ESHAPE, "evp_window_bias_reduce: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = evp_zero_async(dtable, (size_t)R * heads * sizeof(float), s);
+  EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_window_bias_reduce: clearing dtable failed: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(win_bias_reduce_kernel, dim3((unsigned)(nG * heads)), dim3(256), (size_t)R * sizeof(float), s, dA, rel, dtable, N,
+                     evp_window_attention_fused_np(N), heads, R);
+  EVP_CHECK_LAUNCH("evp_window_bias_reduce");
+  return EVP_OK;
 }

@@ -223,6 +223,14 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, gres=None, x2=None, x3=None, want_lp
 
 
 _use_fused_attention = True
+_use_window_mfma = True
+
+
+def set_window_mfma(flag):
+    """A/B switch: Swin window attention on the MFMA kernels (default, bf16 mode) or on the f32 LDS kernels."""
+    global _use_window_mfma
+    _use_window_mfma = bool(flag)
+
 
 
 def set_fused_attention(flag):
@@ -1556,8 +1564,20 @@ class SwinBlockFn(torch.autograd.Function):
         tab = _chk(table.detach(), torch.float32)
         R = tab.shape[0]
         scale = dh ** -0.5
-        call("evp_window_attention_fwd", ptr(qkv), ptr(tab), ptr(_chk(rel, torch.int32)), ptr(att), ptr(probs), Bg, nG, N, heads, R,
-             scale, dt(qkv), stream_ptr())
+        # bf16 mode: the MFMA kernels of the ViT attention with the gathered bias as an additive matrix per (group, head); the
+        # f32 LDS kernels stay the parity path and serve the blocks that return their probabilities
+        fused = _use_window_mfma and T == torch.bfloat16 and not want_attn and N <= 128
+        lse = addm = addmT = None
+        if fused:
+            NP = call("evp_window_attention_fused_np", N)
+            addm = torch.empty(nG * heads * NP * NP, dtype=torch.float32, device=dev)
+            addmT = torch.empty_like(addm)
+            call("evp_window_bias_build", ptr(tab), ptr(_chk(rel, torch.int32)), nG, N, heads, R, ptr(addm), ptr(addmT), stream_ptr())
+            lse = torch.empty(Bg * heads * N, dtype=torch.float32, device=dev)
+            call("evp_window_attention_fused_fwd", ptr(qkv), ptr(addm), Bg, nG, N, heads, scale, ptr(att), ptr(lse), stream_ptr())
+        else:
+            call("evp_window_attention_fwd", ptr(qkv), ptr(tab), ptr(_chk(rel, torch.int32)), ptr(att), ptr(probs), Bg, nG, N, heads, R,
+                 scale, dt(qkv), stream_ptr())
         x1 = torch.empty(M, D, dtype=torch.float32, device=dev)
         gemm(att, wp, x1, M=M, N=D, K=D, bias=pb, residual=x2d)
         ln2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, eps, T)
@@ -1572,6 +1592,7 @@ class SwinBlockFn(torch.autograd.Function):
         ctx.dims = (Bg, nG, N, D, heads, dh, Hd, R, scale)
         ctx.prm = (qkvw, qkvb, pw, pb, f1w, f1b, f2w, f2b)
         ctx.nprm = (n1w, n1b, n2w, n2b)
+        ctx.win = (lse, addm, addmT)          # plain tensors of this node (not inputs / outputs): kept on ctx
         out = x2.view(Bg, N, D)
         if want_attn:
             ctx.mark_non_differentiable(probs)
@@ -1608,8 +1629,15 @@ class SwinBlockFn(torch.autograd.Function):
         gemm(g1_lp, wp, datt, M=M, N=D, K=D, trans_b=True, ldb=D)
         dqkv = torch.empty(M, 3 * D, dtype=T, device=dev)
         dtable = torch.empty(R, heads, dtype=torch.float32, device=dev)
-        call("evp_window_attention_bwd", ptr(qkv), ptr(tab), ptr(rel), ptr(att), ptr(datt), ptr(dqkv), ptr(dtable), Bg, nG, N, heads,
-             R, scale, dt(qkv), stream_ptr())
+        lse, addm, addmT = ctx.win
+        if lse is not None:
+            dA = torch.empty_like(addm)
+            call("evp_window_attention_fused_bwd", ptr(qkv), ptr(att), ptr(datt), ptr(lse), ptr(addm), ptr(addmT), Bg, nG, N, heads, scale,
+                 ptr(dqkv), ptr(dA), stream_ptr())
+            call("evp_window_bias_reduce", ptr(dA), ptr(rel), nG, N, heads, R, ptr(dtable), stream_ptr())
+        else:
+            call("evp_window_attention_bwd", ptr(qkv), ptr(tab), ptr(rel), ptr(att), ptr(datt), ptr(dqkv), ptr(dtable), Bg, nG, N, heads,
+                 R, scale, dt(qkv), stream_ptr())
         dbq = _bgrad(dqkv, qkvb_) if need[6] else None
         dwq = _wgrad(dqkv, ln1, 3 * D, D, M, qkvw_) if need[5] else None
         dln1 = torch.empty(M, D, dtype=T, device=dev)

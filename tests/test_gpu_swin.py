@@ -71,6 +71,79 @@ def test_window_attention_fwd_bwd(dtype, Bg, nG, N, H):
     assert torch.allclose(dtab.cpu().double(), gt, atol=tol * max(1.0, gt.abs().max().item()), rtol=tol)
 
 
+@pytest.mark.parametrize("Bg,nG,N,H", [(6, 3, 49, 3), (8, 2, 49, 6), (2, 1, 96, 12), (4, 2, 24, 24), (3, 3, 1, 6), (2, 1, 128, 3), (82, 41, 49, 3)])
+def test_window_attention_mfma_fwd_bwd(Bg, nG, N, H):
+    """The bf16 MFMA form (evp_window_bias_build -> evp_window_attention_fused_fwd/bwd -> evp_window_bias_reduce) against the
+    same float64 formulation as the f32 LDS kernels above, incl. fully masked (padding) groups and NaN-poisoned outputs."""
+    from eventpretrain_amd._lib import call, ptr, stream_ptr
+    rng = np.random.default_rng(Bg * 1000 + N + 7)
+    R, dh = 169, 32
+    qkv = torch.from_numpy(rng.standard_normal((Bg, N, 3, H, dh)).astype(np.float32)).bfloat16().float()
+    table = torch.from_numpy((rng.standard_normal((R, H)) * 0.5).astype(np.float32))
+    rel = _rand_rel(rng, nG, N, R, 0.4)
+    if nG > 2:
+        rel[-1] = -1                          # an empty (padding) group: every pair masked
+    dout = torch.from_numpy(rng.standard_normal((Bg, N, H * dh)).astype(np.float32)).bfloat16().float()
+    qr = qkv.clone().double().requires_grad_(True)
+    tr = table.clone().double().requires_grad_(True)
+    o_ref, _ = _ref_window_attention(qr, tr, rel, nG, H)
+    (o_ref * dout.double()).sum().backward()
+
+    qd, td, rd = qkv.bfloat16().cuda(), table.cuda(), torch.from_numpy(rel).cuda()
+    NP = call("evp_window_attention_fused_np", N)
+    nan = float("nan")
+    addm = torch.full((nG * H * NP * NP,), nan, device="cuda")
+    addmT = torch.full_like(addm, nan)
+    call("evp_window_bias_build", ptr(td), ptr(rd), nG, N, H, R, ptr(addm), ptr(addmT), stream_ptr())
+    a4 = addm.view(nG, H, NP, NP)
+    assert torch.equal(a4.transpose(2, 3), addmT.view(nG, H, NP, NP)) and torch.isfinite(addm).all()
+    out = torch.full((Bg, N, H * dh), nan, dtype=torch.bfloat16, device="cuda")
+    lse = torch.full((Bg * H * N,), nan, device="cuda")
+    call("evp_window_attention_fused_fwd", ptr(qd), ptr(addm), Bg, nG, N, H, dh ** -0.5, ptr(out), ptr(lse), stream_ptr())
+    dqkv = torch.full_like(qd, nan)
+    dA = torch.full_like(addm, nan)                                           # cleared by the call
+    dtab = torch.full((R, H), 7.0, dtype=torch.float32, device="cuda")       # overwritten, not accumulated
+    dd = dout.bfloat16().cuda()
+    call("evp_window_attention_fused_bwd", ptr(qd), ptr(out), ptr(dd), ptr(lse), ptr(addm), ptr(addmT), Bg, nG, N, H, dh ** -0.5,
+         ptr(dqkv), ptr(dA), stream_ptr())
+    call("evp_window_bias_reduce", ptr(dA), ptr(rd), nG, N, H, R, ptr(dtab), stream_ptr())
+    torch.cuda.synchronize()
+    tol = 2e-2
+    assert torch.isfinite(out.float()).all() and torch.isfinite(dqkv.float()).all() and torch.isfinite(dtab).all()
+    assert torch.allclose(out.float().cpu().double(), o_ref.detach(), atol=tol, rtol=tol)
+    gq = qr.grad
+    assert torch.allclose(dqkv.float().cpu().double(), gq, atol=tol * max(1.0, gq.abs().max().item()), rtol=tol)
+    gt = tr.grad
+    assert torch.allclose(dtab.cpu().double(), gt, atol=tol * max(1.0, gt.abs().max().item()), rtol=tol)
+
+
+def test_swin_bf16_step_mfma_window_attention_matches_lds_kernels():
+    """Whole Swin-T step in bf16: window attention on the MFMA kernels (default) against the f32 LDS kernels (the previous
+    default): loss and gradient norms agree to bf16 accuracy."""
+    from eventpretrain_amd import ops
+    d = load_golden("rec_swin_tiny")
+    x, y, noise = rec_inputs("swin", jl(d["cfg"]))
+    ops.set_compute_dtype(torch.bfloat16)
+    res = {}
+    try:
+        for mode in (True, False):
+            ops.set_window_mfma(mode)
+            a, m = _swin_hub()
+            out = m(x.cuda(), y.cuda(), is_rec=True, noise=noise.cuda())
+            out[0].backward()
+            ops.flush_deferred_grads()
+            torch.cuda.synchronize()
+            res[mode] = (out[0].item(), {n: p.grad.double().norm().item() for n, p in m.named_parameters() if p.grad is not None})
+    finally:
+        ops.set_window_mfma(True)
+        ops.set_compute_dtype(torch.float32)
+    assert abs(res[True][0] - res[False][0]) <= 2e-3 * abs(res[False][0]), (res[True][0], res[False][0])
+    assert abs(res[True][0] - float(d["loss"])) <= BF16_LOSS_RTOL * abs(float(d["loss"]))
+    worst = max(abs(res[True][1][n] - v) / (v + 1e-6) for n, v in res[False][1].items())
+    assert worst <= 6e-2, worst
+    print(f"[swin bf16] MFMA vs LDS window attention: loss {res[True][0]:.6f} / {res[False][0]:.6f}, worst gradient-norm rel diff {worst:.2e}")
+
+
 def test_window_attention_rejects_bad_shapes():
     from eventpretrain_amd import EvpError
     from eventpretrain_amd._lib import call, ptr, stream_ptr
