@@ -236,18 +236,17 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16_t *qkv, bf
 
 // ---------------------------------------------------------------------------------------------------- backward
 // BIAS: addm as in the forward, addmT its transpose per (group, head) ([key][query]: the key-on-lane pass reads 4 consecutive
-// queries), dA [nG][heads][NP][NP] f32 (zeroed by the caller) receives d logits summed over the batch with f32 atomics.
-template <int DH, int NT, int NW, bool BIAS = false>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse,
-                                                       bf16_t *dqkv, int N, int heads, float scale, const float *addm,
-                                                       const float *addmT, float *dA, int nG) {
+// queries); the d logits of this wave's query strip (one strip per wave: NW >= number of strips) are ADDED into dacc, which the
+// windowed wrapper keeps across the batch items it walks and flushes once.
+template <int DH, int NT, int NW, bool BIAS>
+__device__ __forceinline__ void attn_bwd_body(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse, bf16_t *dqkv, int N,
+                                              int heads, float scale, const float *addm, const float *addmT, int nG, const int b, const int h,
+                                              f32x4 (&dacc)[NT]) {
   constexpr int NP = 16 * NT, IMG = NP * DH * 2, KS = DH / 32, DT = DH / 16, CH = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *Qs = smem, *Ks = smem + IMG, *Vs = smem + 2 * IMG, *Gs = smem + 3 * IMG;   // Gs = dO
   float *Ls = reinterpret_cast<float *>(smem + 4 * IMG), *Ds = Ls + NP;          // log-sum-exp, delta = rowsum(dO * O)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  int b, h;
-  head_of_block<DH>(blockIdx.x, gridDim.x, heads, b, h);
   const int bh = b * heads + h;
   const int64_t C = (int64_t)heads * DH, tok = 3 * C;
   const bf16_t *base = qkv + (int64_t)b * N * tok + (int64_t)h * DH;
@@ -310,8 +309,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16_t *qkv, co
     for (int dt = 0; dt < DT; ++dt) accq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int64_t arow = BIAS ? ((int64_t)((b % nG) * heads + h) * NP + q) * NP + 4 * g : 0;
     // key tiles in chunks of CH (even): only CH score tiles are live at a time, dQ accumulates across chunks
-#pragma unroll 1
-    for (int c0 = 0; c0 < NT; c0 += CH) {
+    auto chunk = [&](const int c0) {
       f32x4 P[CH];
 #pragma unroll
       for (int tt = 0; tt < CH; ++tt) {
@@ -339,16 +337,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16_t *qkv, co
             for (int r = 0; r < 4; ++r)
               if (16 * t + 4 * g + r >= N) pv[r] = 0.f;
           }
-          if constexpr (BIAS) {
-            // d logits (unscaled) of this (query, 4 keys) piece, summed over the batch in dA
-            const f32x4 dl = pv * (dp - dqv);
-            if (q < N) {
-              float *da = dA + arow + 16 * t;
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                if (16 * t + 4 * g + r < N) unsafeAtomicAdd(da + r, dl[r]);
-            }
-          }
+          if constexpr (BIAS) dacc[t] += pv * (dp - dqv);      // d logits (unscaled) of this (query, 4 keys) piece
           P[tt] = pv * ((dp - dqv) * scv);
         }
       }
@@ -359,6 +348,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16_t *qkv, co
           if (c0 + 2 * ss < NT)
             accq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<DH>(Ks, dt * 16, (c0 >> 1) + ss, lane),
                                                                pack_tiles(P[2 * ss], P[2 * ss + 1]), accq[dt], 0, 0, 0);
+    };
+    if constexpr (BIAS) {         // unrolled: dacc[] is indexed by the tile number
+#pragma unroll
+      for (int c0 = 0; c0 < NT; c0 += CH) chunk(c0);
+    } else {
+#pragma unroll 1
+      for (int c0 = 0; c0 < NT; c0 += CH) chunk(c0);
     }
     if (q < N) {
 #pragma unroll
@@ -430,6 +426,51 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16_t *qkv, co
   }
 }
 
+template <int DH, int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse,
+                                                       bf16_t *dqkv, int N, int heads, float scale) {
+  int b, h;
+  head_of_block<DH>(blockIdx.x, gridDim.x, heads, b, h);
+  f32x4 unused[NT];
+  attn_bwd_body<DH, NT, NW, false>(qkv, out, dout, lse, dqkv, N, heads, scale, nullptr, nullptr, 1, b, h, unused);
+}
+
+// Windowed form: workgroup = (group, head, batch chunk). It walks `per` batch items of its (group, head), keeping the d logits of
+// its query strips in registers, and adds them into dA once at the end -- B / per adds per element instead of B (one plain store
+// when a single workgroup covers the whole batch). One workgroup per (batch, head) adding every tile straight into dA measured
+// 246 us per Swin-T stage-1 launch: 64 workgroups contending for each row of the same plane.
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void win_attn_bwd_mfma_kernel(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse,
+                                                                bf16_t *dqkv, int N, int heads, float scale, const float *addm,
+                                                                const float *addmT, float *dA, int nG, int B, int nchunk, int per) {
+  constexpr int NP = 16 * NT;
+  const int gh = blockIdx.x / nchunk, c = blockIdx.x - gh * nchunk;
+  const int grp = gh / heads, h = gh - grp * heads;
+  f32x4 dacc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) dacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int rep = 0; rep < per; ++rep) {
+    const int bi = c * per + rep;
+    if (bi >= B) break;
+    attn_bwd_body<32, NT, NW, true>(qkv, out, dout, lse, dqkv, N, heads, scale, addm, addmT, nG, bi * nG + grp, h, dacc);
+    __syncthreads();                       // the next batch item re-stages the LDS images
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, q = wave * 16 + (lane & 15);
+  if (q < N) {
+    float *da = dA + ((int64_t)gh * NP + q) * NP + 4 * g;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (nchunk == 1 && 16 * t + 4 * g + 3 < N) {
+        *reinterpret_cast<float4 *>(da + 16 * t) = make_float4(dacc[t][0], dacc[t][1], dacc[t][2], dacc[t][3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * t + 4 * g + r < N) unsafeAtomicAdd(da + 16 * t + r, dacc[t][r]);
+      }
+    }
+  }
+}
+
 // Waves per workgroup. Measured on MI355X (dec shape B=64, 16 heads, N=196, d_h=32; tools/attn_bench.py, one box): the
 // backward (two passes of dependent MFMA -> softmax algebra -> MFMA chains, latency-bound at two waves per SIMD) runs 62.9 us
 // with 4 waves and 47.2 us with 8; the forward 25.5 us with 4 and 32.2 us with 8 (its 13 strips split worse over 8 waves and
@@ -472,8 +513,7 @@ int launch_bwd(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const f
   constexpr int smem = 4 * 16 * NT * DH * 2 + 2 * 16 * NT * 4;
   auto go = [&](auto kfn, int nthr) {
     if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(kfn, dim3(B * heads), dim3(nthr), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale, (const float *)nullptr,
-                       (const float *)nullptr, (float *)nullptr, 1);
+    hipLaunchKernelGGL(kfn, dim3(B * heads), dim3(nthr), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale);
   };
   const int nw = attn_bwd_waves();
   if (nw == 16) go(attn_bwd_kernel<DH, NT, 16>, 1024);
@@ -538,8 +578,15 @@ int launch_win_bwd(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, con
                    float *dA, int Bg, int nG, int N, int heads, float scale, hipStream_t s) {
   constexpr int smem = 4 * 16 * NT * 32 * 2 + 2 * 16 * NT * 4;
   constexpr int NW = NT <= 4 ? 4 : 8;          // one 16-query strip per wave: no more waves than strips
-  auto k = attn_bwd_kernel<32, NT, NW, true>;
-  hipLaunchKernelGGL(k, dim3(Bg * heads), dim3(64 * NW), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale, addm, addmT, dA, nG);
+  const int B = Bg / nG;
+  int nchunk = (512 + nG * heads - 1) / (nG * heads);        // keep >= ~512 workgroups in the launch
+  if (nchunk > B) nchunk = B;
+  if (nchunk < 1) nchunk = 1;
+  const int per = (B + nchunk - 1) / nchunk;
+  nchunk = (B + per - 1) / per;
+  auto k = win_attn_bwd_mfma_kernel<NT, NW>;
+  hipLaunchKernelGGL(k, dim3(nG * heads * nchunk), dim3(64 * NW), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale, addm, addmT, dA, nG, B, nchunk,
+                     per);
   EVP_CHECK_LAUNCH("evp_window_attention_fused_bwd");
   return EVP_OK;
 }
