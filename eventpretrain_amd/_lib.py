@@ -67,6 +67,7 @@ SIGNATURES = {
     "evp_unpatchify_nhwc": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "evp_dwconv5x5_fwd": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "evp_dwconv5x5_bwd_nslab": [_i, _i, _i],
+    "evp_dwconv_set_band": [_i],
     "evp_dwconv5x5_bwd": [_vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "evp_unshuffle_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "evp_unshuffle_bwd": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],

@@ -212,6 +212,211 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T *dout, c
       part[((int64_t)blockIdx.y * 26 + k) * C + blockIdx.x * 128 + cc] = sh[0][k][cc] + sh[1][k][cc] + sh[2][k][cc] + sh[3][k][cc];
   }
 }
+// ---- band form (round 2) ---------------------------------------------------------------------------------------------------
+// The row walkers above issue the 5 loads of a column when they need them: one exposed load latency per position (measured on
+// ConvViT-Base stage 1, B=64, 56x56x256 bf16: forward 294 us, data gradient 250 us, weight gradient 470 us against ~60 us of HBM
+// time). Here a workgroup first stages a BAND of the (masked) input -- R output rows + 4 halo rows, W + 4 columns, CB channels =
+// 128 bytes per position -- into LDS with all its 16-byte loads in flight at once (zero halo, keep mask applied while staging),
+// then every thread walks its row segment with the same 5x5 register window, fed by 5 LDS reads per position.
+// Thread = (channel pair, segment): NPAIR = 64 / sizeof(T) pairs x NSEG = 256 / NPAIR segments = R rows x SPR segments per row.
+template <typename T> struct BandCfg {
+  static constexpr int EPC = 16 / sizeof(T);              // elements per 16-byte chunk
+  static constexpr int CB = 128 / sizeof(T);              // channels per workgroup (128 bytes per position)
+  static constexpr int NPAIR = CB / 2, NSEG = 256 / NPAIR;
+};
+template <typename T> __device__ __forceinline__ void chunk_scale(uint4 &v, float k);
+template <> __device__ __forceinline__ void chunk_scale<float>(uint4 &v, float k) {
+  v.x = __float_as_uint(__uint_as_float(v.x) * k); v.y = __float_as_uint(__uint_as_float(v.y) * k);
+  v.z = __float_as_uint(__uint_as_float(v.z) * k); v.w = __float_as_uint(__uint_as_float(v.w) * k);
+}
+template <> __device__ __forceinline__ void chunk_scale<bf16_t>(uint4 &v, float k) {
+  uint32_t *u = reinterpret_cast<uint32_t *>(&v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = __uint_as_float(u[i] << 16) * k, b = __uint_as_float(u[i] & 0xFFFF0000u) * k;
+    u[i] = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+  }
+}
+// stage rows [y0 - 2, y0 + R + 2) x columns [-2, W + 2) of image b, channels [c0, c0 + CB): band[row][col + 2][128 bytes]
+template <typename T, int R, bool MASKED>
+__device__ __forceinline__ void stage_band(const T *__restrict__ src, const float *__restrict__ mask, int b, int y0, int H, int W, int C, int c0,
+                                           int ms, int mgw, int mL, char *band, int tid) {
+  constexpr int EPC = BandCfg<T>::EPC;
+  const int WP = W + 4, total = (R + 4) * WP * 8;
+  for (int base = tid; base < total; base += 256 * 4) {
+    uint4 v[4];
+    float k[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + u * 256;
+      v[u] = make_uint4(0, 0, 0, 0);
+      k[u] = 1.f;
+      if (i < total) {
+        const int ch = i & 7, col = (i >> 3) % WP, row = (i >> 3) / WP;
+        const int yy = y0 - 2 + row, xx = col - 2;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+          if (MASKED && mask) k[u] = keep_at(mask, b, yy, xx, ms, mgw, mL);
+          v[u] = *reinterpret_cast<const uint4 *>(src + (((int64_t)b * H + yy) * W + xx) * C + c0 + ch * EPC);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + u * 256;
+      if (i < total) {
+        if (MASKED && k[u] != 1.f) chunk_scale<T>(v[u], k[u]);
+        *reinterpret_cast<uint4 *>(band + (int64_t)(i >> 3) * 128 + (i & 7) * 16) = v[u];
+      }
+    }
+  }
+}
+// segment s of SPR covers columns [seg_x0(s), seg_x0(s + 1)); cut points are made ODD multiples apart where possible so that the two
+// half-waves of a wave (adjacent segments of one row) read LDS positions an odd number of 128-byte steps apart (no bank conflict)
+__device__ __forceinline__ int seg_x0(int s, int spr, int W) {
+  if (s <= 0) return 0;
+  if (s >= spr) return W;
+  int x = (W * s) / spr;
+  if (((x - (W * (s - 1)) / spr) & 1) == 0 && x + 1 < W) ++x;
+  return x;
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void dwconv_band_kernel(const T *__restrict__ src, const float *__restrict__ mask, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, int B, int H, int W, int C, int ms, int mgw, int mL,
+                                                          T *__restrict__ dst) {
+  constexpr int R = 4, NPAIR = BandCfg<T>::NPAIR, NSEG = BandCfg<T>::NSEG, SPR = NSEG / R, CB = BandCfg<T>::CB;
+  extern __shared__ __attribute__((aligned(16))) char band[];
+  const int tid = threadIdx.x;
+  const int c0 = blockIdx.x * CB;
+  const int r0 = blockIdx.y * R, b = r0 / H, y0 = r0 - b * H;          // H % R == 0: a band never crosses images
+  stage_band<T, R, !BWD>(src, mask, b, y0, H, W, C, c0, ms, mgw, mL, band, tid);
+  const int pair = tid % NPAIR, seg = tid / NPAIR, row = seg / SPR, sx = seg % SPR;
+  const int c = c0 + pair * 2;
+  float k0[5][5], k1[5][5];
+#pragma unroll
+  for (int ki = 0; ki < 5; ++ki)
+#pragma unroll
+    for (int kj = 0; kj < 5; ++kj) {
+      const int t = BWD ? (4 - ki) * 5 + (4 - kj) : ki * 5 + kj;
+      k0[ki][kj] = w[c * 25 + t];
+      k1[ki][kj] = w[(c + 1) * 25 + t];
+    }
+  const float b0 = BWD ? 0.f : bias[c], b1 = BWD ? 0.f : bias[c + 1];
+  __syncthreads();
+  const int WP = W + 4, x_lo = seg_x0(sx, SPR, W), x_hi = seg_x0(sx + 1, SPR, W);
+  // window column kj of output x = band column x + kj (band column = image column + 2)
+  const char *brow = band + ((int64_t)row * WP) * 128 + pair * 2 * sizeof(T);
+  float w0[5][5], w1[5][5];
+  auto load_col = [&](int bc, int kj) {
+#pragma unroll
+    for (int ki = 0; ki < 5; ++ki) ld2<T>(reinterpret_cast<const T *>(brow + ((int64_t)ki * WP + bc) * 128), w0[ki][kj], w1[ki][kj]);
+  };
+  if (x_lo < x_hi) {
+    load_col(x_lo, 0); load_col(x_lo + 1, 1); load_col(x_lo + 2, 2); load_col(x_lo + 3, 3);
+    const int y = y0 + row;
+    for (int x = x_lo; x < x_hi; ++x) {
+      load_col(x + 4, 4);
+      float s0 = b0, s1 = b1;
+#pragma unroll
+      for (int ki = 0; ki < 5; ++ki)
+#pragma unroll
+        for (int kj = 0; kj < 5; ++kj) {
+          s0 += k0[ki][kj] * w0[ki][kj];
+          s1 += k1[ki][kj] * w1[ki][kj];
+        }
+      if (BWD) {
+        const float k = keep_at(mask, b, y, x, ms, mgw, mL);
+        s0 *= k; s1 *= k;
+      }
+      st2<T>(dst + (((int64_t)b * H + y) * W + x) * C + c, s0, s1);
+#pragma unroll
+      for (int ki = 0; ki < 5; ++ki)
+#pragma unroll
+        for (int kj = 0; kj < 4; ++kj) { w0[ki][kj] = w0[ki][kj + 1]; w1[ki][kj] = w1[ki][kj + 1]; }
+    }
+  }
+}
+
+// Weight gradient, band form: a workgroup owns DW_ROWS image rows (one slab, as above) and walks them in bands of R = 2 rows: the
+// masked input band (R + 4 rows) and the R rows of dout are staged in LDS, every thread accumulates its 25 + 1 sums for its channel
+// pair over its segment, the segments meet in LDS once per slab.
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_band_kernel(const T *__restrict__ dout, const T *__restrict__ in, const float *__restrict__ mask,
+                                                                     int B, int H, int W, int C, int ms, int mgw, int mL, float *__restrict__ part) {
+  constexpr int R = 2, NPAIR = BandCfg<T>::NPAIR, NSEG = BandCfg<T>::NSEG, SPR = NSEG / R, CB = BandCfg<T>::CB, EPC = BandCfg<T>::EPC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, WP = W + 4;
+  char *band = smem, *gband = smem + (int64_t)(R + 4) * WP * 128;       // gband[R][W][128 bytes]
+  const int c0 = blockIdx.x * CB, nrows = B * H;
+  const int pair = tid % NPAIR, seg = tid / NPAIR, row = seg / SPR, sx = seg % SPR;
+  const int x_lo = seg_x0(sx, SPR, W), x_hi = seg_x0(sx + 1, SPR, W);
+  float acc0[26], acc1[26];
+#pragma unroll
+  for (int k = 0; k < 26; ++k) acc0[k] = acc1[k] = 0.f;
+  for (int r0 = blockIdx.y * DW_ROWS; r0 < (blockIdx.y + 1) * DW_ROWS && r0 < nrows; r0 += R) {
+    const int b = r0 / H, y0 = r0 - b * H;                               // H % R == 0
+    __syncthreads();                                                     // the previous band has been consumed
+    stage_band<T, R, true>(in, mask, b, y0, H, W, C, c0, ms, mgw, mL, band, tid);
+    for (int i = tid; i < R * W * 8; i += 256) {
+      const int ch = i & 7, pos = i >> 3;
+      *reinterpret_cast<uint4 *>(gband + (int64_t)pos * 128 + ch * 16) =
+          *reinterpret_cast<const uint4 *>(dout + ((int64_t)r0 * W + pos) * C + c0 + ch * EPC);
+    }
+    __syncthreads();
+    if (x_lo < x_hi) {
+      const char *brow = band + ((int64_t)row * WP) * 128 + pair * 2 * sizeof(T);
+      const char *grow = gband + ((int64_t)row * W) * 128 + pair * 2 * sizeof(T);
+      float w0[5][5], w1[5][5];
+      auto load_col = [&](int bc, int kj) {
+#pragma unroll
+        for (int ki = 0; ki < 5; ++ki) ld2<T>(reinterpret_cast<const T *>(brow + ((int64_t)ki * WP + bc) * 128), w0[ki][kj], w1[ki][kj]);
+      };
+      load_col(x_lo, 0); load_col(x_lo + 1, 1); load_col(x_lo + 2, 2); load_col(x_lo + 3, 3);
+      for (int x = x_lo; x < x_hi; ++x) {
+        load_col(x + 4, 4);
+        float g0, g1;
+        ld2<T>(reinterpret_cast<const T *>(grow + (int64_t)x * 128), g0, g1);
+        acc0[25] += g0; acc1[25] += g1;
+#pragma unroll
+        for (int ki = 0; ki < 5; ++ki)
+#pragma unroll
+          for (int kj = 0; kj < 5; ++kj) {
+            acc0[ki * 5 + kj] += g0 * w0[ki][kj];
+            acc1[ki * 5 + kj] += g1 * w1[ki][kj];
+          }
+#pragma unroll
+        for (int ki = 0; ki < 5; ++ki)
+#pragma unroll
+          for (int kj = 0; kj < 4; ++kj) { w0[ki][kj] = w0[ki][kj + 1]; w1[ki][kj] = w1[ki][kj + 1]; }
+      }
+    }
+  }
+  // the NSEG segments of a channel pair meet in LDS (reusing the band): red[seg][26][CB]
+  __syncthreads();
+  float *red = reinterpret_cast<float *>(smem);
+#pragma unroll
+  for (int k = 0; k < 26; ++k) {
+    red[((int64_t)seg * 26 + k) * CB + pair * 2] = acc0[k];
+    red[((int64_t)seg * 26 + k) * CB + pair * 2 + 1] = acc1[k];
+  }
+  __syncthreads();
+  for (int e = tid; e < 26 * CB; e += 256) {
+    const int k = e / CB, cc = e % CB;
+    float sum = 0.f;
+    for (int sg = 0; sg < NSEG; ++sg) sum += red[((int64_t)sg * 26 + k) * CB + cc];
+    part[((int64_t)blockIdx.y * 26 + k) * C + c0 + cc] = sum;
+  }
+}
+
+template <typename T> static inline bool band_ok(int H, int W, int C) {
+  return H % 4 == 0 && DW_ROWS % 2 == 0 && W >= 8 && W <= 64 && C % BandCfg<T>::CB == 0;
+}
+template <typename T> static inline size_t band_smem_fwd(int W) { return (size_t)8 * (W + 4) * 128; }
+template <typename T> static inline size_t band_smem_bwdw(int W) {
+  const size_t a = (size_t)6 * (W + 4) * 128 + (size_t)2 * W * 128, r = (size_t)BandCfg<T>::NSEG * 26 * BandCfg<T>::CB * sizeof(float);
+  return a > r ? a : r;
+}
+
 // dw[c*25 + k] = sum_slab part[slab][k][c] (k < 25), dbias[c] = sum_slab part[slab][25][c]
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_finalize(const float *part, int nslab, int C, float *dw, float *dbias) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -222,6 +427,8 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_finalize(const float *p
   if (k < 25) dw[c * 25 + k] = s;
   else dbias[c] = s;
 }
+
+static int g_dwconv_band = 1;                 // 0: the row walkers (A/B, evp_dwconv_set_band)
 
 static inline int ew_grid(int64_t n) {
   int64_t g = (n + 255) / 256;
@@ -275,12 +482,27 @@ extern "C" int evp_dwconv5x5_fwd(const void *in, int dtype, const float *mask, i
   const int64_t n = (int64_t)B * H * W * (C / 4);
   hipStream_t s = (hipStream_t)stream;
   (void)n;
+  if (g_dwconv_band && (dtype == EVP_F32 ? band_ok<float>(H, W, C) : band_ok<bf16_t>(H, W, C))) {
+    auto go = [&](auto kfn, auto tag) {
+      using T = decltype(tag);
+      const size_t sm = band_smem_fwd<T>(W);
+      if (sm > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+      hipLaunchKernelGGL(kfn, dim3((unsigned)(C / BandCfg<T>::CB), (unsigned)((int64_t)B * H / 4)), dim3(256), sm, s, (const T *)in, mask, w, bias, B,
+                         H, W, C, mask_scale, mgw, mL, (T *)out);
+    };
+    if (dtype == EVP_F32) go(dwconv_band_kernel<float, false>, float{});
+    else go(dwconv_band_kernel<bf16_t, false>, bf16_t{});
+    EVP_CHECK_LAUNCH("evp_dwconv5x5_fwd(band)");
+    return EVP_OK;
+  }
   const dim3 rg((unsigned)((C + 127) / 128), (unsigned)(((int64_t)B * H + 4 * DWF_RPW - 1) / (4 * DWF_RPW)));
   if (dtype == EVP_F32) hipLaunchKernelGGL((dwconv_rows_kernel<float, false>), rg, dim3(256), 0, s, (const float *)in, mask, w, bias, B, H, W, C, mask_scale, mgw, mL, (float *)out);
   else hipLaunchKernelGGL((dwconv_rows_kernel<bf16_t, false>), rg, dim3(256), 0, s, (const bf16_t *)in, mask, w, bias, B, H, W, C, mask_scale, mgw, mL, (bf16_t *)out);
   EVP_CHECK_LAUNCH("evp_dwconv5x5_fwd");
   return EVP_OK;
 }
+
+extern "C" int evp_dwconv_set_band(int on) { g_dwconv_band = on ? 1 : 0; return EVP_OK; }
 
 extern "C" int evp_dwconv5x5_bwd_nslab(int B, int H, int W) { (void)W; return (int)(((int64_t)B * H + DW_ROWS - 1) / DW_ROWS); }
 
@@ -293,6 +515,24 @@ extern "C" int evp_dwconv5x5_bwd(const void *dout, const void *in, int dtype, co
   const int nslab = evp_dwconv5x5_bwd_nslab(B, H, W);
   dim3 wg((C + 127) / 128, nslab);
   (void)n;
+  if (g_dwconv_band && (dtype == EVP_F32 ? band_ok<float>(H, W, C) : band_ok<bf16_t>(H, W, C))) {
+    auto go = [&](auto kd, auto kw, auto tag) {
+      using T = decltype(tag);
+      const size_t sd = band_smem_fwd<T>(W), sw = band_smem_bwdw<T>(W);
+      if (sd > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sd);
+      if (sw > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sw);
+      hipLaunchKernelGGL(kd, dim3((unsigned)(C / BandCfg<T>::CB), (unsigned)((int64_t)B * H / 4)), dim3(256), sd, s, (const T *)dout, mask, w,
+                         (const float *)nullptr, B, H, W, C, mask_scale, mgw, mL, (T *)din);
+      hipLaunchKernelGGL(kw, dim3((unsigned)(C / BandCfg<T>::CB), (unsigned)nslab), dim3(256), sw, s, (const T *)dout, (const T *)in, mask, B, H, W, C,
+                         mask_scale, mgw, mL, workspace);
+    };
+    if (dtype == EVP_F32) go(dwconv_band_kernel<float, true>, dwconv_bwd_weight_band_kernel<float>, float{});
+    else go(dwconv_band_kernel<bf16_t, true>, dwconv_bwd_weight_band_kernel<bf16_t>, bf16_t{});
+    EVP_CHECK_LAUNCH("evp_dwconv5x5_bwd(band)");
+    hipLaunchKernelGGL(dwconv_bwd_weight_finalize, dim3((26 * C + 255) / 256), dim3(256), 0, s, workspace, nslab, C, dw, dbias);
+    EVP_CHECK_LAUNCH("evp_dwconv5x5_bwd(finalize)");
+    return EVP_OK;
+  }
   const dim3 rg((unsigned)((C + 127) / 128), (unsigned)(((int64_t)B * H + 4 * DWF_RPW - 1) / (4 * DWF_RPW)));
   if (dtype == EVP_F32) {
     hipLaunchKernelGGL((dwconv_rows_kernel<float, true>), rg, dim3(256), 0, s, (const float *)dout, mask, w, (const float *)nullptr, B, H, W, C, mask_scale, mgw, mL, (float *)din);

@@ -255,6 +255,9 @@ int evp_dwconv5x5_fwd(const void *in, int dtype, const float *mask, int mask_sca
 /* din (dtype), dw float32 [C,25], dbias float32 [C] (both overwritten); workspace float32
  * [evp_dwconv5x5_bwd_nslab(B,H,W) * 26 * C]. `in` is the un-masked forward input. */
 int evp_dwconv5x5_bwd_nslab(int B, int H, int W);
+/* A/B switch (process-wide): 1 (default) = LDS-band kernels where the shape allows (H % 4 == 0, 8 <= W <= 64, C a multiple of
+ * 64 (bf16) / 32 (f32)), 0 = the register row walkers everywhere. Results agree to f32 summation order. */
+int evp_dwconv_set_band(int on);
 int evp_dwconv5x5_bwd(const void *dout, const void *in, int dtype, const float *mask, int mask_scale, const float *w, int B,
                       int H, int W, int C, void *din, float *dw, float *dbias, float *workspace, void *stream);
 

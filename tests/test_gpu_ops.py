@@ -217,3 +217,59 @@ def test_fused_adamw_matches_torch_adamw():
     for r, m in zip(ref, mine):
         assert torch.allclose(m.detach().cpu().double(), r.detach(), atol=2e-6, rtol=1e-5)
     assert torch.equal(sh.cpu(), mine[0].detach().cpu().bfloat16()), "bf16 shadow not refreshed by the optimizer step"
+
+
+# ------------------------------------------------------------------------------------------------ depthwise 5x5 (ConvViT)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C,scale", [(3, 56, 56, 128, 4), (2, 28, 28, 192, 2), (2, 12, 20, 64, 4), (1, 8, 8, 64, 0)])
+def test_dwconv5x5_band_and_row_kernels_vs_conv2d(dtype, B, H, W, C, scale):
+    """ConvBlock's depthwise conv with the keep mask fused (conv_block.py:41-51): forward, data gradient, weight and bias gradient
+    of the LDS-band kernels and of the register row walkers against torch's conv2d in float64; the two kernel forms agree with
+    each other to summation order."""
+    import torch.nn.functional as F
+    from eventpretrain_amd._lib import call, dt, ptr, stream_ptr
+    g = torch.Generator().manual_seed(B * 100 + W)
+    x = torch.randn(B, H, W, C, generator=g)
+    dy = torch.randn(B, H, W, C, generator=g)
+    if dtype == torch.bfloat16:
+        x, dy = x.bfloat16().float(), dy.bfloat16().float()
+    w = torch.randn(C, 1, 5, 5, generator=g) * 0.2
+    bias = torch.randn(C, generator=g)
+    mask = None
+    keep = torch.ones(B, 1, H, W, dtype=torch.float64)
+    if scale:
+        mask = (torch.rand(B, (H // scale) * (W // scale), generator=g) < 0.5).float()
+        keep = (1 - mask.double()).view(B, 1, H // scale, W // scale).repeat_interleave(scale, 2).repeat_interleave(scale, 3)
+    xr = x.double().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wr = w.double().clone().requires_grad_(True)
+    br = bias.double().clone().requires_grad_(True)
+    yr = F.conv2d(xr * keep, wr, br, padding=2, groups=C)
+    yr.backward(dy.double().permute(0, 3, 1, 2))
+    want = (yr.detach().permute(0, 2, 3, 1), xr.grad.permute(0, 2, 3, 1), wr.grad.view(C, 25), br.grad)
+
+    xd, dyd, wd, bd = x.to(dtype).cuda(), dy.to(dtype).cuda(), w.view(C, 25).cuda().contiguous(), bias.cuda()
+    md = mask.cuda() if mask is not None else None
+    got = {}
+    try:
+        for band in (1, 0):
+            call("evp_dwconv_set_band", band)
+            y = torch.full((B, H, W, C), float("nan"), dtype=dtype, device="cuda")
+            call("evp_dwconv5x5_fwd", ptr(xd), dt(xd), ptr(md), int(scale), ptr(wd), ptr(bd), B, H, W, C, ptr(y), stream_ptr())
+            ns = call("evp_dwconv5x5_bwd_nslab", B, H, W)
+            ws = torch.full((ns * 26 * C,), float("nan"), device="cuda")
+            dx = torch.full((B, H, W, C), float("nan"), dtype=dtype, device="cuda")
+            dw = torch.full((C, 25), float("nan"), device="cuda")
+            db = torch.full((C,), float("nan"), device="cuda")
+            call("evp_dwconv5x5_bwd", ptr(dyd), ptr(xd), dt(xd), ptr(md), int(scale), ptr(wd), B, H, W, C, ptr(dx), ptr(dw), ptr(db), ptr(ws),
+                 stream_ptr())
+            torch.cuda.synchronize()
+            got[band] = (y.float().cpu(), dx.float().cpu(), dw.cpu(), db.cpu())
+    finally:
+        call("evp_dwconv_set_band", 1)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    for band in (1, 0):
+        for t, r, name in zip(got[band], want, ("y", "dx", "dw", "db")):
+            scale_ = max(1.0, r.abs().max().item())
+            assert torch.allclose(t.double(), r, atol=tol * scale_, rtol=tol), (band, name, (t.double() - r).abs().max().item())
+    for a, b_, name in zip(got[1], got[0], ("y", "dx", "dw", "db")):
+        assert torch.allclose(a, b_, atol=1e-5 * max(1.0, b_.abs().max().item()), rtol=1e-5 if dtype == torch.float32 else 1e-2), name
