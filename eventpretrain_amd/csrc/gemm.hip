@@ -697,9 +697,10 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m,
     using GA = GStage<TA, BM, NT, BK>;
     using GB = GStage<TB, BN, NT, BK>;
     constexpr int INFLIGHT = GA::PER_WAVE + GB::PER_WAVE;   // LDS-DMA pieces per wave and tile
-    static_assert(INFLIGHT == 8 || INFLIGHT == 6 || INFLIGHT == 4, "add the vmcnt literal for this tile shape");
+    static_assert(INFLIGHT == 8 || INFLIGHT == 7 || INFLIGHT == 6 || INFLIGHT == 4, "add the vmcnt literal for this tile shape");
     auto wait_all_but_newest_tile = [] {
       if constexpr (INFLIGHT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (INFLIGHT == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
       else if constexpr (INFLIGHT == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     };
@@ -1975,6 +1976,13 @@ template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(cons
     // it stays selectable explicitly for A/B runs
     (void)t256;
     tile = (d->M >= 128 && d->N >= 128 && (t128 >= 192 || splittable)) ? 1 : 2;
+    // One round of 128 x 128 tiles that leaves some CUs with two workgroups and the rest with one (257..384 tiles) ends when the
+    // doubly loaded CUs do; 96 x 128 tiles still fit one round (<= 512) and are 25 % smaller: -13..16 % on the 6272 x 768 outputs
+    // of the encoder (294 -> 396 tiles; tools/gemm_tiles.py), bit-identical results (same k order per element).
+    if constexpr (sizeof(T) == 2 && !TA) {
+      const int64_t t96 = (int64_t)((d->M + 95) / 96) * ((d->N + 127) / 128) * nb;
+      if (tile == 1 && g_gemm_variant != 2 && nb == 1 && t128 > 256 && t96 <= 512) tile = 4;
+    }
   }
   // bf16: LDS-DMA staging (variant 1, default) or register staging (variant 2, kept for A/B runs); f32: registers
   if constexpr (sizeof(T) == 2 && !TA) {
@@ -2027,8 +2035,9 @@ template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(cons
   if constexpr (sizeof(T) == 2) {
     if (g_gemm_variant != 2) {
       if (tile == 3) return launch<T, TC, EPI, TA, TB, 256, 128, 4, 2, true, 3>(d, s);   // 8 waves, 144 KiB ring
-      if (tile == 4) return launch<T, TC, EPI, TA, TB, 128, 128, 2, 2, true, 2, 32, 3>(d, s);   // BK 32, 32 KiB: 3+ blocks / CU
-      if (tile == 5) return launch<T, TC, EPI, TA, TB, 128, 128, 2, 2, true, 2, 32, 4>(d, s);   // BK 32, <=128 VGPR: 4 blocks / CU
+      // 96 x 128: for launches whose 128 x 128 tiling leaves most CUs with one workgroup and a few with two (294 tiles of a
+      // 6272 x 768 output -> 396 tiles): the launch ends when the doubly loaded CUs do, and their tiles are 25 % smaller
+      if (tile == 4) return launch<T, TC, EPI, TA, TB, 96, 128, 2, 2, true, 2>(d, s);
       if (tile == 1) return launch<T, TC, EPI, TA, TB, 128, 128, 2, 2, true, 2>(d, s);
       return launch<T, TC, EPI, TA, TB, 64, 64, 2, 2, true, 2>(d, s);
     }

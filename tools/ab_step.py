@@ -24,6 +24,7 @@ VARIANTS = {
     "nodefer": {"set_deferred_grads": False},
     "now256": {"set_wgrad256": False},
     "nog4": {"set_wgrad_g4": False},
+    "no96": {"_no96": True},                  # 128x128 tiles where the launcher would pick 96x128 (257..384 tiles)
     "noguard": {"_guard_tables": False},     # host free to run ahead (the scalar-table race the guard closes)
 }
 
@@ -35,7 +36,20 @@ def apply(cfg):
             getattr(ops, k)(v)
 
 
+_orig_gemm = ops.gemm
+
+
+def _gemm_no96(a, b, out, *, M, N, K, tile=0, trans_a=False, **kw):
+    if tile == 0 and not trans_a and a.dtype == torch.bfloat16:
+        t128 = ((M + 127) // 128) * ((N + 127) // 128)
+        t96 = ((M + 95) // 96) * ((N + 127) // 128)
+        if M >= 128 and N >= 128 and 256 < t128 and t96 <= 512 and kw.get("batch", (1, 1)) == (1, 1):
+            tile = 1
+    return _orig_gemm(a, b, out, M=M, N=N, K=K, tile=tile, trans_a=trans_a, **kw)
+
+
 def build(B, cfg):
+    ops.gemm = _gemm_no96 if cfg.get("_no96") else _orig_gemm
     apply(cfg)
     a = make_args(model_size="base", pr_phase="rec", device="cuda", batch_size=B)
     torch.manual_seed(1)
@@ -47,6 +61,7 @@ def build(B, cfg):
     ex = GraphedStep(m, opt, fwd, [x, y], noise_shape=(B, 196), generator=torch.Generator(device="cuda").manual_seed(1), warmup=3)
     assert ex.note.startswith("hip-graph"), ex.note
     ex.guard_tables = cfg.get("_guard_tables", True)
+    ops.gemm = _orig_gemm
     apply({})
     return ex
 
