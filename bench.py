@@ -149,8 +149,12 @@ class GemmTimer:
         splittable = bool(kw.get("trans_a")) and out.dtype == torch.float32 and kw.get("bias") is None and act == 0 and kw.get("residual") is None \
             and kw.get("aux") is None and nb == (1, 1) and K >= 2048
         tile = kw.get("tile", 0) or (1 if (M >= 128 and N >= 128 and (t128 >= 192 or splittable)) else 2)
+        # the launcher's own rule (gemm.hip pick_tile): 96x128 tiles when 128x128 would give 257..384 tiles of one round
+        t96 = ((M + 95) // 96) * ((N + 127) // 128)
+        if not kw.get("tile", 0) and tile == 1 and a.dtype == torch.bfloat16 and not kw.get("trans_a") and nb == (1, 1) and t128 > 256 and t96 <= 512:
+            tile = 4
         return ("bf16" if a.dtype == torch.bfloat16 else "f32", "f32" if out.dtype == torch.float32 else "bf16", epi,
-                int(bool(kw.get("trans_a"))), int(bool(kw.get("trans_b"))), {1: "128x128", 2: "64x64"}.get(tile, str(tile)))
+                int(bool(kw.get("trans_a"))), int(bool(kw.get("trans_b"))), {1: "128x128", 2: "64x64", 4: "96x128"}.get(tile, str(tile)))
 
     def summary(self, reps=10):
         sigs = {}
@@ -469,9 +473,9 @@ def main():
         ks.sort(key=lambda d: -d["ms_per_step"])
         if ks:
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
-            # dominant kernel = the FAMILY with the most time: the 128x128-tile forward / data-gradient GEMM, whose
+            # dominant kernel = the FAMILY with the most time: the 128x128 / 96x128-tile forward / data-gradient GEMM, whose
             # instantiations (layout x epilogue x output type) rocprofv3 lists under separate names
-            fam = [d for d in ks if d["kernel"].startswith("gemm_kernel<") and "128x128" in d["kernel"]]
+            fam = [d for d in ks if d["kernel"].startswith("gemm_kernel<") and ("128x128" in d["kernel"] or "96x128" in d["kernel"])]
             grp = [d for d in ks if "grouped" in d["kernel"]]
 
             def fam_entry(ds, name, note):
@@ -483,7 +487,7 @@ def main():
                     "call re-launched 10x between two events on the launch stream)")
             entries = []
             if fam:
-                entries.append(fam_entry(fam, "gemm_kernel<...,tile=128x128> (forward + data-gradient GEMM family, %d instantiations)" % len(fam), note))
+                entries.append(fam_entry(fam, "gemm_kernel<...,tile=128x128|96x128> (forward + data-gradient GEMM family, %d instantiations)" % len(fam), note))
             if grp:
                 entries.append(fam_entry(grp[:1], grp[0]["kernel"], note))
             entries.sort(key=lambda e_: -e_["ms_per_step_in_kernel"])
