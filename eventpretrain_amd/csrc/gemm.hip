@@ -1599,370 +1599,9 @@ static int launch_g4_tn(const evp_gemm_desc *d, hipStream_t s) {
   return EVP_OK;
 }
 
-// ---- persistent form of the 128x128x64 bf16 LDS-DMA body ------------------------------------------------------------
-// At this path's shapes (K = 512..3072, 300-1600 tiles) a third of a GEMM's time was per-tile fixed cost: workgroup
-// launch, the first operand loads' latency, the epilogue's stores draining before the workgroup retires. Here 2 x 256
-// workgroups stay resident and each walks tiles w, w+G, ...; the K loop is ONE pipeline over (tile, k) pairs with two K
-// tiles of LDS-DMA in flight, so the next tile's first operands stream in under the current tile's last MFMAs and its
-// epilogue, and the epilogue's stores drain under the next tile's MFMAs.
-// vmcnt accounting: at the top of iteration j the outstanding vector-memory ops are, oldest first, [loads of j]
-// [loads of j+1] and possibly [epilogue stores of the previous tile] between or after them. vmcnt(8) proves the loads
-// of j have landed whatever the stores do: loads complete in order, so one missing load of j means all 8 of j+1 are
-// missing too -- 9 outstanding.
-template <typename TC, int EPI, bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmParams p, const int ntiles) {
-  constexpr int BM = 128, BN = 128, BK = 64, NT = 256, MI = 4, NI = 4;
-  constexpr int A_BYTES = Img<bf16_t, TA, BM, BK>::BYTES, B_BYTES = Img<bf16_t, TB, BN, BK>::BYTES, STAGE_BYTES = A_BYTES + B_BYTES;
-  using GA = GStage<TA, BM, NT, BK>;
-  using GB = GStage<TB, BN, NT, BK>;
-  static_assert(GA::PER_WAVE + GB::PER_WAVE == 8, "vmcnt(8) below assumes 8 LDS-DMA pieces per wave and K tile");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const bf16_t *A = reinterpret_cast<const bf16_t *>(p.A);
-  const bf16_t *B = reinterpret_cast<const bf16_t *>(p.B);
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(A), 0, 0x7FFFFFFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(B), 0, 0x7FFFFFFF, 0x00020000);
-  const int lda = (int)p.lda, ldb = (int)p.ldb;
-  const int nk = (p.K + BK - 1) / BK;
-  const int G = gridDim.x;
-  int tile = blockIdx.x;
-  if (tile >= ntiles) return;
-  const int my_tiles = (ntiles - tile + G - 1) / G;
-  const int J = my_tiles * nk;                 // K iterations of this workgroup
-
-  // (tile, k) of the next LDS-DMA issue
-  int ld_tile = tile, ld_k = 0, ld_m0, ld_n0;
-  {
-    int tm, tn;
-    map_tile(ntiles, ld_tile, p.tiles_m, tm, tn);
-    ld_m0 = tm * BM; ld_n0 = tn * BN;
-  }
-  auto issue_next = [&](int stage) {
-    char *img = smem + stage * STAGE_BYTES;
-    GA::issue(rsA, lda, ld_m0, ld_k * BK, p.M, p.K, img, wave, lane);
-    GB::issue(rsB, ldb, ld_n0, ld_k * BK, p.N, p.K, img + A_BYTES, wave, lane);
-    if (++ld_k == nk) {
-      ld_k = 0;
-      ld_tile += G;
-      int tm, tn;
-      map_tile(ntiles, ld_tile < ntiles ? ld_tile : tile, p.tiles_m, tm, tn);
-      ld_m0 = tm * BM; ld_n0 = tn * BN;
-    }
-  };
-
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  issue_next(0);
-  if (J > 1) issue_next(1);
-  int cm0, cn0;                                 // tile being computed
-  {
-    int tm, tn;
-    map_tile(ntiles, tile, p.tiles_m, tm, tn);
-    cm0 = tm * BM; cn0 = tn * BN;
-  }
-  int k_in_tile = 0;
-  int landed = 0;                               // K iterations ahead whose operands are already known to be in LDS
-  const int li = lane & 15, lg = lane >> 4;
-  unsigned long long t_begin = 0, t_epi = 0, t_mark = 0;
-  if (p.dbgbuf) t_begin = __builtin_readcyclecounter();
-  for (int j = 0; j < J; ++j) {
-    if (landed > 0) --landed;
-    else if (j + 1 < J) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const char *ia = smem + (j & 1) * STAGE_BYTES, *ib = ia + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 af[MI], bf[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = frag_bf16<TA, BM, BK>(ia, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int jn = 0; jn < NI; ++jn) bf[jn] = frag_bf16<TB, BN, BK>(ib, wn * 64 + jn * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int jn = 0; jn < NI; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[jn], af[i], acc[i][jn], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (j + 2 < J) issue_next(j & 1);
-    if (++k_in_tile == nk) {
-      // Let both in-flight K tiles land BEFORE the stores are issued: the next two iterations then need no vmcnt wait
-      // at all, and the first counted wait after them (vmcnt(8), two iterations on) finds the stores long retired. A
-      // counted wait right after the stores would have to sit out their whole HBM round trip.
-      if (j + 1 < J) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        landed = 2;
-      }
-      if (p.dbgbuf) t_mark = __builtin_readcyclecounter();
-      epilogue<TC, EPI, MI, NI>(acc, p, 0, cm0 + wm * 64 + li, cn0 + wn * 64 + lg * 4, true);
-      if (p.dbgbuf) t_epi += __builtin_readcyclecounter() - t_mark;
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int jn = 0; jn < NI; ++jn) acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
-      k_in_tile = 0;
-      tile += G;
-      if (tile < ntiles) {
-        int tm, tn;
-        map_tile(ntiles, tile, p.tiles_m, tm, tn);
-        cm0 = tm * BM; cn0 = tn * BN;
-      }
-    }
-  }
-  if (p.dbgbuf && tid == 0) {
-    p.dbgbuf[blockIdx.x * 4 + 0] = __builtin_readcyclecounter() - t_begin;
-    p.dbgbuf[blockIdx.x * 4 + 1] = t_epi;
-    p.dbgbuf[blockIdx.x * 4 + 2] = my_tiles;
-    p.dbgbuf[blockIdx.x * 4 + 3] = t_begin;
-  }
-}
-
-template <typename TC, int EPI, bool TA, bool TB> int launch_persist(const evp_gemm_desc *d, hipStream_t s) {
-  GemmParams p;
-  p.M = d->M; p.N = d->N; p.K = d->K;
-  p.A = d->A; p.lda = d->lda; p.sA0 = 0; p.sA1 = 0;
-  p.B = d->B; p.ldb = d->ldb; p.sB0 = 0; p.sB1 = 0;
-  p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = 0; p.sC1 = 0;
-  p.batch1 = 1;
-  p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
-  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = g_gemm_dbg; p.dbgbuf = g_gemm_dbgbuf; p.colsum = nullptr; p.colsum_acc = 0;
-  p.tiles_m = (d->M + 127) / 128;
-  p.splitk = 1; p.k_per_split = d->K;
-  const int ntiles = p.tiles_m * ((d->N + 127) / 128);
-  constexpr int smem = 2 * (Img<bf16_t, TA, 128, 64>::BYTES + Img<bf16_t, TB, 128, 64>::BYTES);
-  auto k = gemm_persist_kernel<TC, EPI, TA, TB>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { evp_set_error("evp_gemm: hipFuncSetAttribute(%d) failed: %s", smem, hipGetErrorString(e)); return EVP_ELAUNCH; }
-    attr_done = true;
-  }
-  const int grid = ntiles < 512 ? ntiles : 512;       // 2 workgroups per CU; a multiple of 8 keeps tile % 8 == XCD
-  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), smem, s, p, ntiles);
-  EVP_CHECK_LAUNCH("evp_gemm");
-  return EVP_OK;
-}
-
-
-// ---- persistent 128x128x64 kernel with the epilogue folded into the next tile's K loop -----------------------------------
-// Measured on the plain persistent kernel above (cycle counters, tools/gemm_epi_probe.py): a finished tile's 16 store
-// instructions per lane took ~5.7k cycles against ~29k for the tile's K loop -- and 1.3k when only a quarter of them was
-// issued. All 512 resident workgroups finish a tile at about the same moment, so every round ends in a 16-32 MB write
-// burst and the waves sit in store back-pressure. Here a finished tile's accumulators are parked in a second register
-// set and written out one 16-row group per K iteration during the first four iterations of the NEXT tile; the
-// residual / aux operands of a group are fetched one iteration ahead. Stores and operand loads are issued right after the
-// top-of-iteration barrier, i.e. a whole MFMA phase before the next counted wait has to see them retired:
-//   top:  s_waitcnt vmcnt(8) ; s_barrier             outstanding then = the 8 LDS-DMA pieces of iteration j+1 at most
-//   [A]   math + stores of row group q (operands fetched in the previous iteration)
-//   [B]   operand loads of row group q+1
-//         MFMAs of iteration j ; s_barrier
-//   [C]   LDS-DMA of iteration j+2
-// vmcnt(8) at the next top is safe whatever order stores and loads retire in: the loads of j+1 are older than the 8
-// pieces of j+2 and loads complete in order, so a missing piece of j+1 leaves at least 9 outstanding.
-// Needs M % 128 == N % 128 == K % 64 == 0, K >= 256, no accumulate (the launcher falls back otherwise).
-template <typename TC, int EPI, bool TA, bool TB, bool RES>
-__global__ __launch_bounds__(256, 2) void gemm_persist2_kernel(const GemmParams p, const int ntiles) {
-  constexpr int BM = 128, BN = 128, BK = 64, NT = 256, MI = 4, NI = 4;
-  constexpr int A_BYTES = Img<bf16_t, TA, BM, BK>::BYTES, B_BYTES = Img<bf16_t, TB, BN, BK>::BYTES, STAGE_BYTES = A_BYTES + B_BYTES;
-  using GA = GStage<TA, BM, NT, BK>;
-  using GB = GStage<TB, BN, NT, BK>;
-  static_assert(GA::PER_WAVE + GB::PER_WAVE == 8, "vmcnt(8) below assumes 8 LDS-DMA pieces per wave and K tile");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 15, lg = lane >> 4;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.A), 0, 0x7FFFFFFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.B), 0, 0x7FFFFFFF, 0x00020000);
-  const int lda = (int)p.lda, ldb = (int)p.ldb;
-  const int nk = p.K / BK;
-  const int G = gridDim.x;
-  int tile = blockIdx.x;
-  if (tile >= ntiles) return;
-  const int my_tiles = (ntiles - tile + G - 1) / G;
-  const int J = my_tiles * nk;
-
-  int ld_tile = tile, ld_k = 0, ld_m0, ld_n0;
-  {
-    int tm, tn;
-    map_tile(ntiles, ld_tile, p.tiles_m, tm, tn);
-    ld_m0 = tm * BM; ld_n0 = tn * BN;
-  }
-  auto issue_next = [&](int stage) {
-    char *img = smem + stage * STAGE_BYTES;
-    GA::issue(rsA, lda, ld_m0, ld_k * BK, p.M, p.K, img, wave, lane);
-    GB::issue(rsB, ldb, ld_n0, ld_k * BK, p.N, p.K, img + A_BYTES, wave, lane);
-    if (++ld_k == nk) {
-      ld_k = 0;
-      ld_tile += G;
-      int tm, tn;
-      map_tile(ntiles, ld_tile < ntiles ? ld_tile : tile, p.tiles_m, tm, tn);
-      ld_m0 = tm * BM; ld_n0 = tn * BN;
-    }
-  };
-
-  f32x4 acc[MI][NI], prev[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int jn = 0; jn < NI; ++jn) acc[i][jn] = prev[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // the parked tile: per-lane row-0 pointers, its bias, and the operands of the row group that is written next
-  TC *pC = nullptr, *pAux = nullptr;
-  const float *pRes = nullptr;
-  float4 pbias[NI], oh[NI], orr[NI];
-#pragma unroll
-  for (int jn = 0; jn < NI; ++jn) pbias[jn] = oh[jn] = orr[jn] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  auto fetch_group = [&](auto Qc) {            // [B]: operand loads of row group Q of the parked tile
-    constexpr int Q = decltype(Qc)::value;
-#pragma unroll
-    for (int jn = 0; jn < NI; ++jn) {
-      if constexpr (EPI == 2) oh[jn] = ld4<TC>(pAux + (int64_t)Q * 16 * p.ldaux + jn * 16);
-      if constexpr (RES) orr[jn] = *reinterpret_cast<const float4 *>(pRes + (int64_t)Q * 16 * p.ldres + jn * 16);
-    }
-  };
-  auto write_group = [&](auto Qc) {            // [A]: epilogue math + stores of row group Q of the parked tile
-    constexpr int Q = decltype(Qc)::value;
-#pragma unroll
-    for (int jn = 0; jn < NI; ++jn) {
-      float4 v = make_float4(prev[Q][jn][0], prev[Q][jn][1], prev[Q][jn][2], prev[Q][jn][3]);     // alpha and bias went in at park()
-      if constexpr (EPI == 1) {
-        st4<TC>(pAux + (int64_t)Q * 16 * p.ldaux + jn * 16, v);
-        if (p.act == EVP_ACT_GELU) v = gelu4(v, true);
-        else v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-      } else if constexpr (EPI == 2) {
-        if (p.act == EVP_ACT_DGELU) v = dgelu_mul4(v, oh[jn], true);
-        else v = make_float4(oh[jn].x > 0.f ? v.x : 0.f, oh[jn].y > 0.f ? v.y : 0.f, oh[jn].z > 0.f ? v.z : 0.f, oh[jn].w > 0.f ? v.w : 0.f);
-      }
-      if constexpr (RES) v = make_float4(v.x + orr[jn].x, v.y + orr[jn].y, v.z + orr[jn].z, v.w + orr[jn].w);
-      st4<TC>(pC + (int64_t)Q * 16 * p.ldc + jn * 16, v);
-    }
-  };
-  // last iteration of a tile, [B] slot: pointers / bias / group-0 operands of the tile about to be parked (the previous
-  // parked tile has been written out by then, so the operand registers are free)
-  auto prefetch_park = [&](int m0, int n0) {
-    const int m = m0 + wm * 64 + li, n = n0 + wn * 64 + lg * 4;
-    pC = reinterpret_cast<TC *>(p.C) + (int64_t)m * p.ldc + n;
-    pAux = reinterpret_cast<TC *>(p.aux) + (int64_t)m * p.ldaux + n;
-    pRes = p.residual + (int64_t)m * p.ldres + n;
-#pragma unroll
-    for (int jn = 0; jn < NI; ++jn)
-      pbias[jn] = p.bias ? *reinterpret_cast<const float4 *>(p.bias + n + jn * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-    fetch_group(std::integral_constant<int, 0>{});
-  };
-  auto park = [&]() {                          // end of a tile: move alpha * acc + bias aside (the bias is only live across one MFMA phase)
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int jn = 0; jn < NI; ++jn) {
-        prev[i][jn] = f32x4{acc[i][jn][0] * p.alpha + pbias[jn].x, acc[i][jn][1] * p.alpha + pbias[jn].y,
-                            acc[i][jn][2] * p.alpha + pbias[jn].z, acc[i][jn][3] * p.alpha + pbias[jn].w};
-        acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-  };
-
-  auto compute = [&](int j) {
-    const char *ia = smem + (j & 1) * STAGE_BYTES, *ib = ia + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 af[MI], bf[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = frag_bf16<TA, BM, BK>(ia, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int jn = 0; jn < NI; ++jn) bf[jn] = frag_bf16<TB, BN, BK>(ib, wn * 64 + jn * 16, ks, lane);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int jn = 0; jn < NI; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[jn], af[i], acc[i][jn], 0, 0, 0);
-    }
-  };
-  // one K iteration; Q >= 0: also write row group Q of the parked tile (and fetch the operands of group Q+1);
-  // last: this iteration finishes the current tile (m0, n0)
-  auto iteration = [&](int j, auto Qc, bool parked, bool last, int m0, int n0) {
-    constexpr int Q = decltype(Qc)::value;
-    if (j + 1 < J) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if constexpr (Q >= 0) {
-      if (parked) {
-        write_group(Qc);
-        if constexpr (Q < 3) fetch_group(std::integral_constant<int, (Q < 3 ? Q + 1 : 3)>{});
-      }
-    }
-    if (last) prefetch_park(m0, n0);
-    compute(j);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (last) park();
-    if (j + 2 < J) issue_next(j & 1);
-  };
-
-  issue_next(0);
-  issue_next(1);                                // nk >= 4, so J >= 4
-  int j = 0;
-  bool parked = false;
-  for (int ti = 0; ti < my_tiles; ++ti) {
-    int tm, tn;
-    map_tile(ntiles, tile, p.tiles_m, tm, tn);
-    const int cm0 = tm * BM, cn0 = tn * BN;
-    iteration(j++, std::integral_constant<int, 0>{}, parked, false, cm0, cn0);
-    iteration(j++, std::integral_constant<int, 1>{}, parked, false, cm0, cn0);
-    iteration(j++, std::integral_constant<int, 2>{}, parked, false, cm0, cn0);
-    iteration(j++, std::integral_constant<int, 3>{}, parked, nk == 4, cm0, cn0);
-    for (int t = 4; t < nk; ++t) iteration(j++, std::integral_constant<int, -1>{}, false, t == nk - 1, cm0, cn0);
-    parked = true;
-    tile += G;
-  }
-  // tail: the last tile of this workgroup
-  write_group(std::integral_constant<int, 0>{});
-  fetch_group(std::integral_constant<int, 1>{});
-  write_group(std::integral_constant<int, 1>{});
-  fetch_group(std::integral_constant<int, 2>{});
-  write_group(std::integral_constant<int, 2>{});
-  fetch_group(std::integral_constant<int, 3>{});
-  write_group(std::integral_constant<int, 3>{});
-}
-
-template <typename TC, int EPI, bool TA, bool TB> int launch_persist2(const evp_gemm_desc *d, hipStream_t s) {
-  GemmParams p;
-  p.M = d->M; p.N = d->N; p.K = d->K;
-  p.A = d->A; p.lda = d->lda; p.sA0 = 0; p.sA1 = 0;
-  p.B = d->B; p.ldb = d->ldb; p.sB0 = 0; p.sB1 = 0;
-  p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = 0; p.sC1 = 0;
-  p.batch1 = 1;
-  p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
-  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = 0; p.dbg = 0; p.dbgbuf = nullptr; p.colsum = nullptr; p.colsum_acc = 0;
-  p.tiles_m = d->M / 128;
-  p.splitk = 1; p.k_per_split = d->K;
-  const int ntiles = p.tiles_m * (d->N / 128);
-  constexpr int smem = 2 * (Img<bf16_t, TA, 128, 64>::BYTES + Img<bf16_t, TB, 128, 64>::BYTES);
-  const int grid = ntiles < 512 ? ntiles : 512;
-  auto go = [&](auto kfn, bool &attr_done) -> int {
-    if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      if (e != hipSuccess) { evp_set_error("evp_gemm: hipFuncSetAttribute(%d) failed: %s", smem, hipGetErrorString(e)); return EVP_ELAUNCH; }
-      attr_done = true;
-    }
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256), smem, s, p, ntiles);
-    EVP_CHECK_LAUNCH("evp_gemm");
-    return EVP_OK;
-  };
-  static bool done_r = false, done_n = false;
-  if (d->residual) return go(gemm_persist2_kernel<TC, EPI, TA, TB, true>, done_r);
-  return go(gemm_persist2_kernel<TC, EPI, TA, TB, false>, done_n);
-}
-
-// shapes the deferred-epilogue persistent kernel takes
-static inline bool persist2_ok(const evp_gemm_desc *d) {
-  const int64_t nbz = (int64_t)(d->batch0 > 0 ? d->batch0 : 1) * (d->batch1 > 0 ? d->batch1 : 1);
-  const bool act_fwd = d->act == EVP_ACT_GELU || d->act == EVP_ACT_RELU;
-  return nbz == 1 && d->M % 128 == 0 && d->N % 128 == 0 && d->K % 64 == 0 && d->K >= 256 && !d->accumulate && d->splitk <= 1 &&
-         (!act_fwd || d->aux) && (d->ldc % 4 == 0);
-}
+// (Two persistent variants of the 128x128 body lived here in round 1 -- one workgroup per CU slot looping over tiles, the second
+// with the C stores of tile i folded into the K loop of tile i+1. Measured: +3..8 % on the largest shapes, slower on the small
+// ones (DESIGN.md section 4 "Epilogues"); never the default, removed in round 2.)
 
 template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(const evp_gemm_desc *d, hipStream_t s) {
   int tile = d->tile;
@@ -1972,9 +1611,7 @@ template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(cons
     const int64_t t256 = (int64_t)((d->M + 255) / 256) * ((d->N + 127) / 128) * nb;
     const bool splittable = d->transA && d->c_dtype == EVP_F32 && !d->bias && d->act == EVP_ACT_NONE && !d->residual &&
                             !d->aux && nb == 1 && d->K >= 2048;
-    // the 256x128 / 3-stage ring variant (tile 3) measured slower than 128x128 at this path's shapes (1 block per CU);
-    // it stays selectable explicitly for A/B runs
-    (void)t256;
+    (void)t256;      // a 256x128 / 3-stage ring variant measured slower than 128x128 at this path's shapes (removed)
     tile = (d->M >= 128 && d->N >= 128 && (t128 >= 192 || splittable)) ? 1 : 2;
     // One round of 128 x 128 tiles that leaves some CUs with two workgroups and the rest with one (257..384 tiles) ends when the
     // doubly loaded CUs do; 96 x 128 tiles still fit one round (<= 512) and are 25 % smaller: -13..16 % on the 6272 x 768 outputs
@@ -1999,20 +1636,7 @@ template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(cons
     if (d->tile == 12) { evp_set_error("evp_gemm: tile 12 (stream-K) is not built for transA"); return EVP_EUNSUPPORTED; }
   }
   if constexpr (sizeof(T) == 2) {
-    if (tile == 8) {        // persistent 128x128 with the epilogue folded into the next tile's K loop
-      if constexpr (!TA) {
-        if (!persist2_ok(d)) { evp_set_error("evp_gemm: tile 8 needs M,N %% 128 == 0, K %% 64 == 0, K >= 256, no batch / accumulate"); return EVP_ESHAPE; }
-        return launch_persist2<TC, EPI, TA, TB>(d, s);
-      } else {
-        evp_set_error("evp_gemm: tile 8 is not built for transA");
-        return EVP_EUNSUPPORTED;
-      }
-    }
-    if (tile == 7) {        // persistent 128x128 (single problem, no split-K)
-      const int64_t nbz = (int64_t)(d->batch0 > 0 ? d->batch0 : 1) * (d->batch1 > 0 ? d->batch1 : 1);
-      if (nbz != 1) { evp_set_error("evp_gemm: tile 7 (persistent) takes no batch"); return EVP_ESHAPE; }
-      return launch_persist<TC, EPI, TA, TB>(d, s);
-    }
+    if (tile == 7 || tile == 8) { evp_set_error("evp_gemm: tiles 7 / 8 (persistent variants) were removed"); return EVP_EUNSUPPORTED; }
     if (tile == 9) {        // G4 body (weight-gradient layout only): 256x256, one wave per SIMD, 32x32x16
       if constexpr (TA && TB && EPI == 0 && std::is_same<TC, float>::value) {
         const int64_t nbz = (int64_t)(d->batch0 > 0 ? d->batch0 : 1) * (d->batch1 > 0 ? d->batch1 : 1);
@@ -2034,7 +1658,6 @@ template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(cons
   }
   if constexpr (sizeof(T) == 2) {
     if (g_gemm_variant != 2) {
-      if (tile == 3) return launch<T, TC, EPI, TA, TB, 256, 128, 4, 2, true, 3>(d, s);   // 8 waves, 144 KiB ring
       // 96 x 128: for launches whose 128 x 128 tiling leaves most CUs with one workgroup and a few with two (294 tiles of a
       // 6272 x 768 output -> 396 tiles): the launch ends when the doubly loaded CUs do, and their tiles are 25 % smaller
       if (tile == 4) return launch<T, TC, EPI, TA, TB, 96, 128, 2, 2, true, 2>(d, s);

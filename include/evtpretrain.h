@@ -117,7 +117,7 @@ typedef struct {
   void *aux; int64_t ldaux;            /* element type = c_dtype; batch strides = C's */
   const float *residual; int64_t ldres; /* batch strides = C's */
   int accumulate;
-  int tile;                             /* 0 auto, 1 = 128x128, 2 = 64x64, 6 = 256x256 ring (bf16, K % 64 == 0), 9 = G4 256x256 (bf16 TN, f32 C, K % 32 == 0), 12 = stream-K 128x128 */
+  int tile;                             /* 0 auto (128x128, 96x128 when 128x128 would give 257..384 tiles, 64x64 for small outputs), 1 = 128x128, 2 = 64x64, 4 = 96x128, 6 = 256x256 ring (bf16, K % 64 == 0), 9 = G4 256x256 (bf16 TN, f32 C, K % 32 == 0), 12 = stream-K 128x128 */
   int splitk;                           /* 0 auto, n = cut K into n slices summed with f32 atomics (plain f32 C only) */
   /* Optional stream-K workspace (bf16, transA = 0, no batch): device memory, >= 4096 + 65536 * 2 * CUs bytes, its first
    * 4096 bytes zeroed ONCE by the caller (the kernel leaves them zero). Used by tile = 12 only (the stream-K form of the
@@ -151,8 +151,8 @@ int evp_sum_slices_f32(const float *ws, float *out, int n_slices, int64_t numel,
 /* Tuning switch for A/B measurements: 1 = LDS-DMA (buffer_load ... lds) staging for bf16 (default), 2 = register
  * staging. Returns the previous value; any other argument only queries. Results are identical. */
 int evp_gemm_set_variant(int v);
-/* Measurement aid: device buffer uint64 [4*512] that the persistent kernel (tile 7) fills per workgroup with
- * {total cycles, cycles inside epilogues, tiles done, start cycle}; NULL (default) switches it off. */
+/* Measurement aid: device buffer uint64 [16 * grid] that the stream-K kernel (tile 12) fills per workgroup with cycle stamps of
+ * its segments; NULL (default) switches it off. */
 int evp_gemm_set_debug_buffer(void *buf);
 
 /* ------------------------------------------------------------------------------------------------ K4/K9 LayerNorm
