@@ -461,25 +461,43 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const void *x, int dtype
   part[((int64_t)blockIdx.y * 2 + 0) * C + c] = mean;
   part[((int64_t)blockIdx.y * 2 + 1) * C + c] = m2;
 }
-__global__ void bn_stats_finalize(const float *part, int nslab, int64_t R, int C, float eps, float momentum, float *mean_out,
-                                  float *invstd_out, float *running_mean, float *running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// 1024 threads = 64 columns x 16 slab groups: each thread folds every 16th slab (Chan's pairwise update, in double), the 16 partial
+// (n, mean, M2) triples of a column then meet in LDS. (One thread per column walking all R / 64 slabs serially took 68 us at
+// R = 12 608, C = 4096: 16 workgroups, a dependent chain of 197 double-precision divisions each.)
+__global__ __launch_bounds__(1024) void bn_stats_finalize(const float *part, int nslab, int64_t R, int C, float eps, float momentum, float *mean_out,
+                                                          float *invstd_out, float *running_mean, float *running_var) {
+  __shared__ double sh[3][16][65];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double mean = 0.0, m2 = 0.0, n = 0.0;
-  for (int s = 0; s < nslab; ++s) {
-    const int64_t r0 = (int64_t)s * BN_ROWS;
-    const double nb = (double)((r0 + BN_ROWS < R ? r0 + BN_ROWS : R) - r0);
-    const double mb = part[((int64_t)s * 2 + 0) * C + c], m2b = part[((int64_t)s * 2 + 1) * C + c];
-    const double delta = mb - mean, tot = n + nb;
-    mean += delta * nb / tot;
-    m2 += m2b + delta * delta * n * nb / tot;
-    n = tot;
+  if (c < C)
+    for (int s = g; s < nslab; s += 16) {
+      const int64_t r0 = (int64_t)s * BN_ROWS;
+      const double nb = (double)((r0 + BN_ROWS < R ? r0 + BN_ROWS : R) - r0);
+      const double mb = part[((int64_t)s * 2 + 0) * C + c], m2b = part[((int64_t)s * 2 + 1) * C + c];
+      const double delta = mb - mean, tot = n + nb;
+      mean += delta * nb / tot;
+      m2 += m2b + delta * delta * n * nb / tot;
+      n = tot;
+    }
+  sh[0][g][cl] = n; sh[1][g][cl] = mean; sh[2][g][cl] = m2;
+  __syncthreads();
+  if (g == 0 && c < C) {
+    for (int i = 1; i < 16; ++i) {
+      const double nb = sh[0][i][cl];
+      if (nb > 0.0) {
+        const double delta = sh[1][i][cl] - mean, tot = n + nb;
+        mean += delta * nb / tot;
+        m2 += sh[2][i][cl] + delta * delta * n * nb / tot;
+        n = tot;
+      }
+    }
+    const float var_b = (float)(m2 / n);
+    mean_out[c] = (float)mean;
+    invstd_out[c] = 1.0f / sqrtf(var_b + eps);
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(m2 / (n > 1.0 ? n - 1.0 : 1.0));
   }
-  const float var_b = (float)(m2 / n);
-  mean_out[c] = (float)mean;
-  invstd_out[c] = 1.0f / sqrtf(var_b + eps);
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-  if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(m2 / (n > 1.0 ? n - 1.0 : 1.0));
 }
 __global__ __launch_bounds__(256) void bn_apply(const void *x, int dtype, int64_t total, int C, const float *gamma,
                                                 const float *beta, const float *mean, const float *invstd, int relu, void *y) {
@@ -509,16 +527,23 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const void *dy, const void
   part[((int64_t)blockIdx.y * 2 + 0) * C + c] = s0;
   part[((int64_t)blockIdx.y * 2 + 1) * C + c] = s1;
 }
-__global__ void bn_bwd_finalize(const float *part, int nslab, int C, float *sum_dy, float *sum_dy_xhat) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(1024) void bn_bwd_finalize(const float *part, int nslab, int C, float *sum_dy, float *sum_dy_xhat) {
+  __shared__ float sh[2][16][65];
+  const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float a = 0.f, b = 0.f;
-  for (int s = 0; s < nslab; ++s) {
-    a += part[((int64_t)s * 2 + 0) * C + c];
-    b += part[((int64_t)s * 2 + 1) * C + c];
+  if (c < C)
+    for (int s = g; s < nslab; s += 16) {
+      a += part[((int64_t)s * 2 + 0) * C + c];
+      b += part[((int64_t)s * 2 + 1) * C + c];
+    }
+  sh[0][g][cl] = a; sh[1][g][cl] = b;
+  __syncthreads();
+  if (g == 0 && c < C) {
+    for (int i = 1; i < 16; ++i) { a += sh[0][i][cl]; b += sh[1][i][cl]; }
+    sum_dy[c] = a;
+    sum_dy_xhat[c] = b;
   }
-  sum_dy[c] = a;
-  sum_dy_xhat[c] = b;
 }
 __global__ __launch_bounds__(256) void bn_bwd_apply(const void *dy, const void *x, const void *y, int dtype, int64_t R, int C,
                                                     const float *gamma, const float *mean, const float *invstd, int relu,
@@ -662,7 +687,7 @@ extern "C" int evp_batchnorm_fwd(const void *x, int dtype, int64_t R, int C, con
   const int ns = evp_batchnorm_nblk(R);
   hipLaunchKernelGGL(bn_stats_partial, dim3((C + 255) / 256, ns), dim3(256), 0, s, x, dtype, R, C, workspace);
   EVP_CHECK_LAUNCH("evp_batchnorm_fwd(stats)");
-  hipLaunchKernelGGL(bn_stats_finalize, dim3((C + 255) / 256), dim3(256), 0, s, workspace, ns, R, C, eps, momentum, mean, invstd, running_mean, running_var);
+  hipLaunchKernelGGL(bn_stats_finalize, dim3((C + 63) / 64), dim3(1024), 0, s, workspace, ns, R, C, eps, momentum, mean, invstd, running_mean, running_var);
   EVP_CHECK_LAUNCH("evp_batchnorm_fwd(finalize)");
   const int64_t total = R * C;
   int64_t g = (total + 255) / 256; if (g > 4096) g = 4096;
@@ -681,7 +706,7 @@ extern "C" int evp_batchnorm_bwd(const void *dy, const void *x, const void *y, i
   float *sum_dy = workspace + (int64_t)ns * 2 * C, *sum_dy_xhat = sum_dy + C;
   hipLaunchKernelGGL(bn_bwd_partial, dim3((C + 255) / 256, ns), dim3(256), 0, s, dy, x, y, dtype, R, C, mean, invstd, relu, workspace);
   EVP_CHECK_LAUNCH("evp_batchnorm_bwd(partial)");
-  hipLaunchKernelGGL(bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, workspace, ns, C, sum_dy, sum_dy_xhat);
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3((C + 63) / 64), dim3(1024), 0, s, workspace, ns, C, sum_dy, sum_dy_xhat);
   EVP_CHECK_LAUNCH("evp_batchnorm_bwd(finalize)");
   const int64_t total = R * C;
   int64_t g = (total + 255) / 256; if (g > 4096) g = 4096;
