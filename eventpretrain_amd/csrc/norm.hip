@@ -560,6 +560,150 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const void *dy, const void *
   }
 }
 
+// ---- 4-column vector forms (C % 4 == 0): 16-byte (f32) / 8-byte (bf16) accesses instead of one element per lane; a block is 64
+// column groups x 4 row lanes over one slab of BN_ROWS rows, the row lanes meet in LDS -------------------------------------------
+__device__ __forceinline__ float4 ld4_any(const void *p, int dtype, int64_t i) {
+  if (dtype == EVP_BF16) {
+    const uint2 u = *reinterpret_cast<const uint2 *>(reinterpret_cast<const bf16_t *>(p) + i);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+  }
+  return *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p) + i);
+}
+__device__ __forceinline__ void st4_any(void *p, int dtype, int64_t i, float4 v) {
+  if (dtype == EVP_BF16) {
+    uint2 u;
+    u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2 *>(reinterpret_cast<bf16_t *>(p) + i) = u;
+  } else {
+    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p) + i) = v;
+  }
+}
+__global__ __launch_bounds__(256) void bn_stats_partial_v4(const void *x, int dtype, int64_t R, int C, float *part) {
+  __shared__ float sh[3][4][260];
+  const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + cg * 4;
+  const int64_t r0 = (int64_t)blockIdx.y * BN_ROWS;
+  const int64_t r1 = r0 + BN_ROWS < R ? r0 + BN_ROWS : R;
+  float mean[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+  int n = 0;
+  if (c < C)
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      const float4 v4 = ld4_any(x, dtype, r * C + c);
+      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+      ++n;
+      const float inv = 1.0f / (float)n;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = v[j] - mean[j];
+        mean[j] += d * inv;
+        m2[j] += d * (v[j] - mean[j]);
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sh[0][rl][cg * 4 + j] = (float)n; sh[1][rl][cg * 4 + j] = mean[j]; sh[2][rl][cg * 4 + j] = m2[j]; }
+  __syncthreads();
+  const int cc = threadIdx.x;                      // one column per thread for the combine
+  if (blockIdx.x * 256 + cc < C) {
+    float nn = sh[0][0][cc], mu = sh[1][0][cc], q = sh[2][0][cc];
+    for (int i = 1; i < 4; ++i) {
+      const float nb = sh[0][i][cc];
+      if (nb > 0.f) {
+        const float delta = sh[1][i][cc] - mu, tot = nn + nb;
+        mu += delta * nb / tot;
+        q += sh[2][i][cc] + delta * delta * nn * nb / tot;
+        nn = tot;
+      }
+    }
+    part[((int64_t)blockIdx.y * 2 + 0) * C + blockIdx.x * 256 + cc] = mu;
+    part[((int64_t)blockIdx.y * 2 + 1) * C + blockIdx.x * 256 + cc] = q;
+  }
+}
+__global__ __launch_bounds__(256) void bn_bwd_partial_v4(const void *dy, const void *x, const void *y, int dtype, int64_t R, int C,
+                                                         const float *mean, const float *invstd, int relu, float *part) {
+  __shared__ float sh[2][4][260];
+  const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + cg * 4;
+  const int64_t r0 = (int64_t)blockIdx.y * BN_ROWS;
+  const int64_t r1 = r0 + BN_ROWS < R ? r0 + BN_ROWS : R;
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const float4 mu = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(invstd + c);
+    const float mua[4] = {mu.x, mu.y, mu.z, mu.w}, isa[4] = {is.x, is.y, is.z, is.w};
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      const float4 d4 = ld4_any(dy, dtype, r * C + c), x4 = ld4_any(x, dtype, r * C + c);
+      float d[4] = {d4.x, d4.y, d4.z, d4.w};
+      const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+      if (relu) {
+        const float4 y4 = ld4_any(y, dtype, r * C + c);
+        const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!(yv[j] > 0.f)) d[j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s0[j] += d[j];
+        s1[j] += d[j] * (xv[j] - mua[j]) * isa[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sh[0][rl][cg * 4 + j] = s0[j]; sh[1][rl][cg * 4 + j] = s1[j]; }
+  __syncthreads();
+  const int cc = threadIdx.x;
+  if (blockIdx.x * 256 + cc < C) {
+    part[((int64_t)blockIdx.y * 2 + 0) * C + blockIdx.x * 256 + cc] = (sh[0][0][cc] + sh[0][1][cc]) + (sh[0][2][cc] + sh[0][3][cc]);
+    part[((int64_t)blockIdx.y * 2 + 1) * C + blockIdx.x * 256 + cc] = (sh[1][0][cc] + sh[1][1][cc]) + (sh[1][2][cc] + sh[1][3][cc]);
+  }
+}
+__global__ __launch_bounds__(256) void bn_apply_v4(const void *x, int dtype, int64_t total4, int C, const float *gamma, const float *beta,
+                                                   const float *mean, const float *invstd, int relu, void *y) {
+  for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * 256) {
+    const int64_t i = i4 * 4;
+    const int c = (int)(i % C);
+    const float4 v = ld4_any(x, dtype, i), mu = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(invstd + c);
+    float o[4] = {(v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w};
+    if (gamma) {
+      const float4 g = *reinterpret_cast<const float4 *>(gamma + c), b = *reinterpret_cast<const float4 *>(beta + c);
+      o[0] = o[0] * g.x + b.x; o[1] = o[1] * g.y + b.y; o[2] = o[2] * g.z + b.z; o[3] = o[3] * g.w + b.w;
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+    }
+    st4_any(y, dtype, i, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_v4(const void *dy, const void *x, const void *y, int dtype, int64_t total4, int64_t R, int C,
+                                                       const float *gamma, const float *mean, const float *invstd, int relu,
+                                                       const float *sum_dy, const float *sum_dy_xhat, void *dx) {
+  const float invR = 1.0f / (float)R;
+  for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * 256) {
+    const int64_t i = i4 * 4;
+    const int c = (int)(i % C);
+    const float4 d4 = ld4_any(dy, dtype, i), x4 = ld4_any(x, dtype, i);
+    float d[4] = {d4.x, d4.y, d4.z, d4.w};
+    const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+    if (relu) {
+      const float4 y4 = ld4_any(y, dtype, i);
+      const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (!(yv[j] > 0.f)) d[j] = 0.f;
+    }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float is = invstd[c + j];
+      const float xh = (xv[j] - mean[c + j]) * is;
+      const float g = gamma ? gamma[c + j] : 1.f;
+      o[j] = g * is * (d[j] - sum_dy[c + j] * invR - xh * sum_dy_xhat[c + j] * invR);
+    }
+    st4_any(dx, dtype, i, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
 }  // namespace
 
 #define DISPATCH_VPL(D, CALL)                                   \
@@ -685,13 +829,16 @@ extern "C" int evp_batchnorm_fwd(const void *x, int dtype, int64_t R, int C, con
   EVP_CHECK_ARG((gamma == nullptr) == (beta == nullptr), EVP_EINVAL, "evp_batchnorm_fwd: gamma and beta go together");
   hipStream_t s = (hipStream_t)stream;
   const int ns = evp_batchnorm_nblk(R);
-  hipLaunchKernelGGL(bn_stats_partial, dim3((C + 255) / 256, ns), dim3(256), 0, s, x, dtype, R, C, workspace);
+  const bool v4 = (C % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+  if (v4) hipLaunchKernelGGL(bn_stats_partial_v4, dim3((C + 255) / 256, ns), dim3(256), 0, s, x, dtype, R, C, workspace);
+  else hipLaunchKernelGGL(bn_stats_partial, dim3((C + 255) / 256, ns), dim3(256), 0, s, x, dtype, R, C, workspace);
   EVP_CHECK_LAUNCH("evp_batchnorm_fwd(stats)");
   hipLaunchKernelGGL(bn_stats_finalize, dim3((C + 63) / 64), dim3(1024), 0, s, workspace, ns, R, C, eps, momentum, mean, invstd, running_mean, running_var);
   EVP_CHECK_LAUNCH("evp_batchnorm_fwd(finalize)");
   const int64_t total = R * C;
-  int64_t g = (total + 255) / 256; if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(bn_apply, dim3((int)g), dim3(256), 0, s, x, dtype, total, C, gamma, beta, mean, invstd, relu, y);
+  int64_t g = ((v4 ? total / 4 : total) + 255) / 256; if (g > 4096) g = 4096;
+  if (v4) hipLaunchKernelGGL(bn_apply_v4, dim3((int)g), dim3(256), 0, s, x, dtype, total / 4, C, gamma, beta, mean, invstd, relu, y);
+  else hipLaunchKernelGGL(bn_apply, dim3((int)g), dim3(256), 0, s, x, dtype, total, C, gamma, beta, mean, invstd, relu, y);
   EVP_CHECK_LAUNCH("evp_batchnorm_fwd(apply)");
   return EVP_OK;
 }
@@ -704,13 +851,16 @@ extern "C" int evp_batchnorm_bwd(const void *dy, const void *x, const void *y, i
   hipStream_t s = (hipStream_t)stream;
   const int ns = evp_batchnorm_nblk(R);
   float *sum_dy = workspace + (int64_t)ns * 2 * C, *sum_dy_xhat = sum_dy + C;
-  hipLaunchKernelGGL(bn_bwd_partial, dim3((C + 255) / 256, ns), dim3(256), 0, s, dy, x, y, dtype, R, C, mean, invstd, relu, workspace);
+  const bool v4 = (C % 4 == 0) && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y | (uintptr_t)dx) & 15) == 0;
+  if (v4) hipLaunchKernelGGL(bn_bwd_partial_v4, dim3((C + 255) / 256, ns), dim3(256), 0, s, dy, x, y, dtype, R, C, mean, invstd, relu, workspace);
+  else hipLaunchKernelGGL(bn_bwd_partial, dim3((C + 255) / 256, ns), dim3(256), 0, s, dy, x, y, dtype, R, C, mean, invstd, relu, workspace);
   EVP_CHECK_LAUNCH("evp_batchnorm_bwd(partial)");
   hipLaunchKernelGGL(bn_bwd_finalize, dim3((C + 63) / 64), dim3(1024), 0, s, workspace, ns, C, sum_dy, sum_dy_xhat);
   EVP_CHECK_LAUNCH("evp_batchnorm_bwd(finalize)");
   const int64_t total = R * C;
-  int64_t g = (total + 255) / 256; if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(bn_bwd_apply, dim3((int)g), dim3(256), 0, s, dy, x, y, dtype, R, C, gamma, mean, invstd, relu, sum_dy, sum_dy_xhat, dx);
+  int64_t g = ((v4 ? total / 4 : total) + 255) / 256; if (g > 4096) g = 4096;
+  if (v4) hipLaunchKernelGGL(bn_bwd_apply_v4, dim3((int)g), dim3(256), 0, s, dy, x, y, dtype, total / 4, R, C, gamma, mean, invstd, relu, sum_dy, sum_dy_xhat, dx);
+  else hipLaunchKernelGGL(bn_bwd_apply, dim3((int)g), dim3(256), 0, s, dy, x, y, dtype, R, C, gamma, mean, invstd, relu, sum_dy, sum_dy_xhat, dx);
   EVP_CHECK_LAUNCH("evp_batchnorm_bwd(apply)");
   hipError_t e = hipSuccess;
   if (dgamma) e = hipMemcpyAsync(dgamma, sum_dy_xhat, sizeof(float) * C, hipMemcpyDeviceToDevice, s);
