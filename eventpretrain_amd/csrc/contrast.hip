@@ -139,6 +139,25 @@ __global__ __launch_bounds__(256) void enqueue_dev_kernel(float *queue, const fl
     queue[((int64_t)c * L + l) * K + ptr + b] = keys[((int64_t)b * L + l) * C + c];
   }
 }
+// Tiled form: queue is [C][L][K] (K contiguous), keys are [B][L][C] (C contiguous): a block moves a 64-batch x 64-channel tile of one
+// token l through LDS, reading 256-byte runs along C and writing 256-byte runs along K (the element-wise form above reads every
+// key with a stride of L*C floats: 153 us per step at B=64, L=197, C=256).
+__global__ __launch_bounds__(256) void enqueue_dev_tiled_kernel(float *queue, const float *keys, const int64_t *qptr, int B, int L, int C, int K) {
+  __shared__ float tile[64][65];
+  const int ptr = (int)(*qptr);
+  if (ptr < 0 || ptr + B > K) return;
+  const int l = blockIdx.x, c0 = blockIdx.y * 64, b0 = blockIdx.z * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int b = b0 + r, c = c0 + tx;
+    tile[r][tx] = (b < B && c < C) ? keys[((int64_t)b * L + l) * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r, b = b0 + tx;
+    if (c < C && b < B) queue[((int64_t)c * L + l) * K + ptr + b] = tile[tx][r];
+  }
+}
 __global__ void advance_ptr_kernel(int64_t *qptr, int B, int K) { *qptr = (*qptr + B) % K; }
 
 static inline int rows_grid(int64_t rows) {
@@ -206,8 +225,13 @@ extern "C" int evp_infonce_queue(const float *pos, const float *neg, int64_t R, 
 extern "C" int evp_enqueue_keys_dev(float *queue, const float *keys, int64_t *queue_ptr, int B, int L, int C, int K, void *stream) {
   EVP_CHECK_ARG(queue && keys && queue_ptr, EVP_EINVAL, "evp_enqueue_keys_dev: null pointer");
   EVP_CHECK_ARG(B > 0 && L > 0 && C > 0 && K > 0 && K % B == 0, EVP_ESHAPE, "evp_enqueue_keys_dev: queue length %d must be a multiple of the batch %d", K, B);
-  int64_t g = ((int64_t)B * L * C + 255) / 256; if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(enqueue_dev_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, queue, keys, queue_ptr, B, L, C, K);
+  if (L <= 65535 && (C + 63) / 64 <= 65535 && (B + 63) / 64 <= 65535) {
+    hipLaunchKernelGGL(enqueue_dev_tiled_kernel, dim3((unsigned)L, (unsigned)((C + 63) / 64), (unsigned)((B + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                       queue, keys, queue_ptr, B, L, C, K);
+  } else {
+    int64_t g = ((int64_t)B * L * C + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(enqueue_dev_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, queue, keys, queue_ptr, B, L, C, K);
+  }
   EVP_CHECK_LAUNCH("evp_enqueue_keys_dev");
   hipLaunchKernelGGL(advance_ptr_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, queue_ptr, B, K);
   EVP_CHECK_LAUNCH("evp_enqueue_keys_dev(advance)");
