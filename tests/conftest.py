@@ -29,3 +29,20 @@ def jload(arr):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _restore_global_switches(request):
+    """GPU tests flip process-wide switches (compute dtype, kernel A/B selectors); a test that fails half-way must not leave
+    them set for the tests after it."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    try:
+        import torch
+        from eventpretrain_amd import ops
+        ops.set_compute_dtype(torch.float32)
+        ops.set_window_mfma(True)
+        ops.set_fused_attention(True)
+    except Exception:
+        pass

@@ -412,8 +412,8 @@ def test_swin_static_plan_equals_pattern_plan_against_reference():
         assert torch.allclose(gs, g, atol=1e-7 + 1e-4 * g.abs().max().item(), rtol=1e-4), n
 
 
-@pytest.mark.parametrize("slack", [1.25, 1.05, 0.9])
-def test_swin_graphed_step_follows_eager_trajectory(slack):
+@pytest.mark.parametrize("slack,dtype", [(1.25, torch.float32), (1.05, torch.float32), (0.9, torch.float32), (1.05, torch.bfloat16)])
+def test_swin_graphed_step_follows_eager_trajectory(slack, dtype):
     """ONE captured graph serves every mask pattern (tables refreshed by an H2D copy per step); patterns that need more
     groups than the fixed shape holds (slack 1.05: about a third of them) run eagerly in between without disturbing the
     graph; when NO pattern fits (0.9) the executor says so and stays eager. Either way the losses follow the plain eager executor's from the same start and noise stream."""
@@ -424,7 +424,7 @@ def test_swin_graphed_step_follows_eager_trajectory(slack):
     d = load_golden("rec_swin_tiny")
     x, y, _ = rec_inputs("swin", jl(d["cfg"]))
     B = x.shape[0]
-    ops.set_compute_dtype(torch.float32)
+    ops.set_compute_dtype(dtype)
     fwd = lambda mm, xx, yy, noise: mm(xx, yy, is_rec=True, noise=noise)
     runs, notes = {}, {}
     for mode in ("eager", "graph"):
@@ -439,7 +439,8 @@ def test_swin_graphed_step_follows_eager_trajectory(slack):
             assert ex.note.startswith("eager (graph capture failed"), ex.note      # no pattern fits: nothing to capture
         runs[mode] = [ex.step().item() for _ in range(12)]
         notes[mode] = (ex.eager_fallbacks, getattr(m.backbone, "_static_plan", None))
-    assert runs["graph"] == pytest.approx(runs["eager"], rel=2e-5), (runs, notes)
+    ops.set_compute_dtype(torch.float32)
+    assert runs["graph"] == pytest.approx(runs["eager"], rel=2e-5 if dtype == torch.float32 else 5e-3), (runs, notes)
     fallbacks, sp = notes["graph"]
     if slack >= 1.25:
         assert fallbacks == 0 and sp.overflows == 0

@@ -46,7 +46,7 @@ def patch_fallback(ex, mode):
 def main():
     slack = float(sys.argv[1]) if len(sys.argv) > 1 else 1.05
     mode = sys.argv[2] if len(sys.argv) > 2 else "full"
-    ops.set_compute_dtype(torch.float32)
+    ops.set_compute_dtype(torch.bfloat16 if os.environ.get("PROBE_BF16") else torch.float32)
     a = make_args(model_size="tiny", pr_phase="rec", backbone_type="swin", device="cuda")
     m = hub.pretrain_hub_model_swin_tiny_patch16(a, emb_frames_dim=512, queue_length=1024, T=0.07)
     det_fill_module_(m)
@@ -80,7 +80,7 @@ def main():
                     torch.rand(noise_cpu.shape, generator=ex.host_gen, out=noise_cpu)
             return real(noise_cpu)
         ex.step_prepare = filtered
-    for i in range(8):
+    for i in range(10):
         fb = ex.eager_fallbacks
         loss = ex.step().item()
         torch.cuda.synchronize()
