@@ -101,9 +101,20 @@ __global__ __launch_bounds__(256) void evp_zero_kernel(uint32_t *p, int64_t pitc
   const int64_t r = e / width_dw, c = e - r * width_dw;
   p[r * pitch_dw + c] = 0u;
 }
+// 16-byte stores, grid-stride (large contiguous buffers: a ConvViT patch-embed gradient is 205 MB)
+__global__ __launch_bounds__(256) void evp_zero16_kernel(uint4 *p, int64_t n16) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n16; e += (int64_t)gridDim.x * 256) p[e] = make_uint4(0u, 0u, 0u, 0u);
+}
 inline hipError_t evp_zero2d_async(void *p, size_t pitch_bytes, size_t width_bytes, size_t rows, hipStream_t s) {
   if (width_bytes == 0 || rows == 0) return hipSuccess;
   if ((pitch_bytes | width_bytes | (size_t)(uintptr_t)p) & 3) return hipErrorInvalidValue;
+  if ((rows == 1 || pitch_bytes == width_bytes) && (((size_t)(uintptr_t)p | (width_bytes * rows)) & 15) == 0) {
+    const int64_t n16 = (int64_t)(width_bytes * rows / 16);
+    int64_t g = (n16 + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(evp_zero16_kernel, dim3((unsigned)g), dim3(256), 0, s, (uint4 *)p, n16);
+    return hipGetLastError();
+  }
   const int64_t total = (int64_t)(width_bytes / 4) * (int64_t)rows;
   hipLaunchKernelGGL(evp_zero_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (uint32_t *)p, (int64_t)(pitch_bytes / 4),
                      (int64_t)(width_bytes / 4), total);
