@@ -96,7 +96,8 @@ SIGNATURES = {
     "evp_window_bias_build": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "evp_window_attention_fused_fwd": [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
     "evp_window_attention_fused_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
-    "evp_window_bias_reduce": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "evp_window_attention_fused_nchunk": [_i, _i, _i],
+    "evp_window_bias_reduce": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "evp_gather_rows_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "evp_swin_fuse_gather_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "evp_swin_fuse_gather_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -109,7 +110,7 @@ SIGNATURES = {
 }
 _OTHER_RESTYPE = {"evp_last_error": C.c_char_p, "evp_target_arch": C.c_char_p}
 _NO_STATUS = {"evp_dwconv5x5_bwd_nslab", "evp_gemm_set_variant", "evp_attention_fused_supported", "evp_layernorm_bwd_nblk", "evp_colsum_nblk", "evp_batchnorm_nblk", "evp_abi_version",
-              "evp_window_attention_fused_np"}
+              "evp_window_attention_fused_np", "evp_window_attention_fused_nchunk"}
 
 _lib = None
 

@@ -455,19 +455,14 @@ __global__ __launch_bounds__(64 * NW) void win_attn_bwd_mfma_kernel(const bf16_t
     attn_bwd_body<32, NT, NW, true>(qkv, out, dout, lse, dqkv, N, heads, scale, addm, addmT, nG, bi * nG + grp, h, dacc);
     __syncthreads();                       // the next batch item re-stages the LDS images
   }
+  // every chunk owns a plane set dA[c][g][h][NP][NP]: plain stores (evp_window_bias_reduce sums the chunks). With atomics into one
+  // plane set, 32 workgroups per plane contended at Swin stage 3 (nG = 1): 101 us per launch, most of it the adds.
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, q = wave * 16 + (lane & 15);
   if (q < N) {
-    float *da = dA + ((int64_t)gh * NP + q) * NP + 4 * g;
+    float *da = dA + (((int64_t)c * gridDim.x / nchunk + gh) * NP + q) * NP + 4 * g;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      if (nchunk == 1 && 16 * t + 4 * g + 3 < N) {
-        *reinterpret_cast<float4 *>(da + 16 * t) = make_float4(dacc[t][0], dacc[t][1], dacc[t][2], dacc[t][3]);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (16 * t + 4 * g + r < N) unsafeAtomicAdd(da + 16 * t + r, dacc[t][r]);
-      }
-    }
+    for (int t = 0; t < NT; ++t)
+      *reinterpret_cast<float4 *>(da + 16 * t) = make_float4(dacc[t][0], dacc[t][1], dacc[t][2], dacc[t][3]);
   }
 }
 
@@ -543,25 +538,39 @@ __global__ __launch_bounds__(256) void win_bias_build_kernel(const float *__rest
   addmT[(((int64_t)g * H + h) * NP + j) * NP + i] = v;
 }
 
-// dtable[r][h] += sum over (g, i, j) with rel[g][i][j] == r of dA[g][h][i][j]: one workgroup per (group, head), the table
-// privatised in LDS, at most R global atomics per workgroup (dtable zeroed by the launcher)
+// dtable[r][h] += sum over (chunk, g, i, j) with rel[g][i][j] == r of dA[chunk][g][h][i][j]: workgroup = ((group, head), slice of the
+// N x N pairs), the table privatised in LDS, at most R global atomics per workgroup (dtable zeroed by the launcher)
 __global__ __launch_bounds__(256) void win_bias_reduce_kernel(const float *__restrict__ dA, const int32_t *__restrict__ rel, float *__restrict__ dtable,
-                                                              int N, int NP, int H, int R) {
+                                                              int N, int NP, int H, int R, int nchunk, int nplanes) {
   extern __shared__ float tab[];
   const int g = blockIdx.x / H, h = blockIdx.x % H;
   for (int r = threadIdx.x; r < R; r += 256) tab[r] = 0.f;
   __syncthreads();
-  const float *plane = dA + (int64_t)blockIdx.x * NP * NP;
-  for (int e = threadIdx.x; e < N * N; e += 256) {
-    const int i = e / N, j = e - i * N;
+  const int per = (N * N + gridDim.y - 1) / gridDim.y, e0 = blockIdx.y * per, e1 = (e0 + per < N * N) ? e0 + per : N * N;
+  for (int e = e0 + threadIdx.x; e < e1; e += 256) {
     const int r = rel[(int64_t)g * N * N + e];
-    if (r >= 0) atomicAdd(&tab[r], plane[i * NP + j]);
+    if (r >= 0) {
+      const int i = e / N, j = e - i * N;
+      float v = 0.f;
+      for (int c = 0; c < nchunk; ++c) v += dA[((int64_t)c * nplanes + blockIdx.x) * NP * NP + i * NP + j];
+      atomicAdd(&tab[r], v);
+    }
   }
   __syncthreads();
   for (int r = threadIdx.x; r < R; r += 256) {
     const float t = tab[r];
     if (t != 0.f) unsafeAtomicAdd(dtable + (int64_t)r * H + h, t);
   }
+}
+
+// batch chunks of the windowed backward: keep >= ~512 workgroups in the launch, every chunk non-empty
+static inline void win_chunks(int Bg, int nG, int heads, int *nchunk, int *per) {
+  const int B = Bg / nG;
+  int nc = (512 + nG * heads - 1) / (nG * heads);
+  if (nc > B) nc = B;
+  if (nc < 1) nc = 1;
+  *per = (B + nc - 1) / nc;
+  *nchunk = (B + *per - 1) / *per;
 }
 
 template <int NT>
@@ -579,11 +588,8 @@ int launch_win_bwd(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, con
   constexpr int smem = 4 * 16 * NT * 32 * 2 + 2 * 16 * NT * 4;
   constexpr int NW = NT <= 4 ? 4 : 8;          // one 16-query strip per wave: no more waves than strips
   const int B = Bg / nG;
-  int nchunk = (512 + nG * heads - 1) / (nG * heads);        // keep >= ~512 workgroups in the launch
-  if (nchunk > B) nchunk = B;
-  if (nchunk < 1) nchunk = 1;
-  const int per = (B + nchunk - 1) / nchunk;
-  nchunk = (B + per - 1) / per;
+  int nchunk, per;
+  win_chunks(Bg, nG, heads, &nchunk, &per);
   auto k = win_attn_bwd_mfma_kernel<NT, NW>;
   hipLaunchKernelGGL(k, dim3(nG * heads * nchunk), dim3(64 * NW), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale, addm, addmT, dA, nG, B, nchunk,
                      per);
@@ -669,21 +675,29 @@ extern "C" int evp_window_attention_fused_bwd(const void *qkv, const void *out, 
   EVP_CHECK_ARG(Bg > 0 && nG > 0 && Bg % nG == 0 && N > 0 && N <= 128 && heads > 0, EVP_ESHAPE,
                 "evp_window_attention_fused_bwd: bad shape (Bg=%d nG=%d N=%d)", Bg, nG, N);
   hipStream_t s = (hipStream_t)stream;
-  const int NP = evp_window_attention_fused_np(N);
-  hipError_t e = evp_zero_async(dA, (size_t)nG * heads * NP * NP * sizeof(float), s);
-  EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_window_attention_fused_bwd: clearing dA failed: %s", hipGetErrorString(e));
   DISPATCH_WIN_NT(return (launch_win_bwd<NTV>((const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, addm, addmT, (bf16_t *)dqkv, dA, Bg,
                                               nG, N, heads, scale, s)))
 }
 
-extern "C" int evp_window_bias_reduce(const float *dA, const int32_t *rel, int nG, int N, int heads, int R, float *dtable, void *stream) {
+extern "C" int evp_window_attention_fused_nchunk(int Bg, int nG, int heads) {
+  if (Bg <= 0 || nG <= 0 || heads <= 0 || Bg % nG != 0) return 0;
+  int nchunk, per;
+  win_chunks(Bg, nG, heads, &nchunk, &per);
+  return nchunk;
+}
+
+extern "C" int evp_window_bias_reduce(const float *dA, const int32_t *rel, int Bg, int nG, int N, int heads, int R, float *dtable, void *stream) {
   EVP_CHECK_ARG(dA && rel && dtable, EVP_EINVAL, "evp_window_bias_reduce: null pointer");
   EVP_CHECK_ARG(nG > 0 && N > 0 && N <= 128 && heads > 0 && R > 0 && R <= 4096, EVP_ESHAPE, "evp_window_bias_reduce: bad shape");
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = evp_zero_async(dtable, (size_t)R * heads * sizeof(float), s);
   EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_window_bias_reduce: clearing dtable failed: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(win_bias_reduce_kernel, dim3((unsigned)(nG * heads)), dim3(256), (size_t)R * sizeof(float), s, dA, rel, dtable, N,
-                     evp_window_attention_fused_np(N), heads, R);
+  const int nchunk = evp_window_attention_fused_nchunk(Bg, nG, heads);
+  EVP_CHECK_ARG(nchunk > 0, EVP_ESHAPE, "evp_window_bias_reduce: Bg must be a positive multiple of nG");
+  int split = (256 + nG * heads - 1) / (nG * heads);          // ~256 workgroups
+  if (split > 16) split = 16;
+  hipLaunchKernelGGL(win_bias_reduce_kernel, dim3((unsigned)(nG * heads), (unsigned)split), dim3(256), (size_t)R * sizeof(float), s, dA, rel, dtable, N,
+                     evp_window_attention_fused_np(N), heads, R, nchunk, nG * heads);
   EVP_CHECK_LAUNCH("evp_window_bias_reduce");
   return EVP_OK;
 }

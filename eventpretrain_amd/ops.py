@@ -1631,10 +1631,11 @@ class SwinBlockFn(torch.autograd.Function):
         dtable = torch.empty(R, heads, dtype=torch.float32, device=dev)
         lse, addm, addmT = ctx.win
         if lse is not None:
-            dA = torch.empty_like(addm)
+            nchunk = call("evp_window_attention_fused_nchunk", Bg, nG, heads)
+            dA = torch.empty(nchunk * addm.numel(), dtype=torch.float32, device=dev)
             call("evp_window_attention_fused_bwd", ptr(qkv), ptr(att), ptr(datt), ptr(lse), ptr(addm), ptr(addmT), Bg, nG, N, heads, scale,
                  ptr(dqkv), ptr(dA), stream_ptr())
-            call("evp_window_bias_reduce", ptr(dA), ptr(rel), nG, N, heads, R, ptr(dtable), stream_ptr())
+            call("evp_window_bias_reduce", ptr(dA), ptr(rel), Bg, nG, N, heads, R, ptr(dtable), stream_ptr())
         else:
             call("evp_window_attention_bwd", ptr(qkv), ptr(tab), ptr(rel), ptr(att), ptr(datt), ptr(dqkv), ptr(dtable), Bg, nG, N, heads,
                  R, scale, dt(qkv), stream_ptr())

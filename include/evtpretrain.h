@@ -371,10 +371,13 @@ int evp_window_attention_bwd(const void *qkv, const float *table, const int32_t 
  *                           [nG, H, NP, NP] each with NP = evp_window_attention_fused_np(N) (32 / 64 / 96 / 128), zero outside N x N;
  *   evp_window_attention_fused_fwd   out = softmax(scale*q k^T + addm[bg % nG, h]) v; qkv / out bf16 as above; lse float32
  *                           [Bg*H, N] (log-sum-exp of the logits, kept for the backward; probabilities are never stored);
- *   evp_window_attention_fused_bwd   dqkv (bf16) and dA float32 [nG, H, NP, NP] = d logits summed over the batch (cleared here,
- *                           f32 atomics); evp_window_bias_reduce then folds dA through rel into dtable float32 [R, H] (cleared
- *                           there; masked pairs contribute nothing, swin_block.py:140-149). */
+ *   evp_window_attention_fused_bwd   dqkv (bf16) and dA float32 [nchunk, nG, H, NP, NP], nchunk = evp_window_attention_fused_nchunk(Bg, nG,
+ *                           H): every batch chunk's workgroups store the d logits they summed over their batch items into their own
+ *                           planes (plain stores, the N x N part of every plane is written); evp_window_bias_reduce then sums the
+ *                           chunks and folds them through rel into dtable float32 [R, H] (cleared there; masked pairs contribute
+ *                           nothing, swin_block.py:140-149). */
 int evp_window_attention_fused_np(int N);
+int evp_window_attention_fused_nchunk(int Bg, int nG, int heads);
 int evp_window_bias_build(const float *table, const int32_t *rel, int nG, int N, int heads, int R, float *addm, float *addmT,
                           void *stream);
 int evp_window_attention_fused_fwd(const void *qkv, const float *addm, int Bg, int nG, int N, int heads, float scale, void *out,
@@ -382,7 +385,7 @@ int evp_window_attention_fused_fwd(const void *qkv, const float *addm, int Bg, i
 int evp_window_attention_fused_bwd(const void *qkv, const void *out, const void *dout, const float *lse, const float *addm,
                                    const float *addmT, int Bg, int nG, int N, int heads, float scale, void *dqkv, float *dA,
                                    void *stream);
-int evp_window_bias_reduce(const float *dA, const int32_t *rel, int nG, int N, int heads, int R, float *dtable, void *stream);
+int evp_window_bias_reduce(const float *dA, const int32_t *rel, int Bg, int nG, int N, int heads, int R, float *dtable, void *stream);
 /* Token row gather used by GroupingModule.group/merge (swin_block.py:454-466) and PatchMerging's 2x2 regrouping
  * (:193-201): out[b, s, :] = idx[s] >= 0 ? x[b, idx[s], :] : 0; x float32 [B, n_in, C], out float32 [B, n_out, C],
  * idx int32 [n_out] (shared by the batch) or [B, n_out] when idx_per_sample != 0. C % 4 == 0. The backward of a

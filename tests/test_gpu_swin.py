@@ -101,12 +101,13 @@ def test_window_attention_mfma_fwd_bwd(Bg, nG, N, H):
     lse = torch.full((Bg * H * N,), nan, device="cuda")
     call("evp_window_attention_fused_fwd", ptr(qd), ptr(addm), Bg, nG, N, H, dh ** -0.5, ptr(out), ptr(lse), stream_ptr())
     dqkv = torch.full_like(qd, nan)
-    dA = torch.full_like(addm, nan)                                           # cleared by the call
+    nchunk = call("evp_window_attention_fused_nchunk", Bg, nG, H)
+    dA = torch.full((nchunk * addm.numel(),), nan, device="cuda")             # the N x N part of every plane is written
     dtab = torch.full((R, H), 7.0, dtype=torch.float32, device="cuda")       # overwritten, not accumulated
     dd = dout.bfloat16().cuda()
     call("evp_window_attention_fused_bwd", ptr(qd), ptr(out), ptr(dd), ptr(lse), ptr(addm), ptr(addmT), Bg, nG, N, H, dh ** -0.5,
          ptr(dqkv), ptr(dA), stream_ptr())
-    call("evp_window_bias_reduce", ptr(dA), ptr(rd), nG, N, H, R, ptr(dtab), stream_ptr())
+    call("evp_window_bias_reduce", ptr(dA), ptr(rd), Bg, nG, N, H, R, ptr(dtab), stream_ptr())
     torch.cuda.synchronize()
     tol = 2e-2
     assert torch.isfinite(out.float()).all() and torch.isfinite(dqkv.float()).all() and torch.isfinite(dtab).all()
