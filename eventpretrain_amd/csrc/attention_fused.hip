@@ -546,15 +546,26 @@ __global__ __launch_bounds__(256) void win_bias_reduce_kernel(const float *__res
   const int g = blockIdx.x / H, h = blockIdx.x % H;
   for (int r = threadIdx.x; r < R; r += 256) tab[r] = 0.f;
   __syncthreads();
-  const int per = (N * N + gridDim.y - 1) / gridDim.y, e0 = blockIdx.y * per, e1 = (e0 + per < N * N) ? e0 + per : N * N;
+  // a thread takes 4 consecutive keys of one query row (16-byte loads of every chunk's plane); slices of the N x (NP / 4) pieces
+  const int Q4 = NP / 4, total = N * Q4;
+  const int per = (total + gridDim.y - 1) / gridDim.y, e0 = blockIdx.y * per, e1 = (e0 + per < total) ? e0 + per : total;
   for (int e = e0 + threadIdx.x; e < e1; e += 256) {
-    const int r = rel[(int64_t)g * N * N + e];
-    if (r >= 0) {
-      const int i = e / N, j = e - i * N;
-      float v = 0.f;
-      for (int c = 0; c < nchunk; ++c) v += dA[((int64_t)c * nplanes + blockIdx.x) * NP * NP + i * NP + j];
-      atomicAdd(&tab[r], v);
+    const int i = e / Q4, j0 = (e - i * Q4) * 4;
+    if (j0 >= N) continue;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *src = dA + (int64_t)blockIdx.x * NP * NP + i * NP + j0;
+    for (int c = 0; c < nchunk; ++c) {
+      const float4 a = *reinterpret_cast<const float4 *>(src + (int64_t)c * nplanes * NP * NP);
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
     }
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    const int32_t *rrow = rel + ((int64_t)g * N + i) * N + j0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (j0 + u < N) {
+        const int r = rrow[u];
+        if (r >= 0) atomicAdd(&tab[r], vv[u]);
+      }
   }
   __syncthreads();
   for (int r = threadIdx.x; r < R; r += 256) {
