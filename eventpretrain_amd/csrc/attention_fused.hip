@@ -574,10 +574,19 @@ __global__ __launch_bounds__(256) void win_bias_reduce_kernel(const float *__res
   }
 }
 
-// batch chunks of the windowed backward: keep >= ~512 workgroups in the launch, every chunk non-empty
+// batch chunks of the windowed backward: at least ~512 workgroups in the launch (1024 / 2048 / 4096 measured the same or slower on
+// Swin-T / Swin-B; EVP_WIN_BWD_WGS overrides), every chunk non-empty
+static inline int win_target_wgs() {
+  static const int v = [] {
+    const char *e = getenv("EVP_WIN_BWD_WGS");
+    const int n = e ? atoi(e) : 0;
+    return n >= 64 && n <= 65536 ? n : 512;
+  }();
+  return v;
+}
 static inline void win_chunks(int Bg, int nG, int heads, int *nchunk, int *per) {
   const int B = Bg / nG;
-  int nc = (512 + nG * heads - 1) / (nG * heads);
+  int nc = (win_target_wgs() + nG * heads - 1) / (nG * heads);
   if (nc > B) nc = B;
   if (nc < 1) nc = 1;
   *per = (B + nc - 1) / nc;
