@@ -219,6 +219,10 @@ class SwinTransformer(nn.Module):
         hook `prepare(noise_cpu) -> bool`: call it with the step's mask noise (CPU tensor [B, cells]; row 0 decides the
         pattern, swin.py:151) BEFORE the forward / the graph replay; False = this pattern does not fit the fixed shape
         (the static plan is switched off for that one step: run it eagerly)."""
+        if self.args.masking_strategy != "random":
+            # density / anti-density noise is computed on the device from the voxel grid: the pattern is not known on the host
+            # before the launch, which is what the fixed-address plan needs
+            raise NotImplementedError("enable_static_plan: only the random masking strategy draws its noise on the host")
         keep = int(self.num_patches * (1 - self.mask_ratio))
         self._static_plan = StaticPatternPlan(self, device, keep, slack)
         self._static = self._static_plan
