@@ -15,7 +15,7 @@ def bench(fn, reps=20, warm=4):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 shapes = [("enc.qkv", 6272, 2304, 768), ("enc.proj", 6272, 768, 768), ("enc.fc1", 6272, 3072, 768), ("enc.fc2", 6272, 768, 3072),
-          ("dec.qkv", 12544, 1536, 512), ("dec.fc1", 12544, 2048, 512), ("dec.fc2", 12544, 512, 2048), ("4096^3", 4096, 4096, 4096)]
+          ("cvit.proj", 12544, 768, 768), ("cvit.fc2", 12544, 768, 3072), ("cvit.qkv", 12544, 2304, 768), ("cvit.fc1", 12544, 3072, 768), ("dec.qkv", 12544, 1536, 512), ("dec.fc1", 12544, 2048, 512), ("dec.fc2", 12544, 512, 2048), ("4096^3", 4096, 4096, 4096)]
 for name, M, N, K in shapes:
     x = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
     dy = torch.randn(M, N, device="cuda").bfloat16(); dx = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
