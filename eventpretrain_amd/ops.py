@@ -1609,22 +1609,23 @@ class SwinBlockFn(torch.autograd.Function):
         dev = g2.device
         bf = T == torch.bfloat16
         g2 = _chk(g2.contiguous(), torch.float32).view(M, D)
-        g2_lp = cast(g2, T)
+        # as in ViTBlockFn: the LayerNorm backward that produced g2 (the block above, when no regrouping gather sits in between:
+        # the single-group stages) may have left its bf16 copy and column sums; bias gradients ride on the weight-gradient launch
+        g2_side_lp, g2_cs = _side_take(g2) if bf else (None, None)
+        g2_lp = g2_side_lp if g2_side_lp is not None else cast(g2, T)
         qkvw_, qkvb_, pw_, pb_, f1w_, f1b_, f2w_, f2b_ = ctx.prm
         need = ctx.needs_input_grad
-        db2 = _bgrad(g2, f2b_) if need[14] else None
-        dw2 = _wgrad(g2_lp, h_act, D, Hd, M, f2w_) if need[13] else None
+        dw2, db2 = _wgrad_bias(g2_lp, h_act, D, Hd, M, f2w_, f2b_, need[13], need[14], dy_f32=g2, dy_colsum=g2_cs)
         dh_pre = torch.empty(M, Hd, dtype=T, device=dev)
         gemm(g2_lp, w2, dh_pre, M=M, N=Hd, K=D, trans_b=True, ldb=Hd, act=ACT_DGELU, aux=h_pre)
-        db1 = _bgrad(dh_pre, f1b_) if need[12] else None
-        dw1 = _wgrad(dh_pre, ln2, Hd, D, M, f1w_) if need[11] else None
+        dw1, db1 = _wgrad_bias(dh_pre, ln2, Hd, D, M, f1w_, f1b_, need[11], need[12])
         dln2 = torch.empty(M, D, dtype=T, device=dev)
         gemm(dh_pre, w1, dln2, M=M, N=D, K=Hd, trans_b=True, ldb=D)
-        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf, params=ctx.nprm[2:])
+        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf, params=ctx.nprm[2:], side=bf)
+        g1_side_lp, g1_cs = _side_take(g1) if bf else (None, None)
         if not bf:
             g1_lp = g1
-        dbp = _bgrad(g1, pb_) if need[8] else None
-        dwp = _wgrad(g1_lp, att, D, D, M, pw_) if need[7] else None
+        dwp, dbp = _wgrad_bias(g1_lp, att, D, D, M, pw_, pb_, need[7], need[8], dy_f32=g1, dy_colsum=g1_cs)
         datt = torch.empty(M, D, dtype=T, device=dev)
         gemm(g1_lp, wp, datt, M=M, N=D, K=D, trans_b=True, ldb=D)
         dqkv = torch.empty(M, 3 * D, dtype=T, device=dev)
@@ -1639,11 +1640,10 @@ class SwinBlockFn(torch.autograd.Function):
         else:
             call("evp_window_attention_bwd", ptr(qkv), ptr(tab), ptr(rel), ptr(att), ptr(datt), ptr(dqkv), ptr(dtable), Bg, nG, N, heads,
                  R, scale, dt(qkv), stream_ptr())
-        dbq = _bgrad(dqkv, qkvb_) if need[6] else None
-        dwq = _wgrad(dqkv, ln1, 3 * D, D, M, qkvw_) if need[5] else None
+        dwq, dbq = _wgrad_bias(dqkv, ln1, 3 * D, D, M, qkvw_, qkvb_, need[5], need[6])
         dln1 = torch.empty(M, D, dtype=T, device=dev)
         gemm(dqkv, wq, dln1, M=M, N=D, K=3 * D, trans_b=True, ldb=D)
-        g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1, params=ctx.nprm[:2])
+        g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1, want_lp=bf, params=ctx.nprm[:2], side=bf)
         return (g0.view(Bg, N, D), dtable, None, dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None)
 
 
