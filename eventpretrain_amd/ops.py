@@ -1387,6 +1387,7 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x2d, n1w, n2w, mean1, rstd1, ln1, c1, a, x1, mean2, rstd2, ln2, h_pre, h_act, w1, w2, wf1, wf2, awf, mask)
         ctx.cfg = (B, H, W, Cc, Hd, int(mask_scale), tuple(aw.shape))
         ctx.prm = (c1w, c1b, c2w, c2b, f1w, f1b, f2w, f2b)
+        ctx.nprm = (n1w, n1b, n2w, n2b)
         return x2.view(B, HW, Cc)
 
     @staticmethod
@@ -1400,21 +1401,22 @@ class ConvBlockFn(torch.autograd.Function):
         bf = T == torch.bfloat16
         dev = g2.device
         g2 = _chk(g2.contiguous(), torch.float32).view(M, Cc)
-        g2_lp = cast(g2, T)
-        db2 = _bgrad(g2, f2b_) if need[14] else None
-        dwf2 = _wgrad(g2_lp, h_act, Cc, Hd, M, f2w_, tuple(f2w_.shape)) if need[13] else None
+        # as in ViTBlockFn: bf16 copy / column sums left by the LayerNorm backward of the block above, bias gradients on the
+        # weight-gradient launch, LayerNorm dgamma / dbeta through the grouped column sums
+        g2_side_lp, g2_cs = _side_take(g2) if bf else (None, None)
+        g2_lp = g2_side_lp if g2_side_lp is not None else cast(g2, T)
+        dwf2, db2 = _wgrad_bias(g2_lp, h_act, Cc, Hd, M, f2w_, f2b_, need[13], need[14], dy_f32=g2, shape=tuple(f2w_.shape), dy_colsum=g2_cs)
         dh_pre = torch.empty(M, Hd, dtype=T, device=dev)
         gemm(g2_lp, wf2, dh_pre, M=M, N=Hd, K=Cc, trans_b=True, ldb=Hd, act=ACT_DGELU, aux=h_pre)
-        db1 = _bgrad(dh_pre, f1b_) if need[12] else None
-        dwf1 = _wgrad(dh_pre, ln2, Hd, Cc, M, f1w_, tuple(f1w_.shape)) if need[11] else None
+        dwf1, db1 = _wgrad_bias(dh_pre, ln2, Hd, Cc, M, f1w_, f1b_, need[11], need[12], shape=tuple(f1w_.shape))
         dln2 = torch.empty(M, Cc, dtype=T, device=dev)
         gemm(dh_pre, wf1, dln2, M=M, N=Cc, K=Hd, trans_b=True, ldb=Cc)
-        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf)
+        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf, params=ctx.nprm[2:], side=bf)
+        g1_side_lp, g1_cs = _side_take(g1) if bf else (None, None)
         if not bf:
             g1_lp = g1
         # conv branch
-        dbc2 = _bgrad(g1, c2b_) if need[8] else None
-        dwc2 = _wgrad(g1_lp, a, Cc, Cc, M, c2w_, tuple(c2w_.shape)) if need[7] else None
+        dwc2, dbc2 = _wgrad_bias(g1_lp, a, Cc, Cc, M, c2w_, c2b_, need[7], need[8], dy_f32=g1, shape=tuple(c2w_.shape), dy_colsum=g1_cs)
         da = torch.empty(M, Cc, dtype=T, device=dev)
         gemm(g1_lp, w2, da, M=M, N=Cc, K=Cc, trans_b=True, ldb=Cc)
         dc1 = torch.empty(M, Cc, dtype=T, device=dev)
@@ -1424,11 +1426,10 @@ class ConvBlockFn(torch.autograd.Function):
         ws = torch.empty(ns * 26 * Cc, dtype=torch.float32, device=dev)
         call("evp_dwconv5x5_bwd", ptr(da), ptr(c1), dt(c1), ptr(mask), mask_scale, ptr(awf), B, H, W, Cc, ptr(dc1), ptr(daw), ptr(dab),
              ptr(ws), stream_ptr())
-        dbc1 = _bgrad(dc1, c1b_) if need[4] else None
-        dwc1 = _wgrad(dc1, ln1, Cc, Cc, M, c1w_, tuple(c1w_.shape)) if need[3] else None
+        dwc1, dbc1 = _wgrad_bias(dc1, ln1, Cc, Cc, M, c1w_, c1b_, need[3], need[4], shape=tuple(c1w_.shape))
         dln1 = torch.empty(M, Cc, dtype=T, device=dev)
         gemm(dc1, w1, dln1, M=M, N=Cc, K=Cc, trans_b=True, ldb=Cc)
-        g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1)
+        g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1, want_lp=bf, params=ctx.nprm[:2], side=bf)
         return (g0.view(B, H * W, Cc), dn1w, dn1b, dwc1, dbc1, daw.view(awshape), dab, dwc2, dbc2, dn2w, dn2b, dwf1, db1, dwf2, db2,
                 None, None, None, None)
 
