@@ -242,7 +242,10 @@ template <int DH, int NT, int NW, bool BIAS>
 __device__ __forceinline__ void attn_bwd_body(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse, bf16_t *dqkv, int N,
                                               int heads, float scale, const float *addm, const float *addmT, int nG, const int b, const int h,
                                               f32x4 (&dacc)[NT]) {
-  constexpr int NP = 16 * NT, IMG = NP * DH * 2, KS = DH / 32, DT = DH / 16, CH = 4;
+  #ifndef ATTN_CH
+#define ATTN_CH 4
+#endif
+  constexpr int NP = 16 * NT, IMG = NP * DH * 2, KS = DH / 32, DT = DH / 16, CH = ATTN_CH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *Qs = smem, *Ks = smem + IMG, *Vs = smem + 2 * IMG, *Gs = smem + 3 * IMG;   // Gs = dO
   float *Ls = reinterpret_cast<float *>(smem + 4 * IMG), *Ds = Ls + NP;          // log-sum-exp, delta = rowsum(dO * O)
