@@ -107,7 +107,10 @@ class StaticPatternPlan:
             off += (nb + 15) // 16 * 16
         self.nbytes = off
         self.dev_buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device)
-        self.pins = [torch.zeros(self.nbytes, dtype=torch.uint8).pin_memory() for _ in range(self.RING)]
+        self._cuda = self.device.type == "cuda"     # a CPU "device" is only used by the host-logic tests
+        self.pins = [torch.zeros(self.nbytes, dtype=torch.uint8) for _ in range(self.RING)]
+        if self._cuda:
+            self.pins = [p_.pin_memory() for p_ in self.pins]
         self.pin_events = [None] * self.RING
         self.turn = 0
         tdt = {np.int32: torch.int32, np.int64: torch.int64}
@@ -165,9 +168,10 @@ class StaticPatternPlan:
         for name, arr in staged.items():
             self._host(pin, name)[...] = arr
         self.dev_buf.copy_(pin, non_blocking=True)
-        ev = self.pin_events[t] or torch.cuda.Event()
-        ev.record()
-        self.pin_events[t] = ev
+        if self._cuda:
+            ev = self.pin_events[t] or torch.cuda.Event()
+            ev.record()
+            self.pin_events[t] = ev
         for i, lay in enumerate(layouts):
             lay.coords_dev = self.view[f"s{i}.coords64"]
             self.stages[i].layout = lay

@@ -148,3 +148,63 @@ def test_swin_host_grouping_matches_oracle():
     assert np.array_equal(lay.coords, d["coords_l1"][0])
     rows, inv, lay2 = PatchMerging.plan(lay)
     assert np.array_equal(lay2.coords, d["coords_l2"][0]) and np.array_equal(rows[inv], np.arange(lay.n))
+
+
+def test_swin_static_plan_tables_are_a_padded_form_of_the_pattern_plan():
+    """Host logic of the fixed-shape Swin window plan (model/backbone/swin.py StaticPatternPlan, CPU buffers here): for random
+    visibility patterns the fixed-shape tables describe the same grouping rule as the pattern-sized plan -- every visible token
+    sits in exactly one slot, slots of one group never mix windows unmasked, padding slots are masked and receive no gradient,
+    the adjoint tables invert the gathers -- and a pattern that needs more groups than the shape holds is refused untouched."""
+    import types
+    import torch
+    from eventpretrain_amd.model.backbone import swin as swin_mod
+    from eventpretrain_amd.model.sub_module.swin_block import PlanOverflow
+
+    class _Blk:        # what StaticPatternPlan reads from a BasicBlock
+        def __init__(self, res, last):
+            self.input_resolution = (res, res)
+            self.window_size = min(7, res)
+            self.shift_size = 0 if res <= 7 else 3
+            self.downsample = None if last else object()
+
+    model = types.SimpleNamespace(patches_resolution=[56, 56], num_patches=49,
+                                  swin_block=[_Blk(56, False), _Blk(28, False), _Blk(14, False), _Blk(7, True)])
+    plan = swin_mod.StaticPatternPlan(model, "cpu", keep=24, slack=1.25)
+    rng = np.random.default_rng(5)
+    for _ in range(6):
+        vis = np.zeros(49, dtype=bool)
+        vis[rng.permutation(49)[:24]] = True
+        plan.load(vis)
+        n0 = plan.geom[0][1]
+        assert plan.tok_ids.shape[0] == n0 == 24 * 64
+        for i, (r, n, mods, has_merge) in enumerate(plan.geom):
+            lay = plan.stages[i].layout
+            assert lay.n == n and lay.res == r
+            tokmap = plan.view[f"s{i}.tokmap"].numpy()
+            assert (tokmap >= 0).sum() == n and np.array_equal(np.sort(tokmap[tokmap >= 0]), np.arange(n))
+            for shift, mode, gs, ng in mods:
+                rel = plan.view[f"s{i}.{shift}.rel"].numpy()
+                assert rel.shape == (ng, gs, gs)
+                if mode != "grouping":
+                    continue
+                gather = plan.view[f"s{i}.{shift}.shuffle"].numpy()
+                gadj = plan.view[f"s{i}.{shift}.shuffle_adj"].numpy()
+                scat = plan.view[f"s{i}.{shift}.unshuffle"].numpy()
+                sadj = plan.view[f"s{i}.{shift}.unshuffle_adj"].numpy()
+                real = sadj >= 0                                   # slots that hold a token
+                assert real.sum() == n and np.array_equal(np.sort(sadj[real]), np.arange(n))
+                assert np.array_equal(gather[real], sadj[real])    # a real slot gathers its own token
+                assert np.array_equal(scat, gadj) and np.array_equal(sadj[scat], np.arange(n))   # token -> slot -> token
+                pad = ~real.reshape(ng, gs)
+                assert (rel[pad] == -1).all() and (rel.transpose(0, 2, 1)[pad] == -1).all()        # padding rows and columns masked
+                # unmasked pairs share a window of the (shifted) 7x7 partition
+                ws = 7
+                c = lay.coords[np.where(real, sadj, 0)].reshape(ng, gs, 2)
+                w = (c + (ws - shift) % ws) // ws
+                same = (w[:, :, None, :] == w[:, None, :, :]).all(-1) & real.reshape(ng, gs)[:, :, None] & real.reshape(ng, gs)[:, None, :]
+                assert np.array_equal(rel >= 0, same)
+    tight = swin_mod.StaticPatternPlan(model, "cpu", keep=24, slack=0.9)
+    before = tight.dev_buf.clone()
+    with pytest.raises(PlanOverflow):
+        tight.load(vis)
+    assert torch.equal(tight.dev_buf, before) and tight.loads == 0
