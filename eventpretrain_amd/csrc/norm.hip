@@ -692,13 +692,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_v4(const void *dy, const voi
       for (int j = 0; j < 4; ++j)
         if (!(yv[j] > 0.f)) d[j] = 0.f;
     }
+    const float4 is4 = *reinterpret_cast<const float4 *>(invstd + c), mu4 = *reinterpret_cast<const float4 *>(mean + c);
+    const float4 s04 = *reinterpret_cast<const float4 *>(sum_dy + c), s14 = *reinterpret_cast<const float4 *>(sum_dy_xhat + c);
+    const float4 g4 = gamma ? *reinterpret_cast<const float4 *>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float isa[4] = {is4.x, is4.y, is4.z, is4.w}, mua[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
+    const float s0a[4] = {s04.x, s04.y, s04.z, s04.w}, s1a[4] = {s14.x, s14.y, s14.z, s14.w}, ga[4] = {g4.x, g4.y, g4.z, g4.w};
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float is = invstd[c + j];
-      const float xh = (xv[j] - mean[c + j]) * is;
-      const float g = gamma ? gamma[c + j] : 1.f;
-      o[j] = g * is * (d[j] - sum_dy[c + j] * invR - xh * sum_dy_xhat[c + j] * invR);
+      const float xh = (xv[j] - mua[j]) * isa[j];
+      o[j] = ga[j] * isa[j] * (d[j] - s0a[j] * invR - xh * s1a[j] * invR);
     }
     st4_any(dx, dtype, i, make_float4(o[0], o[1], o[2], o[3]));
   }
