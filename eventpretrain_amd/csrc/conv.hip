@@ -237,12 +237,25 @@ template <> __device__ __forceinline__ void chunk_scale<bf16_t>(uint4 &v, float 
     u[i] = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
   }
 }
-// stage rows [y0 - 2, y0 + R + 2) x columns [-2, W + 2) of image b, channels [c0, c0 + CB): band[row][col + 2][128 bytes]
+// stage rows [y0 - 2, y0 + R + 2) x columns [-2, W + 2) of image b, channels [c0, c0 + CB): band[row][col + 2][128 bytes].
+// MASKED: the keep factor of every band position is worked out ONCE per position into `keep_s` (one mask load and two integer
+// divisions per position instead of per 16-byte chunk; 0 for the halo), and positions with keep 0 -- half of them at mask ratio
+// 0.5 -- are not loaded at all.
 template <typename T, int R, bool MASKED>
 __device__ __forceinline__ void stage_band(const T *__restrict__ src, const float *__restrict__ mask, int b, int y0, int H, int W, int C, int c0,
-                                           int ms, int mgw, int mL, char *band, int tid) {
+                                           int ms, int mgw, int mL, char *band, float *keep_s, int tid) {
   constexpr int EPC = BandCfg<T>::EPC;
-  const int WP = W + 4, total = (R + 4) * WP * 8;
+  const int WP = W + 4, npos = (R + 4) * WP, total = npos * 8;
+  if constexpr (MASKED) {
+    for (int pos = tid; pos < npos; pos += 256) {
+      const int col = pos % WP, row = pos / WP;
+      const int yy = y0 - 2 + row, xx = col - 2;
+      float k = 0.f;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) k = mask ? keep_at(mask, b, yy, xx, ms, mgw, mL) : 1.f;
+      keep_s[pos] = k;
+    }
+    __syncthreads();
+  }
   for (int base = tid; base < total; base += 256 * 4) {
     uint4 v[4];
     float k[4];
@@ -254,17 +267,19 @@ __device__ __forceinline__ void stage_band(const T *__restrict__ src, const floa
       if (i < total) {
         const int ch = i & 7, col = (i >> 3) % WP, row = (i >> 3) / WP;
         const int yy = y0 - 2 + row, xx = col - 2;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-          if (MASKED && mask) k[u] = keep_at(mask, b, yy, xx, ms, mgw, mL);
-          v[u] = *reinterpret_cast<const uint4 *>(src + (((int64_t)b * H + yy) * W + xx) * C + c0 + ch * EPC);
+        bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        if constexpr (MASKED) {
+          k[u] = keep_s[i >> 3];
+          in = k[u] != 0.f;
         }
+        if (in) v[u] = *reinterpret_cast<const uint4 *>(src + (((int64_t)b * H + yy) * W + xx) * C + c0 + ch * EPC);
       }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = base + u * 256;
       if (i < total) {
-        if (MASKED && k[u] != 1.f) chunk_scale<T>(v[u], k[u]);
+        if (MASKED && k[u] != 1.f && k[u] != 0.f) chunk_scale<T>(v[u], k[u]);
         *reinterpret_cast<uint4 *>(band + (int64_t)(i >> 3) * 128 + (i & 7) * 16) = v[u];
       }
     }
@@ -289,7 +304,7 @@ __global__ __launch_bounds__(256) void dwconv_band_kernel(const T *__restrict__ 
   const int tid = threadIdx.x;
   const int c0 = blockIdx.x * CB;
   const int r0 = blockIdx.y * R, b = r0 / H, y0 = r0 - b * H;          // H % R == 0: a band never crosses images
-  stage_band<T, R, !BWD>(src, mask, b, y0, H, W, C, c0, ms, mgw, mL, band, tid);
+  stage_band<T, R, !BWD>(src, mask, b, y0, H, W, C, c0, ms, mgw, mL, band, reinterpret_cast<float *>(band + (int64_t)(R + 4) * (W + 4) * 128), tid);
   const int pair = tid % NPAIR, seg = tid / NPAIR, row = seg / SPR, sx = seg % SPR;
   const int c = c0 + pair * 2;
   float k0[5][5], k1[5][5];
@@ -356,7 +371,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_band_kernel(const T *__
   for (int r0 = blockIdx.y * DW_ROWS; r0 < (blockIdx.y + 1) * DW_ROWS && r0 < nrows; r0 += R) {
     const int b = r0 / H, y0 = r0 - b * H;                               // H % R == 0
     __syncthreads();                                                     // the previous band has been consumed
-    stage_band<T, R, true>(in, mask, b, y0, H, W, C, c0, ms, mgw, mL, band, tid);
+    stage_band<T, R, true>(in, mask, b, y0, H, W, C, c0, ms, mgw, mL, band, reinterpret_cast<float *>(gband + (int64_t)R * W * 128), tid);
     for (int i = tid; i < R * W * 8; i += 256) {
       const int ch = i & 7, pos = i >> 3;
       *reinterpret_cast<uint4 *>(gband + (int64_t)pos * 128 + ch * 16) =
@@ -411,9 +426,10 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_band_kernel(const T *__
 template <typename T> static inline bool band_ok(int H, int W, int C) {
   return H % 4 == 0 && DW_ROWS % 2 == 0 && W >= 8 && W <= 64 && C % BandCfg<T>::CB == 0;
 }
-template <typename T> static inline size_t band_smem_fwd(int W) { return (size_t)8 * (W + 4) * 128; }
+template <typename T> static inline size_t band_smem_fwd(int W) { return (size_t)8 * (W + 4) * 128 + (size_t)8 * (W + 4) * sizeof(float); }
 template <typename T> static inline size_t band_smem_bwdw(int W) {
-  const size_t a = (size_t)6 * (W + 4) * 128 + (size_t)2 * W * 128, r = (size_t)BandCfg<T>::NSEG * 26 * BandCfg<T>::CB * sizeof(float);
+  const size_t a = (size_t)6 * (W + 4) * 128 + (size_t)2 * W * 128 + (size_t)6 * (W + 4) * sizeof(float),
+               r = (size_t)BandCfg<T>::NSEG * 26 * BandCfg<T>::CB * sizeof(float);
   return a > r ? a : r;
 }
 
