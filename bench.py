@@ -9,9 +9,10 @@ backward) -> fused AdamW -> zero_grad, on a synthetic batch that is already resi
 K1 kernel from synthetic event clips before the timed region). Prints ONE JSON line on rank 0.
 
 Extra objects on the same line:
-  roofline      dominant kernel = the 128x128-tile bf16 MFMA GEMM family; achieved = algorithmic FLOPs of its launches in
-                one step / their HIP-event-measured duration (instrumented steps after the timed region), peak = 2.5
-                PFLOP/s dense bf16 (MI355X_MICROARCH.md).
+  roofline      dominant kernel = the forward / data-gradient bf16 MFMA GEMM family; achieved = algorithmic FLOPs of its launches in
+                one step / the sum of their durations INSIDE the replayed step (in-kernel wall-clock stamps, StampedStep);
+                `frac_warm` = the same launches re-launched back to back between HIP events; peak = 2.5 PFLOP/s dense bf16
+                (MI355X_MICROARCH.md). The same object is emitted for every --config.
   voxel         K1 event->voxel scatter: achieved GB/s on 64 clips x 100k events (4.2 MB algorithmic bytes per clip)
                 against the 8 TB/s HBM peak, HIP-event timed.
   cpu_baseline  the CPU oracle (oracle/model_oracle.py: torch fp32 restatement, kind "port") timed on this box's host
@@ -141,20 +142,35 @@ class GemmTimer:
 
     @staticmethod
     def _inst(a, out, kw):
+        """Kernel instantiation a call lands on = the launcher's own rule (gemm.hip pick_tile, gemm_g4.hip evp_g4_gemm_pick)."""
         M, N, K = kw["M"], kw["N"], kw["K"]
         nb = kw.get("batch", (1, 1))
         act = kw.get("act", 0)
         epi = 1 if act in (1, 3) else 2 if act in (2, 4) else 0
+        bf = a.dtype == torch.bfloat16
+        names = ("bf16" if bf else "f32", "f32" if out.dtype == torch.float32 else "bf16", epi, int(bool(kw.get("trans_a"))), int(bool(kw.get("trans_b"))))
+        tile = kw.get("tile", 0)
+        g4_ok = (bf and out.dtype == torch.bfloat16 and not kw.get("trans_a") and nb == (1, 1) and K % 32 == 0 and K >= 96 and N % 8 == 0
+                 and kw.get("residual") is None and not kw.get("accumulate") and not (epi == 1 and kw.get("trans_b")) and not (epi == 2 and not kw.get("trans_b")))
+        if tile == 0 and g4_ok and N >= 1024 and M >= 2048 and GemmTimer.g4_fwd and epi != 1:
+            one_round = ((M + 255) // 256) * ((N + 255) // 256) <= 256
+            tile = 20 if one_round else (22 if kw.get("trans_b") else 0)
+        if tile in (20, 21, 22):
+            return ("g4x",) + names + ({20: "256x256", 21: "256x128", 22: "128x256"}[tile],)
         t128 = ((M + 127) // 128) * ((N + 127) // 128) * nb[0] * nb[1]
         splittable = bool(kw.get("trans_a")) and out.dtype == torch.float32 and kw.get("bias") is None and act == 0 and kw.get("residual") is None \
             and kw.get("aux") is None and nb == (1, 1) and K >= 2048
-        tile = kw.get("tile", 0) or (1 if (M >= 128 and N >= 128 and (t128 >= 192 or splittable)) else 2)
-        # the launcher's own rule (gemm.hip pick_tile): 96x128 tiles when 128x128 would give 257..384 tiles of one round
+        tile = tile or (1 if (M >= 128 and N >= 128 and (t128 >= 192 or splittable)) else 2)
         t96 = ((M + 95) // 96) * ((N + 127) // 128)
-        if not kw.get("tile", 0) and tile == 1 and a.dtype == torch.bfloat16 and not kw.get("trans_a") and nb == (1, 1) and t128 > 256 and t96 <= 512:
+        if not kw.get("tile", 0) and tile == 1 and bf and not kw.get("trans_a") and nb == (1, 1) and t128 > 256 and t96 <= 512:
             tile = 4
-        return ("bf16" if a.dtype == torch.bfloat16 else "f32", "f32" if out.dtype == torch.float32 else "bf16", epi,
-                int(bool(kw.get("trans_a"))), int(bool(kw.get("trans_b"))), {1: "128x128", 2: "64x64", 4: "96x128"}.get(tile, str(tile)))
+        return ("gemm",) + names + ({1: "128x128", 2: "64x64", 4: "96x128"}.get(tile, str(tile)),)
+
+    g4_fwd = True
+
+    @staticmethod
+    def kernel_name(inst):
+        return "%s_kernel<in=%s,out=%s,epi=%d,transA=%d,transB=%d,tile=%s>" % inst
 
     def summary(self, reps=10):
         sigs = {}
@@ -182,8 +198,106 @@ class GemmTimer:
             g[2] += count
         out = []
         for inst, (fl, sec, n) in agg.items():
-            out.append(dict(kernel="gemm_kernel<in=%s,out=%s,epi=%d,transA=%d,transB=%d,tile=%s>" % inst, launches_per_step=n,
+            out.append(dict(kernel=GemmTimer.kernel_name(inst), launches_per_step=n,
                             avg_us=sec / n * 1e6, tflops=fl / sec / 1e12, ms_per_step=sec * 1e3, flops_per_step=fl))
+        out.sort(key=lambda d: -d["ms_per_step"])
+        return out
+
+
+class StampedStep:
+    """IN-STEP kernel durations of every GEMM launch of one optimiser step, measured where the launches run: inside a
+    replayed HIP graph, operands just produced by the previous kernel. A second step executor is captured with the
+    library's in-kernel stamps on (evp_gemm_set_stamp_buffer: every GEMM launch gets a slot, each of its workgroups writes
+    the chip-wide 100 MHz counter when it starts and after its last store was acknowledged); ops.gemm and the grouped
+    weight-gradient entries are wrapped during that capture to record WHAT each stamped launch computes. The graph is then
+    replayed and max(end) - min(start) per slot read back. HIP events cannot do this (they would need a node between any
+    two kernels of the graph); the warm re-launch figure of GemmTimer is printed beside it as `frac_warm`."""
+    STRIDE = 2 * 4096        # uint64 per slot (EVP_STAMP_WGS workgroups x {start, end}), csrc/gemm_common.h
+    GROUPED = {"evp_gemm_grouped_tn_bf16": ("gemm_grouped_tn_kernel<128,128>", 128),
+               "evp_gemm_grouped_tn_g4_bf16": ("gemm_g4_grouped_tn_kernel (256x256, one wave per SIMD, 32x32x16)", 256)}
+
+    def __init__(self, make_executor, device, n_slots=2048):
+        from eventpretrain_amd import ops as _ops
+        from eventpretrain_amd._lib import call
+        self.buf = torch.zeros(n_slots * self.STRIDE, dtype=torch.int64, device=device)
+        self.n_slots = n_slots
+        self.launches = []                      # (slot, kernel name, flops) of the launches made while the graph was captured
+        pending_grouped = {}
+        orig_gemm, orig_call, orig_flush = _ops.gemm, _ops.call, _ops._deferred.flush
+
+        def rec_gemm(a, b, out, **kw):
+            capturing = torch.cuda.is_current_stream_capturing()
+            idx = call("evp_gemm_stamp_count")
+            r = orig_gemm(a, b, out, **kw)
+            if capturing and call("evp_gemm_stamp_count") == idx + 1:
+                nb = kw.get("batch", (1, 1))
+                self.launches.append((idx % n_slots, GemmTimer.kernel_name(GemmTimer._inst(a, out, kw)), 2.0 * kw["M"] * kw["N"] * kw["K"] * nb[0] * nb[1]))
+            return r
+
+        def rec_call(name, *a_):
+            if name not in self.GROUPED:
+                return orig_call(name, *a_)
+            capturing = torch.cuda.is_current_stream_capturing()
+            idx = call("evp_gemm_stamp_count")
+            r = orig_call(name, *a_)
+            fl, tiles = pending_grouped.pop(name, (0.0, 0))
+            if capturing and call("evp_gemm_stamp_count") == idx + 1:
+                self.launches.append((idx % n_slots, "%s (weight gradients of the step, %d tiles)" % (self.GROUPED[name][0], tiles), fl))
+            return r
+
+        def rec_flush():
+            for (_, _, _, n_out, k_in, rows, _bp) in _ops._deferred.w:      # the routing rule of _DeferredGrads._build
+                big = _ops._use_wgrad_g4 and rows % 32 == 0 and rows >= 96 and n_out >= 256 and k_in >= 256
+                name = "evp_gemm_grouped_tn_g4_bf16" if big else "evp_gemm_grouped_tn_bf16"
+                T_ = self.GROUPED[name][1]
+                fl, tiles = pending_grouped.get(name, (0.0, 0))
+                pending_grouped[name] = (fl + 2.0 * n_out * k_in * rows, tiles + ((n_out + T_ - 1) // T_) * ((k_in + T_ - 1) // T_))
+            return orig_flush()
+
+        call("evp_gemm_set_stamp_buffer", self.buf.data_ptr(), n_slots)
+        _ops.gemm, _ops.call, _ops._deferred.flush = rec_gemm, rec_call, rec_flush
+        try:
+            self.executor = make_executor()
+        finally:
+            _ops.gemm, _ops.call, _ops._deferred.flush = orig_gemm, orig_call, orig_flush
+            call("evp_gemm_set_stamp_buffer", None, 0)       # later launches are not stamped; the captured ones keep their slots
+        self.ok = self.executor.graph is not None and len(self.launches) > 0 and len({l[0] for l in self.launches}) == len(self.launches)
+
+    def measure(self, replays=6):
+        """-> per-launch mean duration in seconds (list aligned with self.launches), averaged over `replays` replays."""
+        slots = torch.tensor([l[0] for l in self.launches], dtype=torch.int64, device=self.buf.device)
+        view = self.buf.view(self.n_slots, self.STRIDE)
+        acc = torch.zeros(len(self.launches), dtype=torch.float64)
+        for _ in range(2):
+            self.executor.step()
+        n = 0
+        for _ in range(replays):
+            self.buf.zero_()
+            self.executor.step()
+            torch.cuda.synchronize()
+            st = view.index_select(0, slots).cpu().numpy().view(np.uint64).reshape(len(self.launches), -1, 2)
+            start = ~st[:, :, 0]                     # stored complemented: 0 = not written
+            have = st[:, :, 0] != 0
+            t0 = np.where(have, start, np.uint64(0xFFFFFFFFFFFFFFFF)).min(axis=1)
+            t1 = st[:, :, 1].max(axis=1)
+            if not (have.any(axis=1).all() and (t1 > t0).all()):
+                continue
+            acc += torch.from_numpy((t1 - t0).astype(np.float64) * 1e-8)       # 100 MHz ticks
+            n += 1
+        return (acc / max(n, 1)).tolist() if n else None
+
+    def summary(self, replays=6):
+        durs = self.measure(replays)
+        if durs is None:
+            return None
+        agg = {}
+        for (slot, name, fl), sec in zip(self.launches, durs):
+            g = agg.setdefault(name, [0.0, 0.0, 0])
+            g[0] += fl
+            g[1] += sec
+            g[2] += 1
+        out = [dict(kernel=k, launches_per_step=n, avg_us=sec / n * 1e6, tflops=fl / sec / 1e12, ms_per_step=sec * 1e3, flops_per_step=fl)
+               for k, (fl, sec, n) in agg.items()]
         out.sort(key=lambda d: -d["ms_per_step"])
         return out
 
@@ -223,22 +337,22 @@ _PMC_CONFIG_OK = True      # the committed counters are of the headline workload
 
 
 def pmc_traffic(kernel_key):
-    """HBM-side bytes per launch of a kernel from the committed PMC summary (profiles/r01_pmc_traffic.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes with the guide's gfx950 correction), or None. bench.py cannot collect
-    PMC counters itself; the figure is from the same command profiled offline."""
+    """(HBM-side bytes per launch, source file) of a kernel from the newest committed PMC summary under profiles/ (separate rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE passes of THIS command with the guide's gfx950 correction, tools/make_profiles.py), or (None, None).
+    bench.py cannot collect PMC counters itself; the file the figure comes from is named next to it (`traffic_source`)."""
     if not _PMC_CONFIG_OK and "voxel" not in kernel_key:
-        return None
+        return None, None
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(here, fn)) as f:
                 k = json.load(f)["kernels"]
             for name, v in k.items():
                 if name in kernel_key:
-                    return float(v["traffic_bytes"])
+                    return float(v["traffic_bytes"]), "profiles/" + fn
         except Exception:
             pass
-    return None
+    return None, None
 
 
 def cpu_voxel_baseline():
@@ -322,11 +436,15 @@ def main():
     step_prepare = None
     if phase == "rec":
         fwd, noise_shape = (lambda m, x, y, noise: m(x, y, is_rec=True, noise=noise)), (args.batch, cells)
-        if is_swin:
+        if is_swin and not multi:
             # Swin: the window plan is host work per pattern. The noise is drawn on the HOST (seeded per rank), the backbone's
             # fixed-shape plan tables are refreshed by one H2D copy before each replay (SwinTransformer.enable_static_plan), so
             # ONE captured graph serves every pattern; a pattern that overflows the fixed group count runs that step eagerly.
             step_prepare = model.backbone.enable_static_plan(device)
+        elif is_swin:
+            # N > 1: every rank draws its own pattern, so a per-rank eager fall-back could leave the all-reduces unmatched
+            # (engine.GraphedStep refuses the hook together with a reducer): the data-parallel Swin step runs eagerly
+            use_graph = False
     else:
         fwd, noise_shape = (lambda m, x, y, noise: m(x, y)), None
     executor = GraphedStep(model, opt, fwd, [vox, tgt], noise_shape=noise_shape, generator=gen, reducer=reducer, use_graph=use_graph,
@@ -410,7 +528,6 @@ def main():
         orig_call = _ops.call
 
         GROUPED = {"evp_gemm_grouped_tn_bf16": ("gemm_grouped_tn_kernel<128,128>", 128),
-                   "evp_gemm_grouped_tn256_bf16": ("gemm256_grouped_tn_kernel (256x256 ring)", 256),
                    "evp_gemm_grouped_tn_g4_bf16": ("gemm_g4_grouped_tn_kernel (256x256, one wave per SIMD, 32x32x16)", 256)}
 
         def timed_call(name, *a_):
@@ -441,9 +558,8 @@ def main():
 
         def counting_flush():
             for (_, _, _, n_out, k_in, rows, _bp) in _ops._deferred.w:
-                big = _ops._use_wgrad256 and rows % 64 == 0 and n_out >= 256 and k_in >= 256      # the routing rule of flush()
-                name = ("evp_gemm_grouped_tn_g4_bf16" if (_ops._use_wgrad_g4 and rows >= 96) else "evp_gemm_grouped_tn256_bf16") if big \
-                    else "evp_gemm_grouped_tn_bf16"
+                big = _ops._use_wgrad_g4 and rows % 32 == 0 and rows >= 96 and n_out >= 256 and k_in >= 256      # the routing rule of flush()
+                name = "evp_gemm_grouped_tn_g4_bf16" if big else "evp_gemm_grouped_tn_bf16"
                 T_ = GROUPED[name][1]
                 g_ = grouped.setdefault(name, {})
                 g_["flops"] = g_.get("flops", 0.0) + 2.0 * n_out * k_in * rows
@@ -482,30 +598,55 @@ def main():
                            relaunch_median_us=g_["ms"] * 1e3, launches_per_step=1, avg_us=sec * 1e6, tflops=g_["flops"] / sec / 1e12, ms_per_step=sec * 1e3,
                            flops_per_step=g_["flops"]))
         ks.sort(key=lambda d: -d["ms_per_step"])
+        # ---- the same launches timed IN the step (in-kernel stamps inside a replayed graph); see StampedStep
+        ks_step = None
+        if use_graph and executor.graph is not None:
+            try:
+                GemmTimer.g4_fwd = True
+                st = StampedStep(lambda: GraphedStep(model, opt, fwd, [vox, tgt], noise_shape=noise_shape, generator=gen, reducer=None, use_graph=True,
+                                                     warmup=2, step_prepare=step_prepare, host_generator=torch.Generator().manual_seed(100 + rank)), device)
+                ks_step = st.summary() if st.ok else None
+                del st
+            except Exception as e:      # a measurement aid must not lose the bench line
+                result["in_step_timing_error"] = repr(e)
         if ks:
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else 157.3
-            # dominant kernel = the FAMILY with the most time: the 128x128 / 96x128-tile forward / data-gradient GEMM, whose
-            # instantiations (layout x epilogue x output type) rocprofv3 lists under separate names
-            fam = [d for d in ks if d["kernel"].startswith("gemm_kernel<") and ("128x128" in d["kernel"] or "96x128" in d["kernel"])]
-            grp = [d for d in ks if "grouped" in d["kernel"]]
+            # dominant kernel = the FAMILY with the most time: the forward / data-gradient GEMMs (128x128 / 96x128 tiles of the
+            # 16x16x32 body, 256x256 / 128x256 tiles of the G4 body), whose instantiations rocprofv3 lists under separate names
+            is_fam = lambda d: d["kernel"].startswith(("gemm_kernel<", "g4x_kernel<"))
+            is_grp = lambda d: "grouped" in d["kernel"]
 
-            def fam_entry(ds, name, note):
+            def fam_entry(ds_step, ds_warm, name, key):
+                ds = ds_step if ds_step else ds_warm
                 fl_, sec_, n_ = sum(d["flops_per_step"] for d in ds), sum(d["ms_per_step"] for d in ds) * 1e-3, sum(d["launches_per_step"] for d in ds)
-                return {"bound": "mfma", "achieved": fl_ / sec_ / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl_ / sec_ / 1e12 / peak,
-                        "traffic": pmc_traffic(name), "kernel": name, "avg_launch_us": sec_ / n_ * 1e6, "launches_per_step": n_,
-                        "ms_per_step_in_kernel": sec_ * 1e3, "note": note}
-            note = ("achieved = algorithmic 2MNK FLOPs of these launches in one step / their HIP-event durations (each distinct "
-                    "call re-launched 10x between two events on the launch stream; the one-per-step grouped weight-gradient launch: "
-                    "its launch inside the instrumented step, between its own events -- re-launching this milliseconds-long MFMA-dense "
-                    "kernel back to back reads 10-20 % long, the chip clocks down; relaunch_median_us in gemm_kernels)")
+                tr, src = pmc_traffic(key)
+                e_ = {"bound": "mfma", "achieved": fl_ / sec_ / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl_ / sec_ / 1e12 / peak,
+                      "traffic": tr, "traffic_source": src, "kernel": name, "avg_launch_us": sec_ / n_ * 1e6, "launches_per_step": n_,
+                      "ms_per_step_in_kernel": sec_ * 1e3}
+                if ds_step:
+                    e_["frac_in_step"] = e_["frac"]
+                    e_["method"] = ("achieved = algorithmic 2MNK FLOPs of these launches in one step / the sum of their durations INSIDE the replayed "
+                                    "step graph (in-kernel wall-clock stamps, max(end) - min(start) per launch, mean of 6 replays; bench.py StampedStep); "
+                                    "frac_warm = the same launches re-launched back to back between two HIP events (operands cache-warm)")
+                if ds_warm:
+                    fw, sw = sum(d["flops_per_step"] for d in ds_warm), sum(d["ms_per_step"] for d in ds_warm) * 1e-3
+                    e_["frac_warm"] = fw / sw / 1e12 / peak
+                    e_["ms_per_step_in_kernel_warm"] = sw * 1e3
+                return e_
             entries = []
-            if fam:
-                entries.append(fam_entry(fam, "gemm_kernel<...,tile=128x128|96x128> (forward + data-gradient GEMM family, %d instantiations)" % len(fam), note))
-            if grp:
-                entries.append(fam_entry(grp[:1], grp[0]["kernel"], note))
+            fam_w, grp_w = [d for d in ks if is_fam(d)], [d for d in ks if is_grp(d)]
+            fam_s = [d for d in ks_step if is_fam(d)] if ks_step else None
+            grp_s = [d for d in ks_step if is_grp(d)] if ks_step else None
+            if fam_w or fam_s:
+                entries.append(fam_entry(fam_s, fam_w, "gemm_kernel<...> + g4x_kernel<...> (forward + data-gradient GEMM family, %d instantiations)"
+                                         % len(fam_s or fam_w), "gemm_kernel<"))
+            if grp_w or grp_s:
+                gs = sorted(grp_s, key=lambda d: -d["ms_per_step"])[:1] if grp_s else None
+                gw = [d for d in grp_w if gs is None or d["kernel"].split(" (")[0] == gs[0]["kernel"].split(" (")[0]][:1] or grp_w[:1]
+                entries.append(fam_entry(gs, gw, (gs or gw)[0]["kernel"], (gs or gw)[0]["kernel"]))
             entries.sort(key=lambda e_: -e_["ms_per_step_in_kernel"])
             if not entries:
-                entries.append(fam_entry(ks[:1], ks[0]["kernel"], note))
+                entries.append(fam_entry(None, ks[:1], ks[0]["kernel"], ks[0]["kernel"]))
             result["roofline"] = entries[0]
             if len(entries) > 1:
                 result["roofline_second"] = entries[1]
@@ -514,7 +655,9 @@ def main():
             result["step_mfma_frac_launched"] = result["step_tflops_launched"] / peak
             if not headline:
                 result["step_tflops_per_gpu"], result["step_mfma_frac"] = result["step_tflops_launched"], result["step_mfma_frac_launched"]
-            result["gemm_kernels"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items() if k != "flops_per_step"} for d in ks]
+            rnd = lambda ds: [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items() if k != "flops_per_step"} for d in ds]
+            result["gemm_kernels_in_step"] = rnd(ks_step) if ks_step else None
+            result["gemm_kernels_warm"] = rnd(ks)
         # ---- K1 voxel scatter (HBM-bound)
         from eventpretrain_amd.dataset.dataset_utils.events_to_voxel_grid import voxel_grid_batch
         out = torch.empty_like(vox)
@@ -531,7 +674,8 @@ def main():
         bytes_ = args.batch * (n_ev * 32 + 5 * S * S * 4)
         result["voxel"] = {"bound": "hbm", "achieved": bytes_ / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": bytes_ / sec / 1e9 / HBM_PEAK_GBS,
-                           "traffic": (pmc_traffic("voxel_bin_kernel") or 0) + (pmc_traffic("voxel_cuts_kernel") or 0) or None,
+                           "traffic": (pmc_traffic("voxel_bin_kernel")[0] or 0) + (pmc_traffic("voxel_cuts_kernel")[0] or 0) or None,
+                           "traffic_source": pmc_traffic("voxel_bin_kernel")[1],
                            "kernel": "voxel_cuts_kernel+voxel_bin_kernel",
                            "us_per_batch": sec * 1e6, "clips_per_s": args.batch / sec, "events_per_s": args.batch * n_ev / sec,
                            "algorithmic_bytes_per_clip": n_ev * 32 + 5 * S * S * 4}

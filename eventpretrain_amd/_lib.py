@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
                 ("C", _vp), ("c_dtype", _i), ("ldc", _i64), ("strideC0", _i64), ("strideC1", _i64),
                 ("batch0", _i), ("batch1", _i), ("alpha", _f), ("bias", _vp), ("act", _i),
                 ("aux", _vp), ("ldaux", _i64), ("residual", _vp), ("ldres", _i64),
-                ("accumulate", _i), ("tile", _i), ("splitk", _i), ("sk_workspace", _vp), ("sk_workspace_bytes", _i64)]
+                ("accumulate", _i), ("tile", _i), ("splitk", _i)]
 
 
 # name -> argtypes (all return int status unless listed in _OTHER_RESTYPE)
@@ -39,11 +39,11 @@ SIGNATURES = {
     "evp_density_noise": [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "evp_gemm": [C.POINTER(GemmDesc), _vp],
     "evp_gemm_grouped_tn_bf16": [_vp, _vp, _i, _vp],
-    "evp_gemm_grouped_tn256_bf16": [_vp, _vp, _i, _vp],
     "evp_gemm_grouped_tn_g4_bf16": [_vp, _vp, _i, _vp],
     "evp_sum_slices_f32": [_vp, _vp, _i, _i64, _i, _vp],
     "evp_gemm_set_variant": [_i],
-    "evp_gemm_set_debug_buffer": [_vp],
+    "evp_gemm_set_stamp_buffer": [_vp, C.c_longlong],
+    "evp_gemm_stamp_count": [],
     "evp_attention_set_debug_buffer": [_vp],
     "evp_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _vp, _i, _vp, _vp, _vp],
     "evp_layernorm_bwd_nblk": [_i64],
@@ -106,10 +106,13 @@ SIGNATURES = {
     "evp_frame_augment_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "evp_token_mean_fwd": [_vp, _i, _i, _i, _vp, _vp],
     "evp_token_mean_bwd": [_vp, _i, _i, _i, _vp, _vp],
+    "evp_rows_scale_f32": [_vp, _vp, _f, _vp, _i64, _i, _i, _vp, _vp, _vp],
+    "evp_dropout_fwd": [_vp, _i, _vp, _vp, _i64, _f, C.c_uint64, C.c_uint64, _vp],
+    "evp_dropout_apply": [_vp, _i, _vp, _vp, _i64, _f, _vp],
     "evp_abi_version": [],
 }
 _OTHER_RESTYPE = {"evp_last_error": C.c_char_p, "evp_target_arch": C.c_char_p}
-_NO_STATUS = {"evp_dwconv5x5_bwd_nslab", "evp_gemm_set_variant", "evp_attention_fused_supported", "evp_layernorm_bwd_nblk", "evp_colsum_nblk", "evp_batchnorm_nblk", "evp_abi_version",
+_NO_STATUS = {"evp_dwconv5x5_bwd_nslab", "evp_gemm_set_variant", "evp_gemm_stamp_count", "evp_attention_fused_supported", "evp_layernorm_bwd_nblk", "evp_colsum_nblk", "evp_batchnorm_nblk", "evp_abi_version",
               "evp_window_attention_fused_np", "evp_window_attention_fused_nchunk"}
 
 _lib = None

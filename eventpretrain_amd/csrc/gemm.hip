@@ -9,46 +9,19 @@
 // (f32) / 8-byte (bf16) vectors.
 //
 // Replaces the reference's nn.Linear / matmul / einsum call sites listed in include/evtpretrain.h (evp_gemm).
-#include "evp_common.h"
-
-#include <type_traits>
-
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) short i16x4;
-typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#include "gemm_common.h"
 
 static int g_gemm_variant = 1;
+static int g_gemm_g4_fwd = 1;      // A/B switch: wide forward / data-gradient GEMMs on the G4 bodies (default) or on 128x128 tiles
 static int g_gemm_dbg = 0;
-static unsigned long long *g_gemm_dbgbuf = nullptr;
+static unsigned long long *g_stamp_buf = nullptr;   // measurement aid, see gemm_common.h "in-kernel wall-clock stamps"
+static long long g_stamp_slots = 0, g_stamp_next = 0;
+unsigned long long *evp_gemm_next_stamp_slot() {
+  if (!g_stamp_buf || g_stamp_slots <= 0) return nullptr;
+  return g_stamp_buf + (size_t)((g_stamp_next++) % g_stamp_slots) * 2 * EVP_STAMP_WGS;
+}
 
 namespace {
-
-struct GemmParams {
-  int M, N, K;
-  const void *A; int64_t lda, sA0, sA1;
-  const void *B; int64_t ldb, sB0, sB1;
-  void *C; int c_dtype; int64_t ldc, sC0, sC1;
-  int batch1;
-  float alpha;
-  const float *bias;
-  int act;
-  void *aux; int64_t ldaux;
-  const float *residual; int64_t ldres;
-  int accumulate;
-  int tiles_m;
-  int splitk, k_per_split;   // blockIdx.y = K slice
-  int dbg;                   // measurement aid (evp_gemm_set_variant(101): skip the epilogue; results are then garbage)
-  unsigned long long *dbgbuf; // measurement aid: per-workgroup cycle counters of the persistent kernel
-  float *colsum;             // 256x256 TN body only: colsum[m] (+)= sum_k A[k][m] (bias gradient), written by the tile_n == 0 workgroups
-  int colsum_acc;
-  // stream-K (gemm_sk_kernel): partial accumulator tiles and their ready flags, in the caller's workspace
-  float *sk_ws;
-  int *sk_flags;
-  int sk_kiters;             // K tiles per output tile
-  long long sk_total;        // output tiles x sk_kiters
-};
 
 template <typename T> struct Cfg;
 template <> struct Cfg<bf16_t> {
@@ -142,12 +115,10 @@ template <typename T, bool TR, int ROWS, int NT, int BK> struct Stage {
     }
   }
 };
-
 // ---- global -> LDS direct (LDS-DMA) staging of one bf16 operand tile -------------------------------------------
 // One wave-instruction (buffer_load_dwordx4 ... lds) lands 64 x 16 B = 1 KiB contiguously in LDS, so the LDS image is
 // written linearly and the XOR swizzle is applied to the per-lane SOURCE address instead (the same involution the
 // fragment reads use). A 16 KiB tile image = 16 such pieces, 4 per wave (256 threads).
-typedef __attribute__((address_space(3))) void lds_void;
 template <bool TR, int ROWS, int NT, int BK> struct GStage {
   static constexpr int PIECES = Img<bf16_t, TR, ROWS, BK>::BYTES / 1024;   // wave-instructions per tile
   static constexpr int PER_WAVE = PIECES / (NT / 64);
@@ -210,7 +181,6 @@ __device__ __forceinline__ bf16x8 frag_bf16(const char *img, int rb, int ks, int
 // silently turned every counted vmcnt(N) of the staging rings into "wait for everything", i.e. no K tile was ever in
 // flight across the fragment reads. Reads it cannot see are not guarded; the loops guard them themselves (counted vmcnt
 // + barrier before, s_waitcnt lgkmcnt + the `tie` below after).
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 template <bool TR, int ROWS, int BK>
 __device__ __forceinline__ u32x4 frag_bf16_asm(const char *img, int rb, int ks, int lane) {
   const int g = lane >> 4, i = lane & 15;
@@ -240,105 +210,6 @@ __device__ __forceinline__ float frag_f32(const char *img, int rb, int ks, int l
   const float *f = reinterpret_cast<const float *>(img);
   if constexpr (!TR) return f[(rb + i) * Img<float, false, ROWS, 16>::LD + ks * 4 + g];
   else return f[(ks * 4 + g) * Img<float, true, ROWS, 16>::LD + rb + i];
-}
-
-// ---- epilogue helpers ----------------------------------------------------------------------------------------
-// erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7): one v_exp + one v_rcp + 5 fma. Used in bf16 mode only.
-__device__ __forceinline__ void erf_pdf_fast(float x, float &erfv, float &pdf) {
-  const float z = x * 0.70710678118654752440f, az = fabsf(z);
-  const float t = __frcp_rn(1.0f + 0.3275911f * az);
-  const float u = __expf(-0.5f * x * x);          // e^{-x^2/2};  e^{-z^2} = u
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float e = 1.0f - poly * u;
-  erfv = z < 0.f ? -e : e;
-  pdf = 0.39894228040143267794f * u;
-}
-__device__ __forceinline__ float gelu_sel(float x, bool fast) {
-  if (!fast) return gelu_f(x);
-  float e, pdf;
-  erf_pdf_fast(x, e, pdf);
-  return 0.5f * x * (1.0f + e);
-}
-__device__ __forceinline__ float dgelu_sel(float x, bool fast) {     // ragged-edge (scalar) path only
-  if (!fast) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
-  }
-  float e, pdf;
-  erf_pdf_fast(x, e, pdf);
-  return 0.5f * (1.0f + e) + x * pdf;
-}
-
-// bf16-mode activations on PAIRS of values (v_pk_fma_f32 / v_pk_mul_f32: two f32 per lane and instruction) and without
-// transcendentals: Phi(x) = 0.5 + xc*P(xc^2) and phi(x) = Q(xc^2) with xc = clamp(x, -4, 4), P / Q degree-7 / -8
-// minimax fits (|Phi err| <= 5.3e-5, |x*phi err| <= 5.2e-5 in f32 Horner form; beyond +-4 the clamp leaves <= 5e-4).
-// The GELU epilogue of a 128x128 tile was ~25 VALU-equivalents per element -- as long as the tile's whole MFMA work at
-// K = 768; this is ~6. f32 parity mode keeps erff / expf.
-typedef float __attribute__((ext_vector_type(2))) f32x2;
-__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f32x2 splat2(float c) { return f32x2{c, c}; }
-__device__ __forceinline__ f32x2 cdf_poly2(f32x2 xc, f32x2 t) {
-  f32x2 p = splat2(-1.580980095e-09f);
-  p = fma2(p, t, splat2(1.217218683e-07f));
-  p = fma2(p, t, splat2(-4.101103530e-06f));
-  p = fma2(p, t, splat2(8.067003135e-05f));
-  p = fma2(p, t, splat2(-1.048219917e-03f));
-  p = fma2(p, t, splat2(9.664920407e-03f));
-  p = fma2(p, t, splat2(-6.617543876e-02f));
-  p = fma2(p, t, splat2(3.988475314e-01f));
-  return fma2(p, xc, splat2(0.5f));
-}
-__device__ __forceinline__ f32x2 pdf_poly2(f32x2 t) {
-  f32x2 q = splat2(8.990855908e-10f);
-  q = fma2(q, t, splat2(-7.519181097e-08f));
-  q = fma2(q, t, splat2(2.756920725e-06f));
-  q = fma2(q, t, splat2(-5.866515477e-05f));
-  q = fma2(q, t, splat2(8.084384011e-04f));
-  q = fma2(q, t, splat2(-7.582483969e-03f));
-  q = fma2(q, t, splat2(4.857881561e-02f));
-  q = fma2(q, t, splat2(-1.984161263e-01f));
-  return fma2(q, t, splat2(3.986868918e-01f));
-}
-__device__ __forceinline__ f32x2 clamp4(f32x2 x) {
-  return f32x2{__builtin_amdgcn_fmed3f(x.x, -4.f, 4.f), __builtin_amdgcn_fmed3f(x.y, -4.f, 4.f)};
-}
-__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
-  const f32x2 xc = clamp4(x);
-  return x * cdf_poly2(xc, xc * xc);
-}
-__device__ __forceinline__ f32x2 dgelu_fast2(f32x2 h) {       // Phi(h) + h*phi(h)
-  const f32x2 xc = clamp4(h), t = xc * xc;
-  return fma2(xc, pdf_poly2(t), cdf_poly2(xc, t));
-}
-__device__ __forceinline__ float4 gelu4(float4 v, bool fast) {
-  if (fast) {
-    const f32x2 a = gelu_fast2(f32x2{v.x, v.y}), b = gelu_fast2(f32x2{v.z, v.w});
-    return make_float4(a.x, a.y, b.x, b.y);
-  }
-  return make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
-}
-__device__ __forceinline__ float4 dgelu_mul4(float4 v, float4 h, bool fast) {      // v * gelu'(h)
-  if (fast) {
-    const f32x2 a = f32x2{v.x, v.y} * dgelu_fast2(f32x2{h.x, h.y}), b = f32x2{v.z, v.w} * dgelu_fast2(f32x2{h.z, h.w});
-    return make_float4(a.x, a.y, b.x, b.y);
-  }
-  return make_float4(v.x * dgelu_sel(h.x, false), v.y * dgelu_sel(h.y, false), v.z * dgelu_sel(h.z, false), v.w * dgelu_sel(h.w, false));
-}
-
-template <typename TC> __device__ __forceinline__ float4 ld4(const TC *p);
-template <> __device__ __forceinline__ float4 ld4<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
-template <> __device__ __forceinline__ float4 ld4<bf16_t>(const bf16_t *p) {
-  const uint2 u = *reinterpret_cast<const uint2 *>(p);
-  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
-                     __uint_as_float(u.y & 0xFFFF0000u));
-}
-template <typename TC> __device__ __forceinline__ void st4(TC *p, float4 v);
-template <> __device__ __forceinline__ void st4<float>(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
-template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t *p, float4 v) {
-  uint2 u;
-  u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-  u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
-  *reinterpret_cast<uint2 *>(p) = u;
 }
 
 // ragged right edge (N not a multiple of 4, e.g. attention scores with N = 98): element-wise and out of line. All
@@ -582,21 +453,9 @@ __device__ __forceinline__ void epilogue_lds(const f32x4 (&acc)[MI][NI], const G
   }
 }
 
-constexpr int SK_FLAG_BYTES = 4096;              // ready flags (one per workgroup) + the error word, at the start of the workspace
-constexpr int SK_MAX_GRID = SK_FLAG_BYTES / 4 - 8;
-constexpr int SK_ERR_WORD = SK_FLAG_BYTES / 4 - 1;
-// stream-K segment context (gemm_sk_kernel): the XCD's iteration range [base, base + span) is cut into gx equal runs, run
-// j belongs to workgroup blockIdx = j * 8 + xcd; mode 1 = park the accumulators, 2 = whole tile, 3 = collect + finish
-struct SkCtx {
-  int mode, kbeg, kend, j, gx, xcd;
-  long long base, span, tile_begin;
-  __device__ __forceinline__ long long run_begin(int jj) const { return base + (long long)jj * span / gx; }
-};
-
 // ---- the tile body (shared by the plain and the grouped kernel) ------------------------------------------------
 template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN, bool GLDS, int STAGES, int BK>
-__device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m, const int tile_n, const int bz, const int kslice,
-                                          const SkCtx sk = SkCtx{0, 0, 0, 0, 1, 0, 0, 0, 0}) {
+__device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m, const int tile_n, const int bz, const int kslice) {
   constexpr int NT = WM * WN * 64;
   constexpr int KSTEP = Cfg<T>::KSTEP;
   constexpr int WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NI = WTN / 16;
@@ -620,8 +479,8 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m,
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int kbeg = sk.mode ? sk.kbeg : kslice * p.k_per_split;
-  const int kend = sk.mode ? sk.kend : ((kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K);
+  const int kbeg = kslice * p.k_per_split;
+  const int kend = (kbeg + p.k_per_split < p.K) ? kbeg + p.k_per_split : p.K;
   const int ntiles = (kend - kbeg + BK - 1) / BK;
 
   auto compute_tile = [&](const char *ia, const char *ib) {
@@ -775,56 +634,6 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m,
     }
   }
 
-  // ---- stream-K hand-over (mode 1: this segment does not end its tile -> park the accumulators; mode 3: this segment
-  //      ends a tile that earlier workgroups of the same XCD started -> collect theirs). See gemm_sk_kernel.
-  if (sk.mode == 1) {
-    const int slot = sk.j * 8 + sk.xcd;
-    float4 *ws = reinterpret_cast<float4 *>(p.sk_ws + (size_t)slot * (BM * BN));
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-        ws[(i * NI + j) * NT + tid] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-    // Producer and consumer sit on ONE XCD (blockIdx and blockIdx - 8k): they share its L2, the vector L1 is
-    // write-through, so "stores acknowledged" (vmcnt 0, which the workgroup-scope release waits for) is all the
-    // consumer needs -- no L2 write-back / invalidate (an agent-scope fence per wave cost ~140 us per launch here).
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(p.sk_flags + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
-  if (sk.mode == 3) {
-    __shared__ int sk_ok;
-    if (p.dbgbuf && tid == 0) p.dbgbuf[blockIdx.x * 16 + 13] = __builtin_readcyclecounter();   // main loop done
-    for (int jj = sk.j - 1; jj >= 0; --jj) {
-      const int slot = jj * 8 + sk.xcd;
-      if (tid == 0) {
-        int spins = 0, got = 0;
-        while (!(got = __hip_atomic_load(p.sk_flags + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) && ++spins < (1 << 18))
-          __builtin_amdgcn_s_sleep(8);
-        if (got) __hip_atomic_store(p.sk_flags + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one consumer per flag
-        else __hip_atomic_store(p.sk_flags + SK_ERR_WORD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // gave up
-        sk_ok = got;
-        if (p.dbgbuf) p.dbgbuf[blockIdx.x * 16 + 14] = __builtin_readcyclecounter();   // flag seen
-      }
-      __syncthreads();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the slot's lines were never in this CU's L1 (one reader per slot and launch)
-      if (sk_ok) {
-        const float4 *ws = reinterpret_cast<const float4 *>(p.sk_ws + (size_t)slot * (BM * BN));
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j) {
-            const float4 t = ws[(i * NI + j) * NT + tid];
-            acc[i][j][0] += t.x; acc[i][j][1] += t.y; acc[i][j][2] += t.z; acc[i][j][3] += t.w;
-          }
-      }
-      __syncthreads();    // sk_ok is rewritten by the next round
-      if (sk.run_begin(jj) <= sk.tile_begin) break;   // that run held the tile's first K tile
-    }
-    if (p.dbgbuf && tid == 0) p.dbgbuf[blockIdx.x * 16 + 15] = __builtin_readcyclecounter();   // parts added
-  }
-
   // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4
   const int64_t coff = b0 * p.sC0 + b1 * p.sC1;
   const int li = lane & 15, lg = lane >> 4;
@@ -858,108 +667,22 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m,
   }
 }
 
-// Block -> tile map (speed only, never correctness): (1) blocks b and b+8 share an XCD, so renumber to give every XCD
-// a contiguous run of tiles (bijective for any grid size); (2) inside the run walk GROUP_M x tiles_n panels, M
-// fastest, so the ~64 blocks an XCD runs at once share 8 A panels and 8 B panels that fit its 4 MiB L2.
-__device__ __forceinline__ int xcd_renumber(int nblk, int bid) {
-  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
-__device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int &tile_m, int &tile_n) {
-  constexpr int GROUP_M = 8;
-  const int per_group = GROUP_M * tiles_n;
-  const int gid = t / per_group, first_m = gid * GROUP_M;
-  const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
-  const int in_g = t - gid * per_group;
-  tile_m = first_m + in_g % gsz;
-  tile_n = in_g / gsz;
-}
-__device__ __forceinline__ void map_tile(int nblk, int bid, int tiles_m, int &tile_m, int &tile_n) {
-  tile_of(xcd_renumber(nblk, bid), tiles_m, nblk / tiles_m, tile_m, tile_n);
-}
-
 template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN, bool GLDS, int STAGES, int BK, int MINW>
 __global__ __launch_bounds__(WM *WN * 64, MINW) void gemm_kernel(const GemmParams p) {
   int tile_m, tile_n;
+  const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  stamp_begin(p.stamp, wg, gridDim.x * gridDim.y * gridDim.z);
   map_tile(gridDim.x, blockIdx.x, p.tiles_m, tile_m, tile_n);
   gemm_body<T, TC, EPI, TA, TB, BM, BN, WM, WN, GLDS, STAGES, BK>(p, tile_m, tile_n, blockIdx.z, blockIdx.y);
+  stamp_end(p.stamp, wg, gridDim.x * gridDim.y * gridDim.z);
 }
-
-// ---- stream-K form of the same body ---------------------------------------------------------------------------------
-// The forward / dgrad GEMMs of this path have 294-1176 output tiles for 512 resident workgroups: a data-parallel launch
-// leaves up to 43 % of the slots idle in its last round, and all workgroups reach their C-tile stores together. Here a
-// grid of the resident workgroups cuts the iteration space (output tile x K tile, tile-major) into equal runs -- per
-// XCD: each XCD owns an eighth of the tiles and splits it over its own workgroups (blockIdx % 8), so partial tiles
-// never cross XCDs and the panels an XCD streams stay in its L2. A run is [tail of a tile][whole tiles][head of a
-// tile] and is walked BACKWARDS: the head segment (which does not end its tile) comes first and parks its accumulators
-// (64 KiB, raw register layout, coalesced) in the workspace; the tail segment comes last, and the workgroup that ends
-// a tile collects the parked parts of the workgroups before it (blockIdx - 8, -16, ...). So a wait never depends on
-// another wait (no chain), it only ever targets workgroups that were dispatched EARLIER (no deadlock even if the grid
-// were not fully resident), and the summation order is fixed (results are run-to-run identical). Flags are consumed
-// (reset to 0) by their single reader, so a replayed HIP graph finds them clean. The poll is bounded: a lost producer
-// costs a wrong tile and an error word, never a hung GPU.
-// Measured (tools/gemm_sk_check.py, gemm_sk_trace.py; MI355X): bit-reproducible and equal to the data-parallel result
-// to f32 rounding, but 4-15 us SLOWER than it on every shape of this path (enc.fc2 56.9 vs 53.1 us). Per workgroup:
-// park 2.2 us, wait for the neighbour's flag 5.4 us (all runs are equally long, so the part a workgroup needs is
-// finished just when it asks for it -- no slack), adding the parked parts 5.0 us (32 MB of parks do not stay in the
-// 4 MiB L2s), one extra pipeline fill per segment. Kept as an explicit variant (evp_gemm_desc::tile = 12) with its
-// parity test; the next thing to try is the hybrid: one whole tile per CU for the first 256 tiles, stream-K only for
-// the remainder, so that hand-overs sit on workgroups with slack.
-template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN, int STAGES, int BK>
-__global__ __launch_bounds__(WM *WN * 64, 2) void gemm_sk_kernel(const GemmParams p) {
-  const int g = gridDim.x;                         // multiple of 8
-  SkCtx sk;
-  sk.xcd = blockIdx.x & 7;
-  sk.j = blockIdx.x >> 3;
-  sk.gx = g >> 3;
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const long long tiles = (long long)p.tiles_m * tiles_n;
-  const long long t_lo = tiles * sk.xcd / 8, t_hi = tiles * (sk.xcd + 1) / 8;   // this XCD's tiles: no hand-over crosses XCDs
-  sk.base = t_lo * p.sk_kiters;
-  sk.span = (t_hi - t_lo) * p.sk_kiters;
-  const long long it0 = sk.run_begin(sk.j);
-  long long it1 = sk.run_begin(sk.j + 1);
-  // measurement aid (evp_gemm_set_debug_buffer): 16 words per workgroup: start, then (end stamp, mode << 16 | K tiles) per segment
-  int dbg_n = 0;
-  if (p.dbgbuf && threadIdx.x == 0) p.dbgbuf[blockIdx.x * 16] = __builtin_readcyclecounter();
-  while (it1 > it0) {                              // last segment of the run first
-    const int t = (int)((it1 - 1) / p.sk_kiters);
-    sk.tile_begin = (long long)t * p.sk_kiters;
-    const long long seg0 = it0 > sk.tile_begin ? it0 : sk.tile_begin;
-    const int k0 = (int)(seg0 - sk.tile_begin), k1 = (int)(it1 - sk.tile_begin);
-    int tile_m, tile_n;
-    tile_of(t, p.tiles_m, tiles_n, tile_m, tile_n);
-    sk.mode = k1 < p.sk_kiters ? 1 : (k0 > 0 ? 3 : 2);
-    sk.kbeg = k0 * BK;
-    sk.kend = k1 * BK < p.K ? k1 * BK : p.K;
-    gemm_body<T, TC, EPI, TA, TB, BM, BN, WM, WN, true, STAGES, BK>(p, tile_m, tile_n, 0, 0, sk);
-    __syncthreads();      // the epilogue's LDS scratch is the next segment's staging ring
-    if (p.dbgbuf && threadIdx.x == 0 && dbg_n < 7) {
-      p.dbgbuf[blockIdx.x * 16 + 1 + 2 * dbg_n] = __builtin_readcyclecounter();
-      p.dbgbuf[blockIdx.x * 16 + 2 + 2 * dbg_n] = ((unsigned long long)sk.mode << 16) | (unsigned)(k1 - k0);
-      ++dbg_n;
-    }
-    it1 = seg0;
-  }
-}
-
-// ---- grouped weight-gradient GEMM: many independent (dY^T . X) problems in ONE launch ------------------------------
-// problem g: C_g[M_g, N_g] (f32) = A_g^T . B_g with A_g stored [K_g][M_g], B_g stored [K_g][N_g] (bf16). Work item =
-// one 128x128 output tile of one problem; items are listed largest-K first so the long tiles start early.
-struct GroupedProblem {
-  const void *A, *B;
-  void *C;
-  int M, N, K;
-  int lda, ldb, ldc;
-  int accumulate, colsum_accumulate;
-  float *colsum;             // 256x256 kernel only: colsum[m] (+)= sum_k A[k][m]; NULL = none
-};
-struct GroupedItem { int prob, tile_m, tile_n, pad; };
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_grouped_tn_kernel(const GroupedProblem *__restrict__ probs, const GroupedItem *__restrict__ items) {
+__global__ __launch_bounds__(256) void gemm_grouped_tn_kernel(const GroupedProblem *__restrict__ probs, const GroupedItem *__restrict__ items,
+                                                              unsigned long long *stamp) {
   const GroupedItem it = items[blockIdx.x];
   if (it.prob < 0) return;                       // padding of the per-XCD item lists
+  stamp_begin(stamp, blockIdx.x, gridDim.x);
   const GroupedProblem g = probs[it.prob];
   GemmParams p;
   p.M = g.M; p.N = g.N; p.K = g.K;
@@ -967,9 +690,10 @@ __global__ __launch_bounds__(256) void gemm_grouped_tn_kernel(const GroupedProbl
   p.B = g.B; p.ldb = g.ldb; p.sB0 = 0; p.sB1 = 0;
   p.C = g.C; p.c_dtype = EVP_F32; p.ldc = g.ldc; p.sC0 = 0; p.sC1 = 0;
   p.batch1 = 1; p.alpha = 1.0f; p.bias = nullptr; p.act = EVP_ACT_NONE; p.aux = nullptr; p.ldaux = 0;
-  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1; p.dbg = 0; p.dbgbuf = nullptr; p.colsum = nullptr; p.colsum_acc = 0;
+  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1; p.dbg = 0; p.colsum = nullptr; p.colsum_acc = 0; p.stamp = nullptr;
   p.k_per_split = (g.K + 63) / 64 * 64;
   gemm_body<bf16_t, float, 0, true, true, BM, BN, 2, 2, true, 2, 64>(p, it.tile_m, it.tile_n, 0, 0);
+  stamp_end(stamp, blockIdx.x, gridDim.x);
 }
 
 template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, int WM, int WN, bool GLDS, int STAGES, int BK = Cfg<T>::BK,
@@ -982,7 +706,7 @@ int launch(const evp_gemm_desc *d, hipStream_t s) {
   p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = d->strideC0; p.sC1 = d->strideC1;
   p.batch1 = d->batch1 > 0 ? d->batch1 : 1;
   p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
-  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = g_gemm_dbg; p.dbgbuf = g_gemm_dbgbuf; p.colsum = nullptr; p.colsum_acc = 0;
+  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = g_gemm_dbg; p.colsum = nullptr; p.colsum_acc = 0; p.stamp = evp_gemm_next_stamp_slot();
   p.tiles_m = (d->M + BM - 1) / BM;
   const int tiles_n = (d->N + BN - 1) / BN;
   const int nb = (d->batch0 > 0 ? d->batch0 : 1) * p.batch1;
@@ -1033,572 +757,6 @@ int launch(const evp_gemm_desc *d, hipStream_t s) {
   return EVP_OK;
 }
 
-
-// stream-K launch of the 128x128 LDS-DMA body (bf16, A row-major). Workspace (caller-owned, evp_gemm_desc::sk_workspace):
-// [0, 4096) int32 ready flags + error word -- zeroed ONCE by the caller, kept clean by the kernel -- then one 64 KiB
-// accumulator slot per workgroup.
-template <typename TC, int EPI, bool TB> int sk_resident_blocks() {
-  static int blocks = -1;   // per instantiation
-  if (blocks < 0) {
-    constexpr int smem = 2 * (Img<bf16_t, false, 128, 64>::BYTES + Img<bf16_t, TB, 128, 64>::BYTES);
-    auto k = gemm_sk_kernel<bf16_t, TC, EPI, false, TB, 128, 128, 2, 2, 2, 64>;
-    if (smem > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-      return blocks = 0;
-    int per_cu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, smem) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-      return blocks = 0;
-    if (per_cu > 2) per_cu = 2;
-    blocks = per_cu * cus;
-    if (blocks > SK_MAX_GRID) blocks = SK_MAX_GRID;
-    blocks &= ~7;             // whole workgroups per XCD
-  }
-  return blocks;
-}
-// usable for this call? (shape and workspace); *grid = workgroups to launch
-template <typename TC, int EPI, bool TB> bool sk_usable(const evp_gemm_desc *d, int *grid) {
-  const int64_t nb = (int64_t)(d->batch0 > 0 ? d->batch0 : 1) * (d->batch1 > 0 ? d->batch1 : 1);
-  if (nb != 1 || d->K % 64 != 0 || d->K < 256 || !d->sk_workspace || d->splitk > 1) return false;
-  const int g = sk_resident_blocks<TC, EPI, TB>();
-  const int64_t tiles = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128);
-  if (g < 8 || tiles * (d->K / 64) < (int64_t)g * 4) return false;
-  if (d->sk_workspace_bytes < SK_FLAG_BYTES + (int64_t)g * 128 * 128 * 4) return false;
-  *grid = g;
-  return true;
-}
-template <typename TC, int EPI, bool TB> int launch_sk(const evp_gemm_desc *d, hipStream_t s, int g) {
-  GemmParams p;
-  p.M = d->M; p.N = d->N; p.K = d->K;
-  p.A = d->A; p.lda = d->lda; p.sA0 = 0; p.sA1 = 0;
-  p.B = d->B; p.ldb = d->ldb; p.sB0 = 0; p.sB1 = 0;
-  p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = 0; p.sC1 = 0;
-  p.batch1 = 1;
-  p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
-  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = g_gemm_dbg; p.dbgbuf = g_gemm_dbgbuf; p.colsum = nullptr; p.colsum_acc = 0;
-  p.tiles_m = (d->M + 127) / 128;
-  p.splitk = 1; p.k_per_split = d->K;
-  p.sk_flags = reinterpret_cast<int *>(d->sk_workspace);
-  p.sk_ws = reinterpret_cast<float *>(reinterpret_cast<char *>(d->sk_workspace) + SK_FLAG_BYTES);
-  p.sk_kiters = d->K / 64;
-  p.sk_total = (long long)p.tiles_m * ((d->N + 127) / 128) * p.sk_kiters;
-  constexpr int smem = 2 * (Img<bf16_t, false, 128, 64>::BYTES + Img<bf16_t, TB, 128, 64>::BYTES);
-  hipLaunchKernelGGL((gemm_sk_kernel<bf16_t, TC, EPI, false, TB, 128, 128, 2, 2, 2, 64>), dim3((unsigned)g), dim3(256), smem, s, p);
-  EVP_CHECK_LAUNCH("evp_gemm(stream-K)");
-  return EVP_OK;
-}
-
-// ---- 256x256x64 tile, 8 waves, half-tile ring ("8-phase" schedule) ----------------------------------------------
-// The 128x128 body above re-reads 16 KiB of LDS per wave for every 32 MFMAs, which is exactly the LDS port's rate at
-// MFMA peak: that structure tops out near 900 TFLOP/s. Here a wave owns 128x64 of a 256x256 tile (24 KiB per 64 MFMAs)
-// and the K loop is cut into four phases per K tile, each = [fragment ds_reads | one half-tile of LDS-DMA prefetch |
-// counted vmcnt] barrier [16 MFMAs on one 64x32 quadrant] barrier. The two wave rows (wr = 0 / 1; waves w and w+4 share
-// a SIMD) run one barrier apart, so one row's MFMA cluster overlaps the other row's ds_read / prefetch segment.
-// (Issuing the next phase's ds_reads under the same wave's MFMAs instead measured 20 % slower: the segments must stay
-// separate.) One workgroup per CU (128 KiB of LDS): it pays where there are many tiles and a long K -- the weight
-// gradients (K = batch x tokens) -- and not on the forward / dgrad shapes of this path, whose 75-300 tiles of 256x256
-// quantise badly on 256 CUs.
-//
-// Half-tiles (128 rows x 64 k, 16 KiB) in the order the phases first need them:
-//   h=0 A(mh=0): rows wr*128 +      [0,64)   needed in phase 1        h=2 B(nh=1): cols wc*64 + 32 + [0,32)  phase 2
-//   h=1 B(nh=0): cols wc*64 +       [0,32)   needed in phase 1        h=3 A(mh=1): rows wr*128 + 64 + [0,64) phase 3
-// Ring of 8 slots (2 K tiles x 4). Half-tile s = 4t+h is issued in global phase s-5 and every phase ends its first
-// segment with vmcnt(6): everything but the three newest half-tiles has landed, i.e. all s <= g+2, which is what phase
-// g+1 reads (RAW: the wait sits before that phase's barriers, the read one phase later). A slot is re-staged >= 3
-// phases after its last ds_read (WAR), also across the one-barrier stagger of the two wave rows.
-template <typename TC, int EPI, bool TA, bool TB>
-__device__ __forceinline__ void gemm256_body(const GemmParams &p, const int tile_m, const int tile_n, const int bz) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int HALF = 16384;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 2, wc = wave & 3;
-  const int m0 = tile_m * 256, n0 = tile_n * 256;
-  const int b0 = bz / p.batch1, b1 = bz % p.batch1;
-  const bf16_t *A = reinterpret_cast<const bf16_t *>(p.A) + b0 * p.sA0 + b1 * p.sA1;
-  const bf16_t *B = reinterpret_cast<const bf16_t *>(p.B) + b0 * p.sB0 + b1 * p.sB1;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(A), 0, 0x7FFFFFFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(B), 0, 0x7FFFFFFF, 0x00020000);
-  const int lda = (int)p.lda, ldb = (int)p.ldb;
-  const int nk = p.K / 64;
-
-  // per-lane source byte offsets of this wave's two 1-KiB pieces of each half-tile (the K-tile advance goes in soffset).
-  // An LDS-DMA piece is written lane-linearly, so the image's XOR swizzle is applied to the source address.
-  int voff[4][2];
-#pragma unroll
-  for (int h = 0; h < 4; ++h) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int piece = wave * 2 + i;
-      const bool isA = (h == 0) || (h == 3);
-      const bool tr = isA ? TA : TB;
-      const int sub = (h >= 2) ? 1 : 0;                 // mh for the A halves, nh for the B halves
-      const int ld = isA ? lda : ldb, lim = isA ? p.M : p.N, o0 = isA ? m0 : n0;
-      int off;
-      if (!tr) {                                        // k contiguous: 8 rows x 8 chunks per piece
-        const int row = piece * 8 + (lane >> 3), pos = lane & 7;
-        const int gr = isA ? o0 + (row >> 6) * 128 + sub * 64 + (row & 63) : o0 + (row >> 5) * 64 + sub * 32 + (row & 31);
-        off = gr < lim ? (gr * ld + ((pos ^ (row & 7)) << 3)) * 2 : (int)0x80000000;
-      } else {                                          // k strided: 4 k-rows x 16 chunks per piece
-        const int k = piece * 4 + (lane >> 4), pos = lane & 15;
-        const int rl = (pos ^ (((k & 3) << 2) | ((k >> 2) & 3))) << 3;
-        const int gr = isA ? o0 + (rl >> 6) * 128 + sub * 64 + (rl & 63) : o0 + (rl >> 5) * 64 + sub * 32 + (rl & 31);
-        off = gr < lim ? (k * ld + gr) * 2 : (int)0x80000000;
-      }
-      voff[h][i] = off;
-    }
-  }
-  const int kstepA = TA ? 64 * lda * 2 : 128, kstepB = TB ? 64 * ldb * 2 : 128;   // bytes per K tile
-
-  auto issue = [&](auto Hc, int t) {
-    constexpr int h = decltype(Hc)::value;
-    char *slot = smem + (((t & 1) << 2) + h) * HALF + wave * 2048;
-    if constexpr (h == 0 || h == 3) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void *)(slot), 16, voff[h][0], t * kstepA, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void *)(slot + 1024), 16, voff[h][1], t * kstepA, 0, 0);
-    } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void *)(slot), 16, voff[h][0], t * kstepB, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void *)(slot + 1024), 16, voff[h][1], t * kstepB, 0, 0);
-    }
-  };
-  auto wait_halves = [](int rem) {                      // leave the `rem` (0..3) newest half-tiles in flight
-    if (rem >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (rem == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-
-  f32x4 acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  u32x4 af[4][2], bq0[2][2], bq1[2][2];    // fragments, read through frag_bf16_asm (the compiler must not guard them with vmcnt(0))
-  // bias gradient riding on the weight-gradient GEMM: colsum[m] = sum_k A[k][m]. The A fragments of the wc == 0 waves of
-  // the tile_n == 0 workgroups already hold every A value once; v_dot2c_f32_bf16 against (1, 1) adds a fragment's 8 k values
-  // in 4 VALU instructions that issue in the shadow of the MFMAs.
-  const bool do_colsum = p.colsum != nullptr && tile_n == 0 && wc == 0;
-  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-  const int last = 4 * nk - 1;              // index of the last half-tile
-  constexpr int AHEAD = 5;                  // half-tile s is issued in global phase s - AHEAD
-  issue(std::integral_constant<int, 0>{}, 0);
-  issue(std::integral_constant<int, 1>{}, 0);
-  issue(std::integral_constant<int, 2>{}, 0);
-  issue(std::integral_constant<int, 3>{}, 0);
-  if (nk > 1) issue(std::integral_constant<int, 0>{}, 1);
-  wait_halves((last < AHEAD - 1 ? last : AHEAD - 1) - 1);      // half-tiles 0 and 1 have landed
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger the second wave row by one barrier
-
-  auto phase = [&](auto Pc, int t) {
-    constexpr int P = decltype(Pc)::value;
-    const char *base = smem + ((t & 1) << 2) * HALF;
-    if constexpr (P == 0) {
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) bq0[jj][ks] = frag_bf16_asm<TB, 128, 64>(base + 1 * HALF, wc * 32 + jj * 16, ks, lane);
-#pragma unroll
-      for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) af[ii][ks] = frag_bf16_asm<TA, 128, 64>(base, wr * 64 + ii * 16, ks, lane);
-    } else if constexpr (P == 1) {
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) bq1[jj][ks] = frag_bf16_asm<TB, 128, 64>(base + 2 * HALF, wc * 32 + jj * 16, ks, lane);
-    } else if constexpr (P == 2) {
-#pragma unroll
-      for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) af[ii][ks] = frag_bf16_asm<TA, 128, 64>(base + 3 * HALF, wr * 64 + ii * 16, ks, lane);
-    }
-    const int g = 4 * t + P;
-    if (g + AHEAD <= last) issue(std::integral_constant<int, (P + AHEAD) & 3>{}, (g + AHEAD) >> 2);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int ii = 0; ii < 4; ++ii) tie(af[ii][ks]);
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) { tie(bq0[jj][ks]); tie(bq1[jj][ks]); }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-    constexpr int mh = (P >= 2) ? 1 : 0, nh = (P == 1 || P == 2) ? 1 : 0;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-          acc[mh * 4 + ii][nh * 2 + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              __builtin_bit_cast(bf16x8, nh ? bq1[jj][ks] : bq0[jj][ks]), __builtin_bit_cast(bf16x8, af[ii][ks]), acc[mh * 4 + ii][nh * 2 + jj], 0, 0, 0);
-    if constexpr (P == 0 || P == 2) {         // the phases that loaded a new A half
-      if (do_colsum) {
-        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-        const bf16x2 ones = __builtin_bit_cast(bf16x2, 0x3F803F80u);
-        // (pairs taken with shufflevector: bit-casting the fragment to 4 dwords and indexing them made hipcc 7.2 feed
-        // dword 0 to all four dot instructions)
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 f = __builtin_bit_cast(bf16x8, af[ii][ks]);
-            float c = csum[mh * 4 + ii];
-            c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), ones, c, false);
-            c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), ones, c, false);
-            c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), ones, c, false);
-            c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), ones, c, false);
-            csum[mh * 4 + ii] = c;
-          }
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    {   // the counted wait sits after the MFMA cluster (the DMA has that much longer to land) and before the barrier that
-        // publishes this wave's landed pieces to the readers of the next phase
-      const int newest = g + AHEAD <= last ? g + AHEAD : last;
-      const int rem = newest - (g + 2);
-      wait_halves(rem < 0 ? 0 : rem);
-    }
-    __builtin_amdgcn_s_barrier();
-  };
-
-  for (int t = 0; t < nk; ++t) {
-    phase(std::integral_constant<int, 0>{}, t);
-    phase(std::integral_constant<int, 1>{}, t);
-    phase(std::integral_constant<int, 2>{}, t);
-    phase(std::integral_constant<int, 3>{}, t);
-  }
-  if (wr == 0) __builtin_amdgcn_s_barrier();   // balances the stagger barrier of the other wave row
-
-  const int64_t coff = b0 * p.sC0 + b1 * p.sC1;
-  epilogue<TC, EPI, 8, 4>(acc, p, coff, m0 + wr * 128 + (lane & 15), n0 + wc * 64 + (lane >> 4) * 4, true);
-  if (do_colsum) {                              // lane (li, g) holds the k-group-g part of row li: fold the four groups
-#pragma unroll
-    for (int rt = 0; rt < 8; ++rt) {
-      float v = csum[rt];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      const int m = m0 + wr * 128 + rt * 16 + (lane & 15);
-      if ((lane >> 4) == 0 && m < p.M) p.colsum[m] = p.colsum_acc ? p.colsum[m] + v : v;
-    }
-  }
-}
-
-template <typename TC, int EPI, bool TA, bool TB>
-__global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
-  int tile_m, tile_n;
-  map_tile(gridDim.x, blockIdx.x, p.tiles_m, tile_m, tile_n);
-  gemm256_body<TC, EPI, TA, TB>(p, tile_m, tile_n, blockIdx.z);
-}
-
-// grouped weight gradients on the 256x256 ring: same problem / item tables as gemm_grouped_tn_kernel, 256x256 items
-__global__ __launch_bounds__(512) void gemm256_grouped_tn_kernel(const GroupedProblem *__restrict__ probs, const GroupedItem *__restrict__ items) {
-  const GroupedItem it = items[blockIdx.x];
-  if (it.prob < 0) return;                       // padding of the per-XCD item lists (see the host-side ordering)
-  const GroupedProblem g = probs[it.prob];
-  GemmParams p;
-  p.M = g.M; p.N = g.N; p.K = g.K;
-  p.A = g.A; p.lda = g.lda; p.sA0 = 0; p.sA1 = 0;
-  p.B = g.B; p.ldb = g.ldb; p.sB0 = 0; p.sB1 = 0;
-  p.C = g.C; p.c_dtype = EVP_F32; p.ldc = g.ldc; p.sC0 = 0; p.sC1 = 0;
-  p.batch1 = 1; p.alpha = 1.0f; p.bias = nullptr; p.act = EVP_ACT_NONE; p.aux = nullptr; p.ldaux = 0;
-  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1; p.dbg = 0; p.dbgbuf = nullptr; p.colsum = nullptr; p.colsum_acc = 0;
-  p.k_per_split = g.K;
-  p.colsum = g.colsum; p.colsum_acc = g.colsum_accumulate;
-  gemm256_body<float, 0, true, true>(p, it.tile_m, it.tile_n, 0);
-}
-
-template <typename TC, int EPI, bool TA, bool TB> int launch256(const evp_gemm_desc *d, hipStream_t s) {
-  GemmParams p;
-  p.M = d->M; p.N = d->N; p.K = d->K;
-  p.A = d->A; p.lda = d->lda; p.sA0 = d->strideA0; p.sA1 = d->strideA1;
-  p.B = d->B; p.ldb = d->ldb; p.sB0 = d->strideB0; p.sB1 = d->strideB1;
-  p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = d->strideC0; p.sC1 = d->strideC1;
-  p.batch1 = d->batch1 > 0 ? d->batch1 : 1;
-  p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
-  p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = g_gemm_dbg; p.dbgbuf = g_gemm_dbgbuf; p.colsum = nullptr; p.colsum_acc = 0;
-  p.tiles_m = (d->M + 255) / 256;
-  p.splitk = 1; p.k_per_split = d->K;
-  const int tiles_n = (d->N + 255) / 256;
-  const int nb = (d->batch0 > 0 ? d->batch0 : 1) * p.batch1;
-  constexpr int smem = 8 * 16384;
-  auto k = gemm256_kernel<TC, EPI, TA, TB>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { evp_set_error("evp_gemm: hipFuncSetAttribute(%d) failed: %s", smem, hipGetErrorString(e)); return EVP_ELAUNCH; }
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(k, dim3((unsigned)(p.tiles_m * tiles_n), 1, (unsigned)nb), dim3(512), smem, s, p);
-  EVP_CHECK_LAUNCH("evp_gemm");
-  return EVP_OK;
-}
-
-
-
-// ---- "G4" weight-gradient body: 256x256 tile, 4 waves, ONE wave per SIMD, v_mfma_f32_32x32x16_bf16 ---------------------
-// C[M][N] (f32) (+)= A^T . B, A stored [K][M], B stored [K][N] (TN), K % 32 == 0, K >= 96.
-// Why a second 256x256 body: the half-tile ring above runs two waves per SIMD through barrier-separated read / MFMA phases
-// and needs ~2.0-2.1 us per 64-deep K tile on the weight-gradient shapes. Here a wave owns 128x128 of the tile in 256
-// accumulator registers (the whole 512-register budget belongs to it), which (a) needs 0.25 fragment reads per MFMA,
-// (b) lets the wave hide its own LDS latency: the fragment reads of K step s+1 are issued in front of the 16 MFMAs of
-// step s, no phase barriers -- ONE barrier per 32-deep stage. Both operands are k-strided, so stages can be 32 k-rows
-// thin without splitting cache lines: A 16 KiB + B 16 KiB per stage, FOUR stages in a ring = three tiles of LDS-DMA in
-// flight (measured: the DMA is hidden completely, tools/native/g4_gemm.hip `tn`: 1.25-1.3 us per 64-deep K tile on the
-// step's weight-gradient shapes, 1186 TFLOP/s at 4096^3 against 849 for the ring). One wave per SIMD only issues the
-// 32x32x16 shape at full rate (16x16x32 needs two waves per SIMD).
-// LDS image [32 k][256 m] bf16 (512-byte rows); ds_read_b64_tr_b16 serves 32 lanes as 4 k-rows x 64 B, so the 64-byte
-// block index is XORed with (k & 3) -- on the LDS-DMA source address and on the read address (same involution).
-// RAW / WAR: a stage is read one barrier after every wave's counted vmcnt proved its own pieces landed; it is re-filled
-// (tile t+3 into the stage of tile t-1) after the barrier that follows every wave's lgkmcnt(0) on its last reads of it.
-template <int OFF> __device__ __forceinline__ u32x2 lds_read_tr_imm(unsigned addr) {
-  u32x2 v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF) : "memory");
-  return v;
-}
-__device__ __forceinline__ void tie2(u32x2 &x) { asm volatile("" : "+v"(x)); }
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-__device__ __forceinline__ void gemm_g4_tn_body(const GemmParams &p, const int tile_m, const int tile_n) {
-  constexpr int IMG = 32 * 512, STAGE = 2 * IMG;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = tile_m * 256, n0 = tile_n * 256;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.A), 0, 0x7FFFFFFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.B), 0, 0x7FFFFFFF, 0x00020000);
-  const int lda = (int)p.lda, ldb = (int)p.ldb;
-
-  // LDS-DMA: piece = 2 k-rows x 512 B, lane-linear in LDS; this wave's 4 pieces of each operand image
-  int voffA[4], voffB[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int piece = wave * 4 + i;
-    const int kr = piece * 2 + (lane >> 5), pos = lane & 31;
-    const int m = (((pos >> 2) ^ (kr & 3)) << 5) + ((pos & 3) << 3);
-    voffA[i] = (m0 + m < p.M) ? (kr * lda + m0 + m) * 2 : (int)0x80000000;
-    voffB[i] = (n0 + m < p.N) ? (kr * ldb + n0 + m) * 2 : (int)0x80000000;
-  }
-  const int kstepA = 32 * lda * 2, kstepB = 32 * ldb * 2;
-  auto dma_piece = [&](int idx, int t) {          // idx 0..7: compile time after unrolling
-    char *stage = smem + (t & 3) * STAGE;
-    if (idx < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void *)(stage + (wave * 4 + idx) * 1024), 16, voffA[idx & 3], t * kstepA, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void *)(stage + IMG + (wave * 4 + (idx & 3)) * 1024), 16, voffB[idx & 3], t * kstepB, 0, 0);
-  };
-
-  // fragment addresses (stage 0, K step 0): lane -> k-row 8h + q (+4 for the second read), 16-lane group `sub`, 4 m at 4 pq
-  const int h = lane >> 5, sub = (lane >> 4) & 1, q = (lane >> 2) & 3, pq = lane & 3;
-  const unsigned smem_base = (unsigned)(uintptr_t)(lds_void *)smem;
-  unsigned aaddr[4], baddr[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const unsigned lanepart = (unsigned)((8 * h + q) * 512 + (16 * sub + 4 * pq) * 2);
-    aaddr[i] = smem_base + lanepart + (unsigned)((((wm * 4 + i) ^ q) << 6));
-    baddr[i] = smem_base + IMG + lanepart + (unsigned)((((wn * 4 + i) ^ q) << 6));
-  }
-
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  u32x2 a0[4][2], b0[4][2], a1[4][2], b1[4][2];     // [fragment][k 0..3 / 4..7 of the lane's 8]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int e = 0; e < 2; ++e) a1[i][e] = b1[i][e] = u32x2{0u, 0u};
-  // bias gradient riding on the weight gradient: colsum[m] = sum_k A[k][m], taken from the A fragments of the wn == 0 waves of
-  // the tile_n == 0 workgroups (every A value is in exactly one of them once); v_dot2 against (1, 1), in the MFMAs' shadow
-  const bool do_colsum = p.colsum != nullptr && tile_n == 0 && wn == 0;
-  float csum[4] = {0.f, 0.f, 0.f, 0.f};
-
-  auto readsA = [&](u32x2 (&fa)[4][2], unsigned soff, auto ksc) {
-    constexpr int KS = decltype(ksc)::value;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fa[i][0] = lds_read_tr_imm<KS * 8192>(aaddr[i] + soff);
-      fa[i][1] = lds_read_tr_imm<KS * 8192 + 2048>(aaddr[i] + soff);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto readsB = [&](u32x2 (&fb)[4][2], unsigned soff, auto ksc) {
-    constexpr int KS = decltype(ksc)::value;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fb[i][0] = lds_read_tr_imm<KS * 8192>(baddr[i] + soff);
-      fb[i][1] = lds_read_tr_imm<KS * 8192 + 2048>(baddr[i] + soff);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto tie_all = [&](u32x2 (&fa)[4][2], u32x2 (&fb)[4][2]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { tie2(fa[i][0]); tie2(fa[i][1]); tie2(fb[i][0]); tie2(fb[i][1]); }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto mfma_block = [&](u32x2 (&fa)[4][2], u32x2 (&fb)[4][2], auto dmac, int tn) {
-    constexpr bool DMA = decltype(dmac)::value;
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const u32x4 av = u32x4{fa[i][0][0], fa[i][0][1], fa[i][1][0], fa[i][1][1]};
-        const u32x4 bv = u32x4{fb[j][0][0], fb[j][0][1], fb[j][1][0], fb[j][1][1]};
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bv), __builtin_bit_cast(bf16x8, av), acc[i][j], 0, 0, 0);
-        const int qn = j * 4 + i;
-        if constexpr (DMA) {
-          if ((qn & 1) == 1) {
-            dma_piece(qn >> 1, tn);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-    __builtin_amdgcn_sched_barrier(0);
-    if (do_colsum) {
-      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-      const bf16x2 ones = __builtin_bit_cast(bf16x2, 0x3F803F80u);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        // (pairs taken with shufflevector from the 8-element fragment: bit-casting single dwords made hipcc 7.2 feed the
-        // same dword to several dot instructions -- the ring body above hit the same miscompile)
-        const bf16x8 f = __builtin_bit_cast(bf16x8, u32x4{fa[i][0][0], fa[i][0][1], fa[i][1][0], fa[i][1][1]});
-        float c = csum[i];
-        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), ones, c, false);
-        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), ones, c, false);
-        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), ones, c, false);
-        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), ones, c, false);
-        csum[i] = c;
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  const int nk = p.K / 32;                        // >= 3 (launcher)
-#pragma unroll
-  for (int i = 0; i < 8; ++i) dma_piece(i, 0);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) dma_piece(i, 1);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) dma_piece(i, 2);
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  // one stage; VM = pieces that may still be in flight at its end (16: two newer tiles, 8: one, 0: none, -1: last stage)
-  auto iteration = [&](auto dmac, auto vmc, int t) {
-    constexpr int VM = decltype(vmc)::value;
-    const unsigned soff = (unsigned)((t & 3) * STAGE);
-    readsA(a0, soff, std::integral_constant<int, 0>{});
-    readsB(b0, soff, std::integral_constant<int, 0>{});
-    mfma_block(a1, b1, std::false_type{}, 0);              // (t-1, K step 1); zeros at t = 0
-    readsA(a1, soff, std::integral_constant<int, 1>{});
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");     // the 16 reads of K step 0 have landed (reads return in order)
-    readsB(b1, soff, std::integral_constant<int, 1>{});
-    tie_all(a0, b0);
-    mfma_block(a0, b0, dmac, t + 3);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    tie_all(a1, b1);
-    if constexpr (VM == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if constexpr (VM == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (VM == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (VM >= 0) __builtin_amdgcn_s_barrier();
-  };
-  int t = 0;
-  for (; t + 3 < nk; ++t) iteration(std::true_type{}, std::integral_constant<int, 16>{}, t);
-  iteration(std::false_type{}, std::integral_constant<int, 8>{}, t);
-  iteration(std::false_type{}, std::integral_constant<int, 0>{}, t + 1);
-  iteration(std::false_type{}, std::integral_constant<int, -1>{}, t + 2);
-  mfma_block(a1, b1, std::false_type{}, 0);
-
-  // C[m][n..n+3]: lane m = .. + (lane & 31); register r: n = .. + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)
-  float *C = reinterpret_cast<float *>(p.C);
-  const int mrow = m0 + wm * 128 + (lane & 31), ncol = n0 + wn * 128 + 4 * (lane >> 5);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = mrow + 32 * i;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = ncol + 32 * j + 8 * g;
-        if (n >= p.N) continue;
-        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        float *c = C + (int64_t)m * p.ldc + n;
-        if (n + 3 < p.N) {
-          if (p.accumulate) {
-            const float4 o = *reinterpret_cast<const float4 *>(c);
-            v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w);
-          }
-          *reinterpret_cast<float4 *>(c) = v;
-        } else {
-          const float e[4] = {v.x, v.y, v.z, v.w};
-          for (int u = 0; u < 4 && n + u < p.N; ++u) c[u] = p.accumulate ? c[u] + e[u] : e[u];
-        }
-      }
-  }
-  if (do_colsum) {                               // lanes l and l + 32 hold the two k halves of row (lane & 31)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float v = csum[i];
-      v += __shfl_xor(v, 32, 64);
-      const int m = mrow + 32 * i;
-      if (lane < 32 && m < p.M) p.colsum[m] = p.colsum_acc ? p.colsum[m] + v : v;
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void gemm_g4_grouped_tn_kernel(const GroupedProblem *__restrict__ probs, const GroupedItem *__restrict__ items) {
-  const GroupedItem it = items[blockIdx.x];
-  if (it.prob < 0) return;                       // padding of the per-XCD item lists
-  const GroupedProblem g = probs[it.prob];
-  GemmParams p;
-  p.M = g.M; p.N = g.N; p.K = g.K;
-  p.A = g.A; p.lda = g.lda; p.sA0 = 0; p.sA1 = 0;
-  p.B = g.B; p.ldb = g.ldb; p.sB0 = 0; p.sB1 = 0;
-  p.C = g.C; p.c_dtype = EVP_F32; p.ldc = g.ldc; p.sC0 = 0; p.sC1 = 0;
-  p.batch1 = 1; p.alpha = 1.0f; p.bias = nullptr; p.act = EVP_ACT_NONE; p.aux = nullptr; p.ldaux = 0;
-  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1; p.dbg = 0; p.dbgbuf = nullptr;
-  p.k_per_split = g.K;
-  p.colsum = g.colsum; p.colsum_acc = g.colsum_accumulate;
-  gemm_g4_tn_body(p, it.tile_m, it.tile_n);
-}
-
-__global__ __launch_bounds__(256) void gemm_g4_tn_kernel(const GemmParams p) {
-  int tile_m, tile_n;
-  map_tile(gridDim.x, blockIdx.x, p.tiles_m, tile_m, tile_n);
-  gemm_g4_tn_body(p, tile_m, tile_n);
-}
-
-static int launch_g4_tn(const evp_gemm_desc *d, hipStream_t s) {
-  GemmParams p;
-  p.M = d->M; p.N = d->N; p.K = d->K;
-  p.A = d->A; p.lda = d->lda; p.sA0 = 0; p.sA1 = 0;
-  p.B = d->B; p.ldb = d->ldb; p.sB0 = 0; p.sB1 = 0;
-  p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = 0; p.sC1 = 0;
-  p.batch1 = 1; p.alpha = 1.0f; p.bias = nullptr; p.act = EVP_ACT_NONE; p.aux = nullptr; p.ldaux = 0;
-  p.residual = nullptr; p.ldres = 0; p.accumulate = d->accumulate; p.dbg = 0; p.dbgbuf = nullptr; p.colsum = nullptr; p.colsum_acc = 0;
-  p.tiles_m = (d->M + 255) / 256;
-  p.splitk = 1; p.k_per_split = d->K;
-  const int tiles_n = (d->N + 255) / 256;
-  constexpr int smem = 4 * 2 * 32 * 512;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_g4_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { evp_set_error("evp_gemm: hipFuncSetAttribute(%d) failed: %s", smem, hipGetErrorString(e)); return EVP_ELAUNCH; }
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(gemm_g4_tn_kernel, dim3((unsigned)(p.tiles_m * tiles_n)), dim3(256), smem, s, p);
-  EVP_CHECK_LAUNCH("evp_gemm(g4 tn)");
-  return EVP_OK;
-}
-
 // (Two persistent variants of the 128x128 body lived here in round 1 -- one workgroup per CU slot looping over tiles, the second
 // with the C stores of tile i folded into the K loop of tile i+1. Measured: +3..8 % on the largest shapes, slower on the small
 // ones (DESIGN.md section 4 "Epilogues"); never the default, removed in round 2.)
@@ -1607,11 +765,16 @@ template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(cons
   int tile = d->tile;
   const int64_t nb = (int64_t)(d->batch0 > 0 ? d->batch0 : 1) * (d->batch1 > 0 ? d->batch1 : 1);
   if (tile == 0) {
+    // wide outputs (qkv / fc1 forward, fc2 data gradient): the G4 bodies (gemm_g4.hip), unless switched off for A/B runs
+    if constexpr (sizeof(T) == 2 && !TA) {
+      if (g_gemm_g4_fwd && g_gemm_variant != 2) {
+        const int shape = evp_g4_gemm_pick(d);
+        if (shape) return evp_g4_gemm(d, s, shape, g_gemm_dbg);
+      }
+    }
     const int64_t t128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * nb;
-    const int64_t t256 = (int64_t)((d->M + 255) / 256) * ((d->N + 127) / 128) * nb;
     const bool splittable = d->transA && d->c_dtype == EVP_F32 && !d->bias && d->act == EVP_ACT_NONE && !d->residual &&
                             !d->aux && nb == 1 && d->K >= 2048;
-    (void)t256;      // a 256x128 / 3-stage ring variant measured slower than 128x128 at this path's shapes (removed)
     tile = (d->M >= 128 && d->N >= 128 && (t128 >= 192 || splittable)) ? 1 : 2;
     // One round of 128 x 128 tiles that leaves some CUs with two workgroups and the rest with one (257..384 tiles) ends when the
     // doubly loaded CUs do; 96 x 128 tiles still fit one round (<= 512) and are 25 % smaller: -13..16 % on the 6272 x 768 outputs
@@ -1621,39 +784,28 @@ template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(cons
       if (tile == 1 && g_gemm_variant != 2 && nb == 1 && t128 > 256 && t96 <= 512) tile = 4;
     }
   }
-  // bf16: LDS-DMA staging (variant 1, default) or register staging (variant 2, kept for A/B runs); f32: registers
-  if constexpr (sizeof(T) == 2 && !TA) {
-    // stream-K is explicit only (tile 12): measured on this path's shapes it does not beat the data-parallel launch (see
-    // the note at gemm_sk_kernel)
-    if (d->tile == 12) {
-      int g = 0;
-      if (sk_usable<TC, EPI, TB>(d, &g)) return launch_sk<TC, EPI, TB>(d, s, g);
-      evp_set_error("evp_gemm: tile 12 (stream-K) needs bf16 A row-major, no batch, K %% 64 == 0, K >= 256, >= 4 K tiles per workgroup and sk_workspace");
-      return EVP_ESHAPE;
-    }
-  }
-  if constexpr (sizeof(T) == 2 && TA) {
-    if (d->tile == 12) { evp_set_error("evp_gemm: tile 12 (stream-K) is not built for transA"); return EVP_EUNSUPPORTED; }
+  if (tile == 6 || tile == 7 || tile == 8 || tile == 12) {
+    evp_set_error("evp_gemm: tile %d (256x256 ring / persistent / stream-K variants of rounds 1-2) was removed; see DESIGN.md section 4", tile);
+    return EVP_EUNSUPPORTED;
   }
   if constexpr (sizeof(T) == 2) {
-    if (tile == 7 || tile == 8) { evp_set_error("evp_gemm: tiles 7 / 8 (persistent variants) were removed"); return EVP_EUNSUPPORTED; }
     if (tile == 9) {        // G4 body (weight-gradient layout only): 256x256, one wave per SIMD, 32x32x16
       if constexpr (TA && TB && EPI == 0 && std::is_same<TC, float>::value) {
-        const int64_t nbz = (int64_t)(d->batch0 > 0 ? d->batch0 : 1) * (d->batch1 > 0 ? d->batch1 : 1);
-        if (nbz != 1 || d->K % 32 != 0 || d->K < 96 || d->bias || d->residual || d->aux || d->alpha != 1.0f || d->splitk > 1 ||
+        if (nb != 1 || d->K % 32 != 0 || d->K < 96 || d->bias || d->residual || d->aux || d->alpha != 1.0f || d->splitk > 1 ||
             d->lda % 8 != 0 || d->ldb % 8 != 0) {
           evp_set_error("evp_gemm: tile 9 (G4) needs transA, transB, f32 C, K %% 32 == 0, K >= 96, no batch / epilogue extras");
           return EVP_ESHAPE;
         }
-        return launch_g4_tn(d, s);
+        return evp_g4_gemm_tn(d, s);
       } else {
         evp_set_error("evp_gemm: tile 9 (G4) is built for the weight-gradient layout (transA = transB = 1, f32 C) only");
         return EVP_EUNSUPPORTED;
       }
     }
-    if (tile == 6) {
-      if (d->K % 64 != 0) { evp_set_error("evp_gemm: tile 6 (256x256 ring) needs K %% 64 == 0 (K=%d)", d->K); return EVP_ESHAPE; }
-      return launch256<TC, EPI, TA, TB>(d, s);
+    if (tile >= 20 && tile <= 22) {     // G4 forward / data-gradient bodies, explicit shape
+      if constexpr (!TA) return evp_g4_gemm(d, s, tile, g_gemm_dbg);
+      evp_set_error("evp_gemm: tiles 20-22 need A row-major");
+      return EVP_EUNSUPPORTED;
     }
   }
   if constexpr (sizeof(T) == 2) {
@@ -1706,52 +858,24 @@ extern "C" int evp_gemm_grouped_tn_bf16(const void *problems, const void *items,
     attr_done = true;
   }
   hipLaunchKernelGGL(k, dim3((unsigned)n_items), dim3(256), smem, (hipStream_t)stream,
-                     reinterpret_cast<const GroupedProblem *>(problems), reinterpret_cast<const GroupedItem *>(items));
+                     reinterpret_cast<const GroupedProblem *>(problems), reinterpret_cast<const GroupedItem *>(items), evp_gemm_next_stamp_slot());
   EVP_CHECK_LAUNCH("evp_gemm_grouped_tn_bf16");
   return EVP_OK;
 }
 
-extern "C" int evp_gemm_grouped_tn256_bf16(const void *problems, const void *items, int n_items, void *stream) {
-  EVP_CHECK_ARG(problems && items && n_items > 0, EVP_EINVAL, "evp_gemm_grouped_tn256_bf16: bad argument");
-  auto k = gemm256_grouped_tn_kernel;
-  constexpr int smem = 8 * 16384;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_gemm_grouped_tn256_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(k, dim3((unsigned)n_items), dim3(512), smem, (hipStream_t)stream,
-                     reinterpret_cast<const GroupedProblem *>(problems), reinterpret_cast<const GroupedItem *>(items));
-  EVP_CHECK_LAUNCH("evp_gemm_grouped_tn256_bf16");
+extern "C" int evp_gemm_set_stamp_buffer(void *buf, long long n_slots) {
+  g_stamp_buf = reinterpret_cast<unsigned long long *>(buf);
+  g_stamp_slots = buf ? n_slots : 0;
+  g_stamp_next = 0;
   return EVP_OK;
 }
-
-extern "C" int evp_gemm_grouped_tn_g4_bf16(const void *problems, const void *items, int n_items, void *stream) {
-  EVP_CHECK_ARG(problems && items && n_items > 0, EVP_EINVAL, "evp_gemm_grouped_tn_g4_bf16: bad argument");
-  auto k = gemm_g4_grouped_tn_kernel;
-  constexpr int smem = 4 * 2 * 32 * 512;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_gemm_grouped_tn_g4_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(k, dim3((unsigned)n_items), dim3(256), smem, (hipStream_t)stream,
-                     reinterpret_cast<const GroupedProblem *>(problems), reinterpret_cast<const GroupedItem *>(items));
-  EVP_CHECK_LAUNCH("evp_gemm_grouped_tn_g4_bf16");
-  return EVP_OK;
-}
-
-extern "C" int evp_gemm_set_debug_buffer(void *buf) {   // measurement aid: uint64 [4 * 512]; NULL switches it off
-  g_gemm_dbgbuf = reinterpret_cast<unsigned long long *>(buf);
-  return EVP_OK;
-}
+extern "C" long long evp_gemm_stamp_count(void) { return g_stamp_next; }
 
 extern "C" int evp_gemm_set_variant(int v) {
   const int old = g_gemm_variant;
   if (v >= 100 && v <= 102) g_gemm_dbg = v - 100;
   if (v == 1 || v == 2) g_gemm_variant = v;
+  if (v == 10 || v == 11) g_gemm_g4_fwd = v - 10;
   return old;
 }
 

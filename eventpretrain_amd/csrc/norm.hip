@@ -760,8 +760,14 @@ extern "C" int evp_layernorm_bwd_cs(const void *dy, int dy_dtype, const float *x
   hipStream_t s = (hipStream_t)stream;
   const int g = ln_grid(M);
   const size_t sh = (size_t)ROWS_PER_BLOCK * 3 * D * sizeof(float);
+  // three partial rows per wave live in LDS: 160 KiB per workgroup is the limit (D <= 3412 at 4 rows per block); wider rows take
+  // evp_layernorm_bwd (two partial rows) plus a column sum of dx (ops.layernorm_bwd does that by itself)
+  EVP_CHECK_ARG(sh <= 160 * 1024, EVP_ESHAPE, "evp_layernorm_bwd_cs: D=%d needs %zu bytes of LDS (> 160 KiB); use evp_layernorm_bwd", D, sh);
   DISPATCH_VPL(D, {
-    if (sh > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ln_bwd_kernel<V, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (sh > 48 * 1024) {
+      hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(ln_bwd_kernel<V, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      EVP_CHECK_ARG(ea == hipSuccess, EVP_ELAUNCH, "evp_layernorm_bwd_cs: hipFuncSetAttribute(%zu) failed: %s", sh, hipGetErrorString(ea));
+    }
     hipLaunchKernelGGL((ln_bwd_kernel<V, true>), dim3(g), dim3(LN_THREADS), sh, s, dy, dy_dtype, x, x2, x3, gamma, mean, rstd, gres, M, D, dx, dx_lp, workspace);
   });
   EVP_CHECK_LAUNCH("evp_layernorm_bwd_cs");

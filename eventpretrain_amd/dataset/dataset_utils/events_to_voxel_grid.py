@@ -28,11 +28,15 @@ def voxel_grid_batch(events, clip_offsets, num_bins, size, is_txyp=False, assume
     if out is None:
         out = torch.empty(n_clips, num_bins, H, W, dtype=torch.float32, device=dev)
     n_total = int(events.shape[0])
+    if n_total == 0:                    # every clip empty: the reference returns zero grids (no event touches any bin)
+        return out.zero_()
     if assume_sorted == "trust":
         mode = 1
     else:
         mode = (2 if algo == 0 else 1) if assume_sorted else 0
-    ws = torch.empty(n_clips * (num_bins + 2) + (3 * n_total + 1) // 2 + 2, dtype=torch.int64, device=dev)
+    # cuts [n_clips][bins + 2] int64, then the larger of the decode-once records (algo 2) and the verified mode's per-clip int32
+    # flags -- with many empty / tiny clips (n_total << n_clips) the flags are the larger part
+    ws = torch.empty(n_clips * (num_bins + 2) + max((3 * n_total + 1) // 2 + 2, (n_clips + 1) // 2), dtype=torch.int64, device=dev)
     if scale is None:
         call("evp_voxel_scatter_f32", ptr(events), ptr(clip_offsets), n_clips, n_total, int(num_bins), H, W, int(bool(is_txyp)),
              mode, int(algo), int(tile_rows), ptr(ws), ptr(out), stream_ptr())

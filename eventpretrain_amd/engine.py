@@ -30,6 +30,12 @@ class GraphedStep:
         hook before anything is launched and copied to the static device buffer; False = the captured graph cannot serve
         this step, which then runs eagerly with the same noise."""
         self.model, self.opt, self.forward, self.reducer = model, optimizer, forward, reducer
+        if step_prepare is not None and reducer is not None:
+            # The hook decides per step, from THIS rank's noise, whether the captured launch shape fits; a rank that falls back
+            # to an eager step while the others replay would leave the RCCL all-reduces unmatched (a hang at a random step).
+            # Until the decision is made collectively and the eager fall-back has a data-parallel form, refuse the combination.
+            raise ValueError("GraphedStep: step_prepare (per-step launch geometry, the Swin window plan) cannot be combined with a "
+                             "gradient reducer; step the data-parallel Swin model without the hook (eager window plan per step)")
         self.inputs = [t for t in static_inputs]
         dev = self.inputs[0].device
         self.gen = generator if generator is not None else torch.Generator(device=dev)
@@ -42,6 +48,7 @@ class GraphedStep:
             self._noise_pins = [torch.empty(*noise_shape).pin_memory() for _ in range(3)]
             self._noise_events, self._noise_turn, self._noise_cpu = [None] * 3, 0, None
         self.eager_fallbacks = 0
+        self.noise_feed = None         # optional iterator of (B, L) noise tensors used instead of a draw (tests: a given noise sequence)
         self.graph = self.graph0 = self.graph2 = self.plan = None
         self.parts = False
         self.loss = None
@@ -50,8 +57,18 @@ class GraphedStep:
         self.note = "eager"
         self.multi = reducer is not None
         self.wgrad_chunks = int(wgrad_chunks)
+        if use_graph and self.multi and self._forward_has_collective():
+            # collectives stay outside the captured graphs (module docstring): a forward that all-gathers the contrastive keys
+            # or re-broadcasts buffers from rank 0 is therefore not captured
+            use_graph = False
+            self.note = "eager (the forward holds a collective -- contrastive key all-gather / buffer broadcast -- which is kept out of HIP graphs)"
         if use_graph:
             self._capture(max(2, warmup))
+
+    def _forward_has_collective(self):
+        """True when the model's forward talks to other ranks (PrHubModel.forward_has_collective)."""
+        f = getattr(self.model, "forward_has_collective", None)
+        return bool(f()) if callable(f) else False
 
     # ------------------------------------------------------------------------------------------------ eager form
     def _draw_noise(self):
@@ -59,7 +76,10 @@ class GraphedStep:
         if self.noise is None:
             return True
         if self.step_prepare is None:
-            self.noise.copy_(torch.rand(self.noise.shape, device=self.noise.device, generator=self.gen))
+            if self.noise_feed is not None:
+                self.noise.copy_(next(self.noise_feed).to(self.noise.device, non_blocking=True))
+            else:
+                self.noise.copy_(torch.rand(self.noise.shape, device=self.noise.device, generator=self.gen))
             return True
         t = self._noise_turn
         self._noise_turn = (t + 1) % len(self._noise_pins)
@@ -241,7 +261,16 @@ class GraphedStep:
                 self._mark_tables_read()
         return self.loss
 
-    def _eager_fallback(self):
+    def eager_step_with(self, *inputs):
+        """One optimizer step on inputs whose shapes the captured graph cannot serve (the short last batch of an epoch), leaving
+        the graph usable for the batches after it. Single-process executors only."""
+        noise = None
+        if self.noise is not None:
+            B = inputs[0].shape[0]
+            noise = torch.rand(B, *self.noise.shape[1:], device=self.noise.device, generator=self.gen)
+        return self._eager_fallback(list(inputs), noise)
+
+    def _eager_fallback(self, inputs=None, noise=None):
         """One step outside the captured graph (the step's launch geometry does not fit it), leaving the graph usable: the
         eager backward must not accumulate into the captured gradient tensors, and the optimizer's eager refresh() rewrites
         the pinned pointer tables the graph's H2D nodes re-read -- both are put back."""
@@ -250,7 +279,10 @@ class GraphedStep:
         self.eager_fallbacks += 1
         torch.cuda.current_stream().synchronize()
         self.opt.zero_grad(set_to_none=True)
-        out = self.forward(self.model, *self.inputs, self._noise_cpu.clone())
+        if inputs is None:
+            out = self.forward(self.model, *self.inputs, self._noise_cpu.clone())
+        else:
+            out = self.forward(self.model, *inputs, noise)
         out[0].backward()
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)

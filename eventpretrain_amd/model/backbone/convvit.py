@@ -22,8 +22,8 @@ class ConvViT(nn.Module):
     def __init__(self, args, input_size=224, patch_size=16, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4.,
                  norm_layer=nn.LayerNorm, num_bins=5, mask_ratio=0., drop_rate=0., attn_drop_rate=0., drop_path_rate=0.):
         super().__init__()
-        if drop_rate or attn_drop_rate or drop_path_rate:
-            raise NotImplementedError("drop rates > 0 are not used on the pre-training path")
+        self.drop_rate = float(drop_rate)          # pos_drop (convvit.py:30,132,176)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depth))]     # stochastic depth decay rule (convvit.py:32)
         self.args = args
         self.patch_size = patch_size
         self.sizes = list(input_size)
@@ -33,12 +33,15 @@ class ConvViT(nn.Module):
         self.patch_embed4 = nn.Linear(embed_dim[2], embed_dim[2])
         self.num_patches = self.patch_embed3.num_patches
         self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches, embed_dim[2]), requires_grad=False)
-        self.conv_block1 = nn.ModuleList([ConvBlock(input_size=embed_dim[0], kernel_size=5, mlp_ratio=4.) for _ in range(depth[0])])
+        self.conv_block1 = nn.ModuleList([ConvBlock(input_size=embed_dim[0], kernel_size=5, mlp_ratio=4., drop=drop_rate, drop_path=dpr[i])
+                                          for i in range(depth[0])])
         # the reference sizes the second stage with depth[0] as well (convvit.py:36-38)
-        self.conv_block2 = nn.ModuleList([ConvBlock(input_size=embed_dim[1], kernel_size=5, mlp_ratio=4.) for _ in range(depth[0])])
+        self.conv_block2 = nn.ModuleList([ConvBlock(input_size=embed_dim[1], kernel_size=5, mlp_ratio=4., drop=drop_rate, drop_path=dpr[depth[0] + i])
+                                          for i in range(depth[0])])
         self.vit_block = nn.ModuleList([
-            ViTBlock(dim=embed_dim[2], num_heads=num_heads, mlp_ratio=mlp_ratio[2], qkv_bias=True, qk_scale=None, norm_layer=norm_layer)
-            for _ in range(depth[2])])
+            ViTBlock(dim=embed_dim[2], num_heads=num_heads, mlp_ratio=mlp_ratio[2], qkv_bias=True, qk_scale=None, drop=drop_rate,
+                     attn_drop=attn_drop_rate, drop_path=dpr[depth[0] + depth[1] + i], norm_layer=norm_layer)
+            for i in range(depth[2])])
         if args.phase == "pretrain" and args.pr_phase in ("rec", "rec+con", "rec-n"):
             self.mask_ratio = mask_ratio
             self.stage1_output_decode = nn.Conv2d(embed_dim[0], embed_dim[2], 4, stride=4)
@@ -87,6 +90,8 @@ class ConvViT(nn.Module):
                                         pe3.patch_size[0], s2, s2)
         t3 = ops.LinearFn.apply(t3, self.patch_embed4.weight, self.patch_embed4.bias)
         t3 = ops.AddPosGatherFn.apply(t3, self.pos_embed, ids_keep)
+        if self.training and self.drop_rate > 0:          # pos_drop (convvit.py:132,176)
+            t3 = ops.DropoutFn.apply(t3, self.drop_rate, int(torch.randint(0, 2 ** 62, (1,)).item()))
         return t1, t2, t3, (s1, s2)
 
     def forward(self, x, mask=False, noise=None):

@@ -187,8 +187,8 @@ class SwinTransformer(nn.Module):
                  out_indices=(0, 1, 2, 3), mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
                  drop_path_rate=0.2, norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs):
         super().__init__()
-        if drop_rate or attn_drop_rate or drop_path_rate:
-            raise NotImplementedError("drop rates > 0 are not used on the pre-training path")
+        self.drop_rate = float(drop_rate)          # pos_drop (swin.py:63,185,258)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]    # stochastic depth decay rule (swin.py:66)
         self.args = args
         self.img_size = img_size
         self.patch_size = patch_size
@@ -203,7 +203,7 @@ class SwinTransformer(nn.Module):
         self.swin_block = nn.ModuleList([
             BasicBlock(dim=int(embed_dim[0] * 2 ** i), input_resolution=(res[0] // (2 ** i), res[1] // (2 ** i)),
                        depth=depths[i], num_heads=num_heads[i], window_size=window_size, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
-                       qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate, drop_path=0., norm_layer=norm_layer,
+                       qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])], norm_layer=norm_layer,
                        downsample=PatchMerging if (i < self.num_layers - 1) else None)
             for i in range(self.num_layers)])
         self.norm_layer = norm_layer(embed_dim[-1])
@@ -280,6 +280,8 @@ class SwinTransformer(nn.Module):
         B = x.shape[0]
         ids = plan.tok_ids.unsqueeze(0).expand(B, -1).contiguous()
         t = self.patch_embed(x, ids)
+        if self.training and self.drop_rate > 0:          # pos_drop (swin.py:185,258)
+            t = ops.DropoutFn.apply(t, self.drop_rate, int(torch.randint(0, 2 ** 62, (1,)).item()))
         outs, attn = [], None
         last = len(self.swin_block) - 1
         for i, blk in enumerate(self.swin_block):

@@ -33,12 +33,11 @@ class ViT(nn.Module):
         self.patch_embed = PatchEmbed(img_size=input_size, patch_size=patch_size, in_chans=num_bins, embed_dim=embed_dim)
         self.num_patches = self.patch_embed.num_patches
         self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches, embed_dim), requires_grad=False)
-        if drop_rate:
-            raise NotImplementedError("drop_rate > 0 is not used on the pre-training path")
+        self.drop_rate = float(drop_rate)          # pos_drop (vit.py:26,114,137)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, depth)]      # stochastic depth decay rule (vit.py:28)
         self.vit_block = nn.ModuleList([
             ViTBlock(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=True, qk_scale=None,
-                     drop=drop_rate, attn_drop=attn_drop_rate, drop_path=drop_path_rate * i / max(depth - 1, 1),
-                     norm_layer=norm_layer) for i in range(depth)])
+                     drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer) for i in range(depth)])
         if args.phase == "pretrain" and args.pr_phase in ("rec", "rec+con", "rec-n"):
             self.mask_ratio = mask_ratio
         self.norm_layer = norm_layer(embed_dim)
@@ -69,11 +68,17 @@ class ViT(nn.Module):
         return ops.mask_from_noise(noise.contiguous().float(), self.mask_ratio)
 
     # ------------------------------------------------------------------------------------------------ forward
+    def pos_drop(self, t):
+        """nn.Dropout(p=drop_rate) on the embedded tokens (vit.py:114,137): training mode only."""
+        if self.training and self.drop_rate > 0:
+            t = ops.DropoutFn.apply(t, self.drop_rate, int(torch.randint(0, 2 ** 62, (1,)).item()))
+        return t
+
     def forward(self, x, mask=False, noise=None):
         eps = self.norm_layer.eps
         if mask:
             ids_keep, mask_t, ids_restore = self.random_masking(x, noise)
-            t = self.patch_embed.tokens(x, self.pos_embed, ids_keep)
+            t = self.pos_drop(self.patch_embed.tokens(x, self.pos_embed, ids_keep))
             emb_l1 = emb_l2 = None
             for i, blk in enumerate(self.vit_block):
                 t = blk(t)
@@ -87,7 +92,7 @@ class ViT(nn.Module):
                 emb_lh = ops.LayerNormFn.apply(t, None, None, self.norm_layer.weight, self.norm_layer.bias, eps)
             return emb_l1, emb_l2, emb_lh, mask_t, ids_restore
 
-        t = self.patch_embed.tokens(x, self.pos_embed, None)
+        t = self.pos_drop(self.patch_embed.tokens(x, self.pos_embed, None))
         out_embs = []
         emb_l1 = emb_l2 = attn = None
         last = len(self.vit_block) - 1

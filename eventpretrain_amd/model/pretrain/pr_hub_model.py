@@ -94,6 +94,17 @@ class PrHubModel(nn.Module):
             raise ValueError("queue_policy must be all_gather, rank0_broadcast or local")
         return pol if _dist_ready() else "local"
 
+    def forward_has_collective(self):
+        """True when forward() talks to other ranks: the key all-gather of the queue / of the in-batch InfoNCE (pr_hub_model.py:
+        248-259) or the reference-faithful buffer broadcast. The step executor keeps collectives outside captured HIP graphs,
+        so it does not capture such a forward (engine.GraphedStep)."""
+        if self.args.pr_phase not in _CON_PHASES or not _dist_ready():
+            return False
+        pol = self.queue_policy()
+        if pol == "rank0_broadcast":
+            return True
+        return pol == "all_gather" if self.args.use_queue else bool(self.args.distributed)
+
     @torch.no_grad()
     def _sync_buffers_from_rank0(self):
         """The reference-faithful mode's per-forward buffer broadcast (collective C2 in SURVEY.md 2.2)."""

@@ -31,7 +31,7 @@ def get_coordinates(h, w, device="cpu"):
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
         super().__init__()
-        _reject_dropout(drop=drop)
+        self.drop_rate = float(drop)                # applied by the block's fused function (ops.BlockDrop)
         self.fc1 = nn.Linear(in_features, hidden_features or in_features)
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
 
@@ -67,7 +67,8 @@ class WindowAttention(nn.Module):
 
     def __init__(self, dim, window_size, num_heads, qkv_bias=True, qk_scale=None, attn_drop=0., proj_drop=0.):
         super().__init__()
-        _reject_dropout(attn_drop=attn_drop, proj_drop=proj_drop)
+        _reject_dropout(attn_drop=attn_drop)
+        self.proj_drop_rate = float(proj_drop)
         if qk_scale is not None:
             raise NotImplementedError("qk_scale override is not used on the pre-training path")
         if not qkv_bias:
@@ -170,7 +171,8 @@ class SwinTransformerBlock(nn.Module):
     def __init__(self, dim, input_resolution, num_heads, window_size=7, shift_size=0, mlp_ratio=4., qkv_bias=True,
                  qk_scale=None, drop=0., attn_drop=0., drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
         super().__init__()
-        _reject_dropout(drop=drop, attn_drop=attn_drop, drop_path=drop_path)
+        self.drop_path_rate = float(drop_path)      # swin_block.py:257,270-271: per group instance (x.shape[0]), training mode only
+        self.drop_rate = float(drop)
         self.dim = dim
         self.input_resolution = input_resolution
         self.num_heads = num_heads
@@ -184,12 +186,13 @@ class SwinTransformerBlock(nn.Module):
             raise AssertionError("shift_size must in 0-window_size")
         self.norm1 = norm_layer(dim)
         self.attn = WindowAttention(dim, window_size=_pair(self.window_size), num_heads=num_heads, qkv_bias=qkv_bias,
-                                    qk_scale=qk_scale)
+                                    qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
         self.norm2 = norm_layer(dim)
-        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio))
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), drop=drop)
 
-    def forward(self, x, rel, return_attn=False):
-        return ops.swin_block(x, self, rel, self.norm1.eps, want_attn=return_attn)
+    def forward(self, x, rel, return_attn=False, block_drop=None):
+        rd = block_drop if block_drop is not None else ops.draw_block_drop(self, x.shape[0], x.device)
+        return ops.swin_block(x, self, rel, self.norm1.eps, want_attn=return_attn, rd=rd)
 
     def extra_repr(self):
         return (f"dim={self.dim}, input_resolution={self.input_resolution}, num_heads={self.num_heads}, "

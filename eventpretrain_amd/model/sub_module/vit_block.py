@@ -12,10 +12,12 @@ def _pair(v):
 
 
 def _reject_dropout(**rates):
+    """Attention-probability dropout is the one regulariser not built: the probabilities never leave the fused attention kernels.
+    Every entry script of the reference runs it at 0 (main_pretrain.py:99, main_finetune_cls.py:152)."""
     for k, v in rates.items():
         if v:
-            raise NotImplementedError(f"{k}={v}: the pre-training recipe runs with all drop rates 0 "
-                                      "(main_pretrain.py:98-100); stochastic regularisers are not built")
+            raise NotImplementedError(f"{k}={v}: dropout on the attention probabilities is not built (the reference's scripts run "
+                                      "attn_drop_rate = 0); drop_rate and drop_path_rate are")
 
 
 class PatchEmbed(nn.Module):
@@ -52,7 +54,8 @@ class Attention(nn.Module):
 
     def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
         super().__init__()
-        _reject_dropout(attn_drop=attn_drop, proj_drop=proj_drop)
+        _reject_dropout(attn_drop=attn_drop)
+        self.proj_drop_rate = float(proj_drop)      # applied by the block's fused function (ops.BlockDrop)
         if qk_scale is not None:
             raise NotImplementedError("qk_scale override is not used on the pre-training path")
         if not qkv_bias:
@@ -66,7 +69,7 @@ class Attention(nn.Module):
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
         super().__init__()
-        _reject_dropout(drop=drop)
+        self.drop_rate = float(drop)                # applied by the block's fused function (ops.BlockDrop)
         self.fc1 = nn.Linear(in_features, hidden_features or in_features)
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
 
@@ -77,13 +80,18 @@ class ViTBlock(nn.Module):
     def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
                  drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
         super().__init__()
-        _reject_dropout(drop=drop, attn_drop=attn_drop, drop_path=drop_path)
+        # stochastic depth (vit_block.py:241,252-253) and proj / Mlp dropout: training mode only, both branches; with both rates 0
+        # -- the pre-training recipe -- the block takes the fused path with the residual add inside the GEMM epilogue
+        self.drop_path_rate = float(drop_path)
+        self.drop_rate = float(drop)
         self.norm1 = norm_layer(dim)
-        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
         self.norm2 = norm_layer(dim)
-        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio))
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), drop=drop)
         if self.norm1.eps != self.norm2.eps:
             raise ValueError("norm1/norm2 eps differ")
 
-    def forward(self, x, return_attn=False):
-        return ops.vit_block(x, self, self.attn.num_heads, self.norm1.eps, want_attn=return_attn)
+    def forward(self, x, return_attn=False, block_drop=None):
+        """`block_drop` (ops.BlockDrop): explicit draws / masks for this call (tests); default: drawn here in training mode."""
+        rd = block_drop if block_drop is not None else ops.draw_block_drop(self, x.shape[0], x.device)
+        return ops.vit_block(x, self, self.attn.num_heads, self.norm1.eps, want_attn=return_attn, rd=rd)

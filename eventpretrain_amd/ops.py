@@ -51,19 +51,6 @@ def _chk(t, dtype=None):
 
 
 # ----------------------------------------------------------------------------------------------------- raw calls
-_SK_BYTES = 4096 + 65536 * 1024          # flags page + one 64 KiB accumulator slot per resident workgroup (<= 1023)
-_sk_ws = {}                              # (device index, stream handle) -> workspace: launches sharing one must be ordered
-
-
-def _streamk_workspace(dev):
-    key = (dev.index, stream_ptr())
-    ws = _sk_ws.get(key)
-    if ws is None:
-        ws = torch.zeros(_SK_BYTES, dtype=torch.uint8, device=dev)      # the flags page must start zeroed
-        _sk_ws[key] = ws
-    return ws
-
-
 def gemm(a, b, out, *, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, bias=None, act=ACT_NONE,
          aux=None, residual=None, alpha=1.0, accumulate=False, batch=(1, 1), stride_a=(0, 0), stride_b=(0, 0),
          stride_c=(0, 0), a_off=0, b_off=0, c_off=0, tile=0, splitk=0):
@@ -98,9 +85,6 @@ def gemm(a, b, out, *, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None
     d.accumulate = int(accumulate)
     d.tile = int(tile)
     d.splitk = int(splitk)
-    if tile == 12:           # stream-K variant (explicit only): needs the caller-owned workspace
-        ws = _streamk_workspace(a.device)
-        d.sk_workspace, d.sk_workspace_bytes = ws.data_ptr(), ws.numel()
     call("evp_gemm", C.byref(d), stream_ptr())
     return out
 
@@ -201,7 +185,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, gres=None, x2=None, x3=None, want_lp
     dx_lp = torch.empty(M, D, dtype=torch.bfloat16, device=x.device) if want_lp else None
     nb = call("evp_layernorm_bwd_nblk", M)
     defer = (params is not None and D % 8 == 0 and _deferred.can_defer(params[0]) and _deferred.can_defer(params[1]))
-    if defer and side and _use_grad_side:
+    # (the three-partial-row kernel keeps 4 rows x 3 D floats in LDS: D <= 3412; wider rows take the plain kernel below and the
+    # consumer of dx casts / column-sums it itself)
+    if defer and side and _use_grad_side and 4 * 3 * D * 4 <= 160 * 1024:
         ws = torch.empty(nb, 3 * D, dtype=torch.float32, device=x.device)
         call("evp_layernorm_bwd_cs", ptr(_chk(dy)), dt(dy), ptr(x), ptr(x2), ptr(x3), ptr(gamma), ptr(mean), ptr(rstd),
              ptr(gres), M, D, ptr(dx), ptr(dx_lp), ptr(ws), stream_ptr())
@@ -455,8 +441,8 @@ class _DeferredGrads:
         if w:
             dev = w[0][1].device
 
-            def big_(it):       # long-K problems with >= 256-wide outputs go to the 256x256 ring kernel
-                return _use_wgrad256 and it[5] % 64 == 0 and it[3] >= 256 and it[4] >= 256
+            def big_(it):       # long-K problems with >= 256-wide outputs go to the 256x256 G4 kernel (K % 32 == 0, K >= 96)
+                return _use_wgrad_g4 and it[5] % 32 == 0 and it[5] >= 96 and it[3] >= 256 and it[4] >= 256
             # a bias gradient rides on its Linear's weight-gradient problem only in the 256x256 kernel; otherwise it joins
             # the grouped column sums below
             for it in w:
@@ -488,10 +474,7 @@ class _DeferredGrads:
                     for c in range(len(cuts) - 1):
                         if cuts[c + 1] > cuts[c]:
                             part_ = big[cuts[c]:cuts[c + 1]]
-                            # G4 body (one wave per SIMD, 32-deep stages): K % 32 == 0 holds for every `big_` problem (K % 64)
-                            entry_ = "evp_gemm_grouped_tn_g4_bf16" if (_use_wgrad_g4 and all(it[5] >= 96 for it in part_)) else \
-                                "evp_gemm_grouped_tn256_bf16"
-                            groups.append(("w256r%dc%d" % (r, c), part_, 256, entry_))
+                            groups.append(("w256r%dc%d" % (r, c), part_, 256, "evp_gemm_grouped_tn_g4_bf16"))
                 if small:
                     groups.append(("w128r%d" % r, small, 128, "evp_gemm_grouped_tn_bf16"))
                 for tag, part, T_, entry in groups:
@@ -624,8 +607,8 @@ _use_wgrad_g4 = os.environ.get("EVP_WGRAD_G4", "1") != "0"
 
 
 def set_wgrad_g4(flag):
-    """A/B switch: grouped 256x256 weight gradients on the G4 body (one wave per SIMD, 32x32x16; default) or on the 8-wave
-    half-tile ring."""
+    """A/B switch: long-K weight gradients with >= 256-wide outputs on the 256x256 G4 body (one wave per SIMD, 32x32x16; default)
+    or on 128x128 tiles like the rest."""
     global _use_wgrad_g4
     _use_wgrad_g4 = bool(flag)
 
@@ -638,15 +621,6 @@ def set_wgrad_xcd_order(flag):
 
 
 _deferred = _DeferredGrads()
-_use_wgrad256 = os.environ.get("EVP_WGRAD256", "1") != "0"
-
-
-def set_wgrad256(flag):
-    """A/B switch: route long-K weight gradients to the 256x256 ring kernel (default) or keep all on 128x128 tiles."""
-    global _use_wgrad256
-    _use_wgrad256 = bool(flag)
-
-
 def set_deferred_grads(flag):
     """A/B switch: grouped end-of-backward weight/bias gradients (default) or one GEMM / column sum per layer."""
     _deferred.enabled = bool(flag)
@@ -723,12 +697,88 @@ def _bgrad(x2d, param=None):
     return colsum(x2d)
 
 
+
+# ----------------------------------------------------------------------------------------------------- stochastic regularisers
+class BlockDrop:
+    """Stochastic regularisers of ONE call of a residual block (reference vit_block.py:241,252-253 / conv_block.py:35,43-49 /
+    swin_block.py:257,270-271; timm `drop_path`, nn.Dropout): `u1`, `u2` = float32 [x.shape[0]] uniform draws for the two
+    DropPath applications (None = off), keep_prob = 1 - drop_path; `drop` = elementwise dropout rate of the branch outputs and the
+    MLP hidden (proj_drop / Mlp.drop), its masks drawn by evp_dropout_fwd from (seed, a per-use offset). A block called with
+    rd=None takes the fused fast path (residual add inside the GEMM epilogue)."""
+
+    def __init__(self, u1=None, u2=None, keep_prob=1.0, drop=0.0, seed=0, masks=None):
+        self.u = (u1, u2)
+        self.keep_prob = float(keep_prob)
+        self.drop = float(drop)
+        self.seed = int(seed)
+        self.masks = masks            # optional explicit uint8 masks {"proj": .., "hidden": .., "fc2": ..} (tests: given-mask parity)
+        self._n = 0
+
+    def next_offset(self, numel):
+        o = self._n
+        self._n += (numel + 3) // 4
+        return o
+
+
+def dropout_fwd(x, rd, key):
+    """-> (x * keep / (1 - p), mask uint8) for a contiguous tensor; the mask is rd.masks[key] when given."""
+    out = torch.empty_like(x)
+    n = x.numel()
+    if rd.masks is not None and key in rd.masks:
+        mask = _chk(rd.masks[key]).view(-1)
+        call("evp_dropout_apply", ptr(_chk(x)), dt(x), ptr(mask), ptr(out), n, 1.0 / (1.0 - rd.drop), stream_ptr())
+        return out, mask
+    mask = torch.empty(n, dtype=torch.uint8, device=x.device)
+    call("evp_dropout_fwd", ptr(_chk(x)), dt(x), ptr(out), ptr(mask), n, rd.drop, rd.seed, rd.next_offset(n), stream_ptr())
+    return out, mask
+
+
+def dropout_bwd(g, mask, p):
+    out = torch.empty_like(g)
+    call("evp_dropout_apply", ptr(_chk(g)), dt(g), ptr(mask), ptr(out), g.numel(), 1.0 / (1.0 - p), stream_ptr())
+    return out
+
+
+def rows_scale(x, u, keep_prob, rows_per_sample, res=None, want_out=True, want_lp=False):
+    """(res + s_b * x, bf16(s_b * x)) with s_b = floor(keep_prob + u[b]) / keep_prob per sample b (evp_rows_scale_f32)."""
+    M, D = x.shape
+    out = torch.empty(M, D, dtype=torch.float32, device=x.device) if want_out else None
+    lp = torch.empty(M, D, dtype=torch.bfloat16, device=x.device) if want_lp else None
+    call("evp_rows_scale_f32", ptr(_chk(x, torch.float32)), ptr(u), float(keep_prob), ptr(res), M, D, int(rows_per_sample), ptr(out), ptr(lp),
+         stream_ptr())
+    return out, lp
+
+
+def _branch_residual(a, w, bias, res, M, N, K, rd, which, rps, key):
+    """Residual-stream output of one branch: res + drop_path(dropout(a . w^T + bias)). rd None: fused in the GEMM epilogue."""
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if rd is None:
+        gemm(a, w, out, M=M, N=N, K=K, bias=bias, residual=res)
+        return out, None
+    gemm(a, w, out, M=M, N=N, K=K, bias=bias)
+    mk = None
+    if rd.drop > 0:
+        out, mk = dropout_fwd(out, rd, key)
+    y, _ = rows_scale(out, rd.u[which], rd.keep_prob, rps, res=res)
+    return y, mk
+
+
+def _branch_grad(g, rd, which, rps, mk, T):
+    """Gradient entering a branch whose output was added as res + drop_path(dropout(.)): (f32, compute-dtype copy)."""
+    bf = T == torch.bfloat16
+    gs, gs_lp = rows_scale(g, rd.u[which], rd.keep_prob, rps, want_lp=bf and mk is None)
+    if mk is not None:
+        gs = dropout_bwd(gs, mk, rd.drop)
+        gs_lp = cast(gs, T) if bf else None
+    return gs, (gs_lp if bf else gs)
+
+
 # ----------------------------------------------------------------------------------------------------- autograd
 class ViTBlockFn(torch.autograd.Function):
     """Pre-LN transformer block (model/sub_module/vit_block.py:246-254) on a [B,N,D] f32 residual stream."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, heads, eps, want_attn):
+    def forward(ctx, x, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, heads, eps, want_attn, rd=None):
         B, N, D = x.shape
         M = B * N
         dh = D // heads
@@ -745,19 +795,21 @@ class ViTBlockFn(torch.autograd.Function):
         else:
             probs, att = attention_fwd(qkv, B, N, heads, dh)
             stat = probs
-        x1 = torch.empty(M, D, dtype=torch.float32, device=dev)
-        gemm(att, wp, x1, M=M, N=D, K=D, bias=pb, residual=x2d)
+        x1, mk_p = _branch_residual(att, wp, pb, x2d, M, D, D, rd, 0, N, "proj")
         ln2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, eps, T)
         Hd = f1w.shape[0]
         h_pre = torch.empty(M, Hd, dtype=T, device=dev)
         h_act = torch.empty(M, Hd, dtype=T, device=dev)
         gemm(ln2, w1, h_act, M=M, N=Hd, K=D, bias=f1b, act=ACT_GELU, aux=h_pre)
-        x2 = torch.empty(M, D, dtype=torch.float32, device=dev)
-        gemm(h_act, w2, x2, M=M, N=D, K=Hd, bias=f2b, residual=x1)
+        mk_h = None
+        if rd is not None and rd.drop > 0:
+            h_act, mk_h = dropout_fwd(h_act, rd, "hidden")
+        x2, mk_2 = _branch_residual(h_act, w2, f2b, x1, M, D, Hd, rd, 1, N, "fc2")
         ctx.save_for_backward(x2d, n1w, n2w, mean1, rstd1, ln1, qkv, stat, att, x1, mean2, rstd2, ln2, h_pre, h_act,
                               wq, wp, w1, w2)
         ctx.dims = (B, N, D, heads, dh, Hd)
         ctx.fused = fused
+        ctx.rd, ctx.drop_masks = rd, (mk_p, mk_h, mk_2)
         ctx.prm = (qkvw, qkvb, pw, pb, f1w, f1b, f2w, f2b)     # leaf parameters: targets of the deferred gradients
         ctx.nprm = (n1w, n1b, n2w, n2b)
         out = x2.view(B, N, D)
@@ -777,24 +829,35 @@ class ViTBlockFn(torch.autograd.Function):
         dev = g2.device
         bf = T == torch.bfloat16
         g2 = _chk(g2.contiguous(), torch.float32).view(M, D)
+        rd = ctx.rd
+        mk_p, mk_h, mk_2 = ctx.drop_masks
         # bf16 copy and column-sum partials of the incoming gradient, if the LayerNorm backward that made it left them
         g2_side_lp, g2_cs = _side_take(g2) if bf else (None, None)
-        g2_lp = g2_side_lp if g2_side_lp is not None else cast(g2, T)
+        if rd is None:
+            g2b, g2_lp = g2, (g2_side_lp if g2_side_lp is not None else cast(g2, T))
+        else:                           # the MLP branch sees s_b * g (DropPath) times the fc2-output dropout mask
+            (g2b, g2_lp), g2_cs = _branch_grad(g2, rd, 1, N, mk_2, T), None
         qkvw_, qkvb_, pw_, pb_, f1w_, f1b_, f2w_, f2b_ = ctx.prm
         need = ctx.needs_input_grad
         # MLP
-        dw2, db2 = _wgrad_bias(g2_lp, h_act, D, Hd, M, f2w_, f2b_, need[11], need[12], dy_f32=g2, dy_colsum=g2_cs)
+        dw2, db2 = _wgrad_bias(g2_lp, h_act, D, Hd, M, f2w_, f2b_, need[11], need[12], dy_f32=g2b, dy_colsum=g2_cs)
         dh_pre = torch.empty(M, Hd, dtype=T, device=dev)
         gemm(g2_lp, w2, dh_pre, M=M, N=Hd, K=D, trans_b=True, ldb=Hd, act=ACT_DGELU, aux=h_pre)
+        if mk_h is not None:            # hidden dropout sits between GELU and fc2: its mask commutes with the GELU' product
+            dh_pre = dropout_bwd(dh_pre, mk_h, rd.drop)
         dw1, db1 = _wgrad_bias(dh_pre, ln2, Hd, D, M, f1w_, f1b_, need[9], need[10])
         dln2 = torch.empty(M, D, dtype=T, device=dev)
         gemm(dh_pre, w1, dln2, M=M, N=D, K=Hd, trans_b=True, ldb=D)
-        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf, params=ctx.nprm[2:], side=bf)
-        g1_side_lp, g1_cs = _side_take(g1) if bf else (None, None)
-        if not bf:
+        side = bf and rd is None
+        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=side, params=ctx.nprm[2:], side=side)
+        g1_side_lp, g1_cs = _side_take(g1) if side else (None, None)
+        g1b = g1
+        if rd is not None:
+            g1b, g1_lp = _branch_grad(g1, rd, 0, N, mk_p, T)
+        elif not bf:
             g1_lp = g1
         # attention
-        dwp, dbp = _wgrad_bias(g1_lp, att, D, D, M, pw_, pb_, need[5], need[6], dy_f32=g1, dy_colsum=g1_cs)
+        dwp, dbp = _wgrad_bias(g1_lp, att, D, D, M, pw_, pb_, need[5], need[6], dy_f32=g1b, dy_colsum=g1_cs)
         datt = torch.empty(M, D, dtype=T, device=dev)
         gemm(g1_lp, wp, datt, M=M, N=D, K=D, trans_b=True, ldb=D)
         if ctx.fused:
@@ -806,7 +869,7 @@ class ViTBlockFn(torch.autograd.Function):
         gemm(dqkv, wq, dln1, M=M, N=D, K=3 * D, trans_b=True, ldb=D)
         # the block below this one takes g0 as ITS incoming gradient: leave it the bf16 copy and the column sums
         g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1, want_lp=bf, params=ctx.nprm[:2], side=bf)
-        return (g0.view(B, N, D), dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None)
+        return (g0.view(B, N, D), dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None, None)
 
 
 class PatchEmbedFn(torch.autograd.Function):
@@ -1004,11 +1067,11 @@ class RecLossFn(torch.autograd.Function):
         return dpred, None, None, None, None
 
 
-def vit_block(x, blk, heads, eps, want_attn=False):
+def vit_block(x, blk, heads, eps, want_attn=False, rd=None):
     return ViTBlockFn.apply(x, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias,
                             blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias,
                             blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias,
-                            heads, eps, want_attn)
+                            heads, eps, want_attn, rd)
 
 
 # ----------------------------------------------------------------------------------------------------- contrastive stage
@@ -1361,7 +1424,7 @@ class ConvBlockFn(torch.autograd.Function):
     x = x + conv2(dw5x5(keep * conv1(LN(x)))); x = x + fc2(GELU(fc1(LN(x)))), 1x1 convs as GEMMs."""
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, c1w, c1b, aw, ab, c2w, c2b, n2w, n2b, f1w, f1b, f2w, f2b, mask, mask_scale, H, W):
+    def forward(ctx, x, n1w, n1b, c1w, c1b, aw, ab, c2w, c2b, n2w, n2b, f1w, f1b, f2w, f2b, mask, mask_scale, H, W, rd=None):
         B, HW, Cc = x.shape
         M = B * HW
         T = _compute_dtype
@@ -1376,14 +1439,17 @@ class ConvBlockFn(torch.autograd.Function):
         a = torch.empty(M, Cc, dtype=T, device=dev)
         awf = _chk(aw.detach().contiguous(), torch.float32)
         call("evp_dwconv5x5_fwd", ptr(c1), dt(c1), ptr(mask), int(mask_scale), ptr(awf), ptr(ab), B, H, W, Cc, ptr(a), stream_ptr())
-        x1 = torch.empty(M, Cc, dtype=torch.float32, device=dev)
-        gemm(a, w2, x1, M=M, N=Cc, K=Cc, bias=c2b, residual=x2d)
+        # (CMlp.drop sits after GELU and after fc2, conv_block.py:19-21; the conv branch has no dropout of its own)
+        x1, _ = _branch_residual(a, w2, c2b, x2d, M, Cc, Cc, rd if (rd is None or rd.drop == 0) else BlockDrop(rd.u[0], rd.u[1], rd.keep_prob), 0, HW, "conv2")
         ln2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, 1e-5, T)
         h_pre = torch.empty(M, Hd, dtype=T, device=dev)
         h_act = torch.empty(M, Hd, dtype=T, device=dev)
         gemm(ln2, wf1, h_act, M=M, N=Hd, K=Cc, bias=f1b, act=ACT_GELU, aux=h_pre)
-        x2 = torch.empty(M, Cc, dtype=torch.float32, device=dev)
-        gemm(h_act, wf2, x2, M=M, N=Cc, K=Hd, bias=f2b, residual=x1)
+        mk_h = None
+        if rd is not None and rd.drop > 0:
+            h_act, mk_h = dropout_fwd(h_act, rd, "hidden")
+        x2, mk_2 = _branch_residual(h_act, wf2, f2b, x1, M, Cc, Hd, rd, 1, HW, "fc2")
+        ctx.rd, ctx.drop_masks = rd, (mk_h, mk_2)
         ctx.save_for_backward(x2d, n1w, n2w, mean1, rstd1, ln1, c1, a, x1, mean2, rstd2, ln2, h_pre, h_act, w1, w2, wf1, wf2, awf, mask)
         ctx.cfg = (B, H, W, Cc, Hd, int(mask_scale), tuple(aw.shape))
         ctx.prm = (c1w, c1b, c2w, c2b, f1w, f1b, f2w, f2b)
@@ -1404,19 +1470,31 @@ class ConvBlockFn(torch.autograd.Function):
         # as in ViTBlockFn: bf16 copy / column sums left by the LayerNorm backward of the block above, bias gradients on the
         # weight-gradient launch, LayerNorm dgamma / dbeta through the grouped column sums
         g2_side_lp, g2_cs = _side_take(g2) if bf else (None, None)
-        g2_lp = g2_side_lp if g2_side_lp is not None else cast(g2, T)
-        dwf2, db2 = _wgrad_bias(g2_lp, h_act, Cc, Hd, M, f2w_, f2b_, need[13], need[14], dy_f32=g2, shape=tuple(f2w_.shape), dy_colsum=g2_cs)
+        rd = ctx.rd
+        mk_h, mk_2 = ctx.drop_masks
+        HW = H * W
+        if rd is None:
+            g2b, g2_lp = g2, (g2_side_lp if g2_side_lp is not None else cast(g2, T))
+        else:
+            (g2b, g2_lp), g2_cs = _branch_grad(g2, rd, 1, HW, mk_2, T), None
+        dwf2, db2 = _wgrad_bias(g2_lp, h_act, Cc, Hd, M, f2w_, f2b_, need[13], need[14], dy_f32=g2b, shape=tuple(f2w_.shape), dy_colsum=g2_cs)
         dh_pre = torch.empty(M, Hd, dtype=T, device=dev)
         gemm(g2_lp, wf2, dh_pre, M=M, N=Hd, K=Cc, trans_b=True, ldb=Hd, act=ACT_DGELU, aux=h_pre)
+        if mk_h is not None:
+            dh_pre = dropout_bwd(dh_pre, mk_h, rd.drop)
         dwf1, db1 = _wgrad_bias(dh_pre, ln2, Hd, Cc, M, f1w_, f1b_, need[11], need[12], shape=tuple(f1w_.shape))
         dln2 = torch.empty(M, Cc, dtype=T, device=dev)
         gemm(dh_pre, wf1, dln2, M=M, N=Cc, K=Hd, trans_b=True, ldb=Cc)
-        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf, params=ctx.nprm[2:], side=bf)
-        g1_side_lp, g1_cs = _side_take(g1) if bf else (None, None)
-        if not bf:
+        side = bf and rd is None
+        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=side, params=ctx.nprm[2:], side=side)
+        g1_side_lp, g1_cs = _side_take(g1) if side else (None, None)
+        g1b = g1
+        if rd is not None:
+            g1b, g1_lp = _branch_grad(g1, rd, 0, HW, None, T)
+        elif not bf:
             g1_lp = g1
         # conv branch
-        dwc2, dbc2 = _wgrad_bias(g1_lp, a, Cc, Cc, M, c2w_, c2b_, need[7], need[8], dy_f32=g1, shape=tuple(c2w_.shape), dy_colsum=g1_cs)
+        dwc2, dbc2 = _wgrad_bias(g1_lp, a, Cc, Cc, M, c2w_, c2b_, need[7], need[8], dy_f32=g1b, shape=tuple(c2w_.shape), dy_colsum=g1_cs)
         da = torch.empty(M, Cc, dtype=T, device=dev)
         gemm(g1_lp, w2, da, M=M, N=Cc, K=Cc, trans_b=True, ldb=Cc)
         dc1 = torch.empty(M, Cc, dtype=T, device=dev)
@@ -1431,13 +1509,13 @@ class ConvBlockFn(torch.autograd.Function):
         gemm(dc1, w1, dln1, M=M, N=Cc, K=Cc, trans_b=True, ldb=Cc)
         g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1, want_lp=bf, params=ctx.nprm[:2], side=bf)
         return (g0.view(B, H * W, Cc), dn1w, dn1b, dwc1, dbc1, daw.view(awshape), dab, dwc2, dbc2, dn2w, dn2b, dwf1, db1, dwf2, db2,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
-def conv_block(x, blk, H, W, mask=None, mask_scale=1):
+def conv_block(x, blk, H, W, mask=None, mask_scale=1, rd=None):
     return ConvBlockFn.apply(x, blk.norm1.weight, blk.norm1.bias, blk.conv1.weight, blk.conv1.bias, blk.attn.weight, blk.attn.bias,
                              blk.conv2.weight, blk.conv2.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight,
-                             blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, mask, mask_scale, H, W)
+                             blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, mask, mask_scale, H, W, rd)
 
 
 # ----------------------------------------------------------------------------------------------------- Swin (row a15)
@@ -1546,7 +1624,7 @@ class SwinBlockFn(torch.autograd.Function):
     pre-LN, window attention with the gathered relative-position bias and the -100 group mask (:135-158), MLP."""
 
     @staticmethod
-    def forward(ctx, x, table, rel, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, heads, eps, want_attn):
+    def forward(ctx, x, table, rel, n1w, n1b, qkvw, qkvb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b, heads, eps, want_attn, rd=None):
         Bg, N, D = x.shape
         nG = rel.shape[0]
         M = Bg * N
@@ -1579,15 +1657,17 @@ class SwinBlockFn(torch.autograd.Function):
         else:
             call("evp_window_attention_fwd", ptr(qkv), ptr(tab), ptr(_chk(rel, torch.int32)), ptr(att), ptr(probs), Bg, nG, N, heads, R,
                  scale, dt(qkv), stream_ptr())
-        x1 = torch.empty(M, D, dtype=torch.float32, device=dev)
-        gemm(att, wp, x1, M=M, N=D, K=D, bias=pb, residual=x2d)
+        x1, mk_p = _branch_residual(att, wp, pb, x2d, M, D, D, rd, 0, N, "proj")
         ln2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, eps, T)
         Hd = f1w.shape[0]
         h_pre = torch.empty(M, Hd, dtype=T, device=dev)
         h_act = torch.empty(M, Hd, dtype=T, device=dev)
         gemm(ln2, w1, h_act, M=M, N=Hd, K=D, bias=f1b, act=ACT_GELU, aux=h_pre)
-        x2 = torch.empty(M, D, dtype=torch.float32, device=dev)
-        gemm(h_act, w2, x2, M=M, N=D, K=Hd, bias=f2b, residual=x1)
+        mk_h = None
+        if rd is not None and rd.drop > 0:
+            h_act, mk_h = dropout_fwd(h_act, rd, "hidden")
+        x2, mk_2 = _branch_residual(h_act, w2, f2b, x1, M, D, Hd, rd, 1, N, "fc2")
+        ctx.rd, ctx.drop_masks = rd, (mk_p, mk_h, mk_2)
         ctx.save_for_backward(x2d, n1w, n2w, mean1, rstd1, ln1, qkv, att, x1, mean2, rstd2, ln2, h_pre, h_act, wq, wp, w1, w2,
                               tab, rel)
         ctx.dims = (Bg, nG, N, D, heads, dh, Hd, R, scale)
@@ -1613,20 +1693,31 @@ class SwinBlockFn(torch.autograd.Function):
         # as in ViTBlockFn: the LayerNorm backward that produced g2 (the block above, when no regrouping gather sits in between:
         # the single-group stages) may have left its bf16 copy and column sums; bias gradients ride on the weight-gradient launch
         g2_side_lp, g2_cs = _side_take(g2) if bf else (None, None)
-        g2_lp = g2_side_lp if g2_side_lp is not None else cast(g2, T)
+        rd = ctx.rd
+        mk_p, mk_h, mk_2 = ctx.drop_masks
+        if rd is None:
+            g2b, g2_lp = g2, (g2_side_lp if g2_side_lp is not None else cast(g2, T))
+        else:
+            (g2b, g2_lp), g2_cs = _branch_grad(g2, rd, 1, N, mk_2, T), None
         qkvw_, qkvb_, pw_, pb_, f1w_, f1b_, f2w_, f2b_ = ctx.prm
         need = ctx.needs_input_grad
-        dw2, db2 = _wgrad_bias(g2_lp, h_act, D, Hd, M, f2w_, f2b_, need[13], need[14], dy_f32=g2, dy_colsum=g2_cs)
+        dw2, db2 = _wgrad_bias(g2_lp, h_act, D, Hd, M, f2w_, f2b_, need[13], need[14], dy_f32=g2b, dy_colsum=g2_cs)
         dh_pre = torch.empty(M, Hd, dtype=T, device=dev)
         gemm(g2_lp, w2, dh_pre, M=M, N=Hd, K=D, trans_b=True, ldb=Hd, act=ACT_DGELU, aux=h_pre)
+        if mk_h is not None:
+            dh_pre = dropout_bwd(dh_pre, mk_h, rd.drop)
         dw1, db1 = _wgrad_bias(dh_pre, ln2, Hd, D, M, f1w_, f1b_, need[11], need[12])
         dln2 = torch.empty(M, D, dtype=T, device=dev)
         gemm(dh_pre, w1, dln2, M=M, N=D, K=Hd, trans_b=True, ldb=D)
-        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=bf, params=ctx.nprm[2:], side=bf)
-        g1_side_lp, g1_cs = _side_take(g1) if bf else (None, None)
-        if not bf:
+        side = bf and rd is None
+        g1, g1_lp, dn2w, dn2b = layernorm_bwd(dln2, x1, n2w, mean2, rstd2, gres=g2, want_lp=side, params=ctx.nprm[2:], side=side)
+        g1_side_lp, g1_cs = _side_take(g1) if side else (None, None)
+        g1b = g1
+        if rd is not None:
+            g1b, g1_lp = _branch_grad(g1, rd, 0, N, mk_p, T)
+        elif not bf:
             g1_lp = g1
-        dwp, dbp = _wgrad_bias(g1_lp, att, D, D, M, pw_, pb_, need[7], need[8], dy_f32=g1, dy_colsum=g1_cs)
+        dwp, dbp = _wgrad_bias(g1_lp, att, D, D, M, pw_, pb_, need[7], need[8], dy_f32=g1b, dy_colsum=g1_cs)
         datt = torch.empty(M, D, dtype=T, device=dev)
         gemm(g1_lp, wp, datt, M=M, N=D, K=D, trans_b=True, ldb=D)
         dqkv = torch.empty(M, 3 * D, dtype=T, device=dev)
@@ -1645,14 +1736,49 @@ class SwinBlockFn(torch.autograd.Function):
         dln1 = torch.empty(M, D, dtype=T, device=dev)
         gemm(dqkv, wq, dln1, M=M, N=D, K=3 * D, trans_b=True, ldb=D)
         g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1, want_lp=bf, params=ctx.nprm[:2], side=bf)
-        return (g0.view(Bg, N, D), dtable, None, dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None)
+        return (g0.view(Bg, N, D), dtable, None, dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None, None)
 
 
-def swin_block(x, blk, rel, eps, want_attn=False):
+def swin_block(x, blk, rel, eps, want_attn=False, rd=None):
     a = blk.attn
     return SwinBlockFn.apply(x, a.relative_position_bias_table, rel, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias,
                              a.proj.weight, a.proj.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
-                             blk.mlp.fc2.weight, blk.mlp.fc2.bias, a.num_heads, eps, want_attn)
+                             blk.mlp.fc2.weight, blk.mlp.fc2.bias, a.num_heads, eps, want_attn, rd)
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout on a float32 tensor (vit.py:114 / convvit.py:132 / swin.py:185 `pos_drop`): evp_dropout_fwd / evp_dropout_apply."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, mask=None):
+        xc = _chk(x.detach().contiguous(), torch.float32)
+        rd = BlockDrop(drop=p, seed=seed, masks=None if mask is None else {"x": mask})
+        out, mk = dropout_fwd(xc, rd, "x")
+        ctx.save_for_backward(mk)
+        ctx.p = p
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mk,) = ctx.saved_tensors
+        return dropout_bwd(_chk(g.contiguous(), torch.float32), mk, ctx.p).view(g.shape), None, None, None
+
+
+def draw_block_drop(module, n_samples, device):
+    """BlockDrop for one training-mode call of a residual block module carrying `drop_path_rate` / `drop_rate` attributes, or None
+    when both are off (the fused fast path). The draws come from torch's default generator of the device (as timm's `drop_path`
+    and nn.Dropout do), so torch.manual_seed reproduces a run; the per-element masks use the Philox stream keyed by a seed
+    drawn from the host generator."""
+    dp = float(getattr(module, "drop_path_rate", 0.0) or 0.0)
+    dr = float(getattr(module, "drop_rate", 0.0) or 0.0)
+    if not module.training or (dp <= 0.0 and dr <= 0.0):
+        return None
+    u1 = u2 = None
+    if dp > 0.0:
+        u = torch.rand(2, n_samples, device=device)
+        u1, u2 = u[0], u[1]
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if dr > 0.0 else 0
+    return BlockDrop(u1, u2, 1.0 - dp, dr, seed)
 
 
 class AddFn(torch.autograd.Function):

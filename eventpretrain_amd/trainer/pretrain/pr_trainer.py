@@ -8,7 +8,55 @@ from ...utils import misc
 from ...utils.lr_sched import adjust_learning_rate
 
 
-def _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, loss_name, forward, vis_hook, step_executor=None):
+def auto_step_executor(args, model, optimizer, loss_scaler, batch_tensors, loss_name, vis_hook=None):
+    """The step executor the epoch loops build by themselves on their first batch (and keep on the model): forward + backward +
+    FusedAdamW captured once as a HIP graph and replayed per batch -- an eager step of this path is ~600 launches from Python and
+    runs host-bound at 2.5-3x the device time. Returns None where the captured form cannot stand in for the
+    eager loop: gradient accumulation (accum_iter > 1), backward off, visualisation inside the loop, an optimizer that is not
+    FusedAdamW, a CPU device, a forward replaced on the instance, or `args.graph_step = False` (the opt-out). A data-parallel run
+    takes the executor's multi-GPU form with the scaler's reducer."""
+    from ...engine import GraphedStep
+    from ...optim import FusedAdamW
+    if not getattr(args, "graph_step", True) or args.accum_iter != 1 or not args.backward:
+        return None
+    if not str(args.device).startswith("cuda") or not isinstance(optimizer, FusedAdamW) or "forward" in vars(model):
+        return None
+    if vis_hook is not None and args.visualize:
+        return None
+    x, y = batch_tensors
+    key = (id(optimizer), loss_name, tuple(x.shape), tuple(y.shape), str(ops_dtype()))
+    cached = getattr(model, "_evp_auto_executor", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    if cached is not None and cached[0][:2] == key[:2] and cached[0][4] == key[4]:
+        return cached[1]               # same model / optimizer / phase, another batch shape: the loop steps it eagerly through the executor
+    reducer = getattr(loss_scaler, "reducer", None)
+    is_rec = loss_name == "reconstruct_loss"
+    noise_shape = step_prepare = None
+    if is_rec:
+        fwd = lambda m, x_, y_, noise: m(x_, y_, is_rec=True, noise=noise)
+        if getattr(args, "masking_strategy", "random") == "random":
+            noise_shape = (x.shape[0], model.backbone.num_patches)
+            if getattr(model, "backbone_type", "") == "swin" and reducer is None:
+                step_prepare = model.backbone.enable_static_plan(x.device)
+            elif getattr(model, "backbone_type", "") == "swin":
+                return None            # data-parallel Swin: per-rank window plans, stepped eagerly (engine.GraphedStep)
+    else:
+        fwd = lambda m, x_, y_, noise: m(x_, y_)
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())      # follows torch.manual_seed like the eager draw would
+    ex = GraphedStep(model, optimizer, fwd, [x.clone(), y.clone()], noise_shape=noise_shape,
+                     generator=torch.Generator(device=x.device).manual_seed(seed), reducer=reducer, step_prepare=step_prepare,
+                     host_generator=torch.Generator().manual_seed(seed))
+    model._evp_auto_executor = (key, ex)
+    return ex
+
+
+def ops_dtype():
+    from ... import ops
+    return ops.get_compute_dtype()
+
+
+def _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, loss_name, forward, vis_hook, step_executor=None, auto=True):
     model.train(True)
     logger = misc.MetricLogger(delimiter="  ")
     logger.add_meter("lr", misc.SmoothedValue(window_size=1, fmt="{value:.6f}"))
@@ -18,17 +66,25 @@ def _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, l
         print("log_dir: {}".format(log_writer.log_dir))
     n_iter = len(data_loader)
     last = None
+    auto = auto and step_executor is None
     for it, batch in enumerate(logger.log_every(args, data_loader, args.print_freq, header)):
         if it % args.accum_iter == 0:
             adjust_learning_rate(optimizer, it / n_iter + epoch, args)
         events_voxel_grid = batch[0].to(args.device, non_blocking=True)
         supp = batch[1].to(args.device, non_blocking=True)
+        if step_executor is None and auto:
+            # the fast path is the default path: the loop captures its own step executor on the first batch (auto_step_executor)
+            step_executor = auto_step_executor(args, model, optimizer, loss_scaler, (events_voxel_grid, supp), loss_name, vis_hook)
+            auto = step_executor is not None
         if step_executor is not None:
             # HIP-graph replay of forward + backward + optimizer step (eventpretrain_amd/engine.py); the lr set above
             # reaches the graph through the optimizer's staged scalars
             if args.accum_iter != 1 or not args.backward:
                 raise ValueError("step_executor runs one optimizer step per batch (accum_iter=1, backward=True)")
-            loss = step_executor.step(events_voxel_grid, supp)
+            if tuple(events_voxel_grid.shape) == tuple(step_executor.inputs[0].shape) and tuple(supp.shape) == tuple(step_executor.inputs[1].shape):
+                loss = step_executor.step(events_voxel_grid, supp)
+            else:                          # the short last batch of an epoch: one eager step that leaves the graph usable
+                loss = step_executor.eager_step_with(events_voxel_grid, supp)
             logger.update(**{loss_name: loss.item()})
             step_now = True
         else:
@@ -62,9 +118,10 @@ def _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, l
 
 def pr_rec_one_epoch(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer=None, vis_hook=None,
                      step_executor=None):
-    """Masked-modeling epoch: model(events_voxel_grid, sub_frame, is_rec=True). `step_executor` (an
-    eventpretrain_amd.engine.GraphedStep built on this model / optimizer) replaces the eager forward / backward /
-    optimizer calls by a HIP-graph replay."""
+    """Masked-modeling epoch: model(events_voxel_grid, sub_frame, is_rec=True). The forward / backward / optimizer calls of a
+    batch run as one HIP-graph replay: the loop builds its executor on the first batch (auto_step_executor; opt out with
+    args.graph_step = False) or takes the `step_executor` (an eventpretrain_amd.engine.GraphedStep on this model / optimizer)
+    it is given."""
     return _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, "reconstruct_loss",
                  lambda x, y: model(x, y, is_rec=True), vis_hook, step_executor)
 
@@ -86,7 +143,8 @@ def pr_con_n_one_epoch(args, model, preprocess, clip_model, data_loader, optimiz
         with torch.no_grad():
             clip_emb = clip_model.encode_image(image).to(args.device, non_blocking=True).float()
         return model(x, clip_emb)
-    return _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, "contrastive_loss", forward, vis_hook)
+    # (the CLIP encoder runs inside this loop's forward: no captured step here)
+    return _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, "contrastive_loss", forward, vis_hook, auto=False)
 
 
 def pr_rec_and_con_one_epoch(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer=None, vis_hook=None):

@@ -117,14 +117,12 @@ typedef struct {
   void *aux; int64_t ldaux;            /* element type = c_dtype; batch strides = C's */
   const float *residual; int64_t ldres; /* batch strides = C's */
   int accumulate;
-  int tile;                             /* 0 auto (128x128, 96x128 when 128x128 would give 257..384 tiles, 64x64 for small outputs), 1 = 128x128, 2 = 64x64, 4 = 96x128, 6 = 256x256 ring (bf16, K % 64 == 0), 9 = G4 256x256 (bf16 TN, f32 C, K % 32 == 0), 12 = stream-K 128x128 */
+  int tile;                             /* 0 auto; 1 = 128x128, 2 = 64x64, 4 = 96x128 (LDS-staged 16x16x32 body, two workgroups per CU);
+                                         * 9 = G4 256x256 (bf16 TN, f32 C, K % 32 == 0); 20 / 21 / 22 = G4 forward / data-gradient bodies
+                                         * 256x256 / 256x128 / 128x256 (bf16 operands and C, A row-major, K % 32 == 0, K >= 96, N % 8 == 0,
+                                         * linear or activation epilogue, no residual). Auto sends wide outputs (N >= 1024, M >= 2048) to the
+                                         * G4 bodies, 257..384-tile outputs to 96x128, small outputs to 64x64, the rest to 128x128. */
   int splitk;                           /* 0 auto, n = cut K into n slices summed with f32 atomics (plain f32 C only) */
-  /* Optional stream-K workspace (bf16, transA = 0, no batch): device memory, >= 4096 + 65536 * 2 * CUs bytes, its first
-   * 4096 bytes zeroed ONCE by the caller (the kernel leaves them zero). Used by tile = 12 only (the stream-K form of the
-   * 128x128 kernel; an explicit variant -- it does not beat the data-parallel launch on this path's shapes).
-   * One workspace per stream: launches that share it must be ordered. */
-  void *sk_workspace;
-  int64_t sk_workspace_bytes;
 } evp_gemm_desc;
 int evp_gemm(const evp_gemm_desc *d, void *stream);
 /* Grouped weight-gradient GEMM: n problems C_g[M_g,N_g] (f32) = A_g^T . B_g, A_g stored [K_g][M_g] and B_g stored
@@ -135,25 +133,27 @@ int evp_gemm(const evp_gemm_desc *d, void *stream);
  * and `items` a device array of  struct { int prob, tile_m, tile_n, pad; }  listing every 128x128 output tile
  * (prob < 0 = padding entry, skipped: lets the caller lay the list out per XCD, workgroups i and i+8 share an L2). */
 int evp_gemm_grouped_tn_bf16(const void *problems, const void *items, int n_items, void *stream);
-/* Same problem table, but `items` lists 256x256 output tiles and every K_g must be a multiple of 64: the 8-wave
- * half-tile-ring kernel (one workgroup per CU), the faster form when K_g is long (K_g = batch x tokens here).
- * A non-NULL `colsum` (float32 [M_g]) also receives colsum[m] (+)= sum_k A_g[k][m] -- the bias gradient db = sum over
- * rows of dY of the same Linear -- computed from the A fragments already in registers (no second pass over dY). */
-int evp_gemm_grouped_tn256_bf16(const void *problems, const void *items, int n_items, void *stream);
-/* Same tables (256x256 items), every K_g a multiple of 32 and >= 96: the "G4" body -- 4 waves, one per SIMD, each holding
+/* Same problem table, but `items` lists 256x256 output tiles, every K_g a multiple of 32 and >= 96: the "G4" body -- 4 waves, one per SIMD, each holding
  * 128x128 of the tile in 256 accumulator registers (v_mfma_f32_32x32x16_bf16), 32-deep stages in a four-slot LDS-DMA ring,
  * one barrier per stage. The default for the step's weight gradients (dW = dY^T X of every nn.Linear on the path,
- * model/sub_module/vit_block.py:131-143,225-231). Items with prob < 0 are skipped (padding of per-XCD lists). */
+ * model/sub_module/vit_block.py:131-143,225-231). Items with prob < 0 are skipped (padding of per-XCD lists).
+ * A non-NULL `colsum` (float32 [M_g]) also receives colsum[m] (+)= sum_k A_g[k][m] -- the bias gradient db = sum over
+ * rows of dY of the same Linear -- computed from the A fragments already in registers (no second pass over dY). */
 int evp_gemm_grouped_tn_g4_bf16(const void *problems, const void *items, int n_items, void *stream);
 /* out[i] (+)= sum_s ws[s*numel + i], float32, numel % 4 == 0: reduction of split-K partials when a long-K problem was
  * entered into the grouped launch as several K-slice problems writing to a workspace (ConvViT stage 1: K = B*56*56). */
 int evp_sum_slices_f32(const float *ws, float *out, int n_slices, int64_t numel, int accumulate, void *stream);
-/* Tuning switch for A/B measurements: 1 = LDS-DMA (buffer_load ... lds) staging for bf16 (default), 2 = register
- * staging. Returns the previous value; any other argument only queries. Results are identical. */
+/* Tuning switches for A/B measurements (results are identical up to f32 summation order): 1 = LDS-DMA (buffer_load ... lds)
+ * staging for bf16 (default), 2 = register staging; 10 / 11 = wide forward / data-gradient GEMMs on 128x128 tiles / on the G4
+ * bodies (default). Returns the previous staging variant; any other argument only queries. */
 int evp_gemm_set_variant(int v);
-/* Measurement aid: device buffer uint64 [16 * grid] that the stream-K kernel (tile 12) fills per workgroup with cycle stamps of
- * its segments; NULL (default) switches it off. */
-int evp_gemm_set_debug_buffer(void *buf);
+/* Measurement aid: in-kernel wall-clock stamps. `buf` = device uint64 [n_slots][2 * 4096] (NULL switches stamping off and resets
+ * the slot counter): every following GEMM launch (evp_gemm, the grouped entries) takes the next slot (mod n_slots) and each of its
+ * workgroups b < 4096 writes s_memrealtime (100 MHz) to [2 b] when it starts and to [2 b + 1] after its last store was acknowledged.
+ * max(end) - min(start) of a slot = that launch's duration where it ran -- also inside a replayed HIP graph (bench.py `roofline`).
+ * evp_gemm_stamp_count() = launches stamped since the buffer was installed. */
+int evp_gemm_set_stamp_buffer(void *buf, long long n_slots);
+long long evp_gemm_stamp_count(void);
 
 /* ------------------------------------------------------------------------------------------------ K4/K9 LayerNorm
  * Replaces nn.LayerNorm over the last dim (vit_block.py:247,249; vit.py:126-128 with the 3-tap sum fused:
@@ -430,6 +430,21 @@ int evp_frame_augment_f32(const float *in, const int32_t *params, float *out, in
  * evp_cross_entropy. */
 int evp_token_mean_fwd(const float *x, int B, int N, int D, float *out, void *stream);
 int evp_token_mean_bwd(const float *g, int B, int N, int D, float *dx, void *stream);
+
+/* ------------------------------------------------------------------------------------------------ K24 stochastic depth / dropout
+ * The regularisers of the fine-tuning recipe (main_finetune_cls.py:151-153, drop_path_rate 0.1 by default).
+ * DropPath (timm 0.3.2 `drop_path`; model/sub_module/vit_block.py:241,252-253, conv_block.py:35,43-49, swin_block.py:257,270-271):
+ *   evp_rows_scale_f32: out[m,:] = (res ? res[m,:] : 0) + s_b * x[m,:] with b = m / rows_per_sample and
+ *   s_b = floor(keep_prob + u[b]) / keep_prob (u: float32 [M / rows_per_sample] uniform draws of the caller; u == NULL or
+ *   keep_prob >= 1: s_b = 1); out_lp (optional) receives s_b * x[m,:] in bf16. Forward: x + drop_path(branch); backward: the
+ *   branch's incoming gradient s_b * g. float32, D % 4 == 0; out or out_lp may be NULL.
+ * Dropout (nn.Dropout; vit_block.py:137-141,226-231, vit.py:114): evp_dropout_fwd draws keep ~ Bernoulli(1 - p) per element
+ *   from Philox4x32-10 keyed by (seed, offset + element / 4), writes out = x * keep / (1 - p) and mask (uint8, 1 = kept);
+ *   evp_dropout_apply: out = x * mask * scale (the backward, and the forward for a given mask). dtype = EVP_F32 | EVP_BF16. */
+int evp_rows_scale_f32(const float *x, const float *u, float keep_prob, const float *res, int64_t M, int D, int rows_per_sample,
+                       float *out, void *out_lp, void *stream);
+int evp_dropout_fwd(const void *x, int dtype, void *out, void *mask, int64_t n, float p, uint64_t seed, uint64_t offset, void *stream);
+int evp_dropout_apply(const void *x, int dtype, const void *mask, void *out, int64_t n, float scale, void *stream);
 
 #ifdef __cplusplus
 }

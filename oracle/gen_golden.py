@@ -14,7 +14,7 @@ module object supplying `to_2tuple`, `trunc_normal_` and a `DropPath` that is
 never executed (all drop rates are 0 -> nn.Identity, vit_block.py:241) is put
 in sys.modules for the duration of this script.
 
-Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin,swincon,augment,evaug,ftcls,density,autocast,conbase,swinbase]
+Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin,swincon,augment,evaug,ftcls,density,autocast,conbase,swinbase,convbase]
 """
 import argparse
 import json
@@ -327,6 +327,41 @@ def gen_convsmall():
     out["cfg"] = np.array(json.dumps(cfg))
     out["state_keys"] = np.array(json.dumps({k: list(v.shape) for k, v in hub.state_dict().items()}))
     save("rec_convsmall", **out)
+
+
+def gen_convbase():
+    """ConvViT-Base (BASELINE.json config 4 as bench.py times it): the reference's own `convvit_base_patch16` factory
+    (model/backbone/convvit.py:218-224) hand-composed with `pretrain_rec_decoder_base_patch16` (pr_rec_decoder.py:89-95) -- the hub
+    factory always builds the 384-wide small decoder (pr_hub_model.py:77), which cannot take a 768-wide backbone. Same contents as
+    rec_convsmall."""
+    _ref()
+    from model.backbone.convvit import convvit_base_patch16
+    from model.pretrain.pr_rec_decoder import pretrain_rec_decoder_base_patch16
+    cfg = dict(input=224, patch=16, dims=[256, 384, 768], depth=[2, 2, 11], heads=12, dec_dim=512, dec_depth=8, dec_heads=16,
+               mask_ratio=0.5, B=2)
+    a = make_args(model_size="base", pr_phase="rec", backbone_type="convvit")
+    bb = convvit_base_patch16(args=a, num_bins=5, mask_ratio=0.5, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.)
+    dec = pretrain_rec_decoder_base_patch16(frame_chans=1)
+
+    class Hub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone, self.pretrain_rec_decoder = bb, dec
+
+    hub = Hub()
+    det_fill_module_(hub)
+    hub.train(True)
+
+    def fwd(x, y):
+        emb_l1, emb_l2, emb_lh, mask, ids_restore = hub.backbone(x, mask=True)
+        pred = hub.pretrain_rec_decoder(emb_lh, ids_restore)
+        loss = _rec_loss_ref(a, 16, pred, y, mask)
+        return loss, emb_l1, emb_l2, emb_lh, pred, mask, ids_restore
+
+    out = _run_rec("convbase", cfg, fwd, list(hub.named_parameters()))
+    out["cfg"] = np.array(json.dumps(cfg))
+    out["state_keys"] = np.array(json.dumps({k: list(v.shape) for k, v in hub.state_dict().items()}))
+    save("rec_convbase", **out)
 
 
 def gen_swin():
@@ -827,7 +862,8 @@ def gen_swin_base():
 
 GENS = dict(voxel=gen_voxel, pos=gen_pos, mask=gen_mask, tiny=lambda: gen_composed("tiny"), small=gen_small,
             base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall, swin=gen_swin, swincon=gen_swincon, augment=gen_augment, evaug=gen_evaug, ftcls=gen_ftcls,
-            frameaug=gen_frameaug, density=gen_density, autocast=gen_autocast, conbase=gen_con_base, swinbase=gen_swin_base)
+            frameaug=gen_frameaug, density=gen_density, autocast=gen_autocast, conbase=gen_con_base, swinbase=gen_swin_base,
+            convbase=gen_convbase)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -83,13 +83,36 @@ def attention(sd, pre, x, heads):
     return F.linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"]), p
 
 
-def vit_block(sd, pre, x, heads, eps=1e-6, want_attn=False):
-    """vit_block.py:246-254 pre-LN residual block; Mlp = fc1, GELU(erf), fc2 (vit_block.py:225-231)."""
+def drop_path_scale(u, keep_prob):
+    """timm 0.3.2 `drop_path` (the DropPath the reference imports, vit_block.py:5,241): per SAMPLE, random_tensor = floor(keep_prob +
+    U[0,1)), output = x / keep_prob * random_tensor. timm is absent from /root/reference and from this image: published forward
+    restated; given the draws `u` the arithmetic is pinned, the random stream itself is not (parity unpinned)."""
+    return torch.floor(keep_prob + u) / keep_prob
+
+
+def vit_block(sd, pre, x, heads, eps=1e-6, want_attn=False, drops=None):
+    """vit_block.py:246-254 pre-LN residual block; Mlp = fc1, GELU(erf), fc2 (vit_block.py:225-231).
+    `drops` (training-mode regularisers, vit_block.py:137-141,226-231,252-253): dict(u1, u2, keep_prob) for the two DropPath
+    applications and optionally (p, proj, hidden, fc2) = dropout rate and 0/1 keep masks of the proj output, the MLP hidden
+    and the fc2 output."""
     a, p = attention(sd, pre + "attn.", layer_norm(x, sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], eps), heads)
-    x = x + a
+    s1 = s2 = 1.0
+    if drops is not None:
+        kp = drops.get("keep_prob", 1.0)
+        if drops.get("u1") is not None:
+            s1 = drop_path_scale(drops["u1"], kp).view(-1, 1, 1)
+            s2 = drop_path_scale(drops["u2"], kp).view(-1, 1, 1)
+        if drops.get("p"):
+            a = a * drops["proj"].view_as(a) / (1.0 - drops["p"])
+    x = x + s1 * a
     h = layer_norm(x, sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], eps)
     h = F.gelu(F.linear(h, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"]))
-    x = x + F.linear(h, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    if drops is not None and drops.get("p"):
+        h = h * drops["hidden"].view_as(h) / (1.0 - drops["p"])
+    m = F.linear(h, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    if drops is not None and drops.get("p"):
+        m = m * drops["fc2"].view_as(m) / (1.0 - drops["p"])
+    x = x + s2 * m
     return (x, p) if want_attn else x
 
 

@@ -44,5 +44,12 @@ def _restore_global_switches(request):
         ops.set_compute_dtype(torch.float32)
         ops.set_window_mfma(True)
         ops.set_fused_attention(True)
+        ops.set_grad_side(True)
+        ops.set_wgrad_g4(True)
+        ops.set_wgrad_xcd_order(True)
+        ops.set_deferred_grads(True)
+        from eventpretrain_amd._lib import call
+        call("evp_gemm_set_variant", 1)
+        call("evp_gemm_set_variant", 11)
     except Exception:
         pass

@@ -92,6 +92,8 @@ def _queue_policies(rank):
             torch.manual_seed(7)                                   # same initial queue on both ranks
             m = hub.pretrain_hub_model_tiny_patch16_64(a, emb_frames_dim=512, queue_length=8, T=0.07)
             assert m.queue_policy() == pol
+            # the step executor keeps collectives out of captured graphs: it must know which forwards hold one
+            assert m.forward_has_collective() == (pol != "local")
             q0 = m.queue.clone()
             keys = torch.full((2, 16, 192), float(rank + 1)) + torch.arange(2).view(2, 1, 1)      # rank r, sample i -> r + 1 + i
             if pol == "rank0_broadcast":
@@ -100,6 +102,18 @@ def _queue_policies(rank):
                 assert torch.equal(m.queue, q0), "buffers not taken from rank 0"
             m._dequeue_and_enqueue(keys)
             out[pol] = (int(m.queue_ptr), m.queue[0, 0, :].tolist())
+        # a per-step launch-geometry hook (Swin window plan) together with a reducer is refused: one rank falling back to an
+        # eager step while the others replay would leave the all-reduces unmatched
+        from eventpretrain_amd.engine import GraphedStep
+        from eventpretrain_amd.parallel import BucketedGradReducer
+        lin = torch.nn.Linear(4, 4)
+        red = BucketedGradReducer(list(lin.parameters()))
+        try:
+            GraphedStep(lin, None, lambda m_, x_, n_: (m_(x_).sum(),), [torch.zeros(2, 4)], noise_shape=(2, 4), reducer=red, use_graph=False,
+                        step_prepare=lambda noise: True)
+            out["prepare_with_reducer_refused"] = False
+        except ValueError:
+            out["prepare_with_reducer_refused"] = True
     finally:
         ops.enqueue_keys_dev = real
     return {"queue_" + k: v for k, v in out.items()}
@@ -229,6 +243,7 @@ def test_world_size_2_gloo():
         ptr_, row = res[r]["queue_rank0_broadcast"]
         assert ptr_ == 2 and row[:2] == [1.0 + r, 2.0 + r]          # own keys on rank 0's (broadcast) queue
     assert res[0]["queue_all_gather"] == res[1]["queue_all_gather"]
+    assert res[0]["queue_prepare_with_reducer_refused"] and res[1]["queue_prepare_with_reducer_refused"]
     # overlapped plan without streams: chunks in order, flats summed over ranks ((1+2)*(i+1)), small gradients through the bucket
     for r in (0, 1):
         assert res[r]["plan_log"] == [0, 1]

@@ -184,10 +184,10 @@ def test_argument_errors_raise():
         ops.gemm(a.cpu(), a.cpu(), torch.zeros(8, 8), M=8, N=8, K=12)              # no CPU path
 
 
-@pytest.mark.parametrize("entry", ["evp_gemm_grouped_tn256_bf16", "evp_gemm_grouped_tn_g4_bf16"])
+@pytest.mark.parametrize("entry", ["evp_gemm_grouped_tn_g4_bf16"])
 def test_grouped_tn256_with_fused_column_sums_exact(entry):
-    """evp_gemm_grouped_tn256_bf16 / evp_gemm_grouped_tn_g4_bf16 (8-wave ring and G4 one-wave-per-SIMD bodies, same
-    tables): several dW = dY^T X problems in one launch of a 256x256-tile kernel, with the bias
+    """evp_gemm_grouped_tn_g4_bf16 (the G4 one-wave-per-SIMD body): several dW = dY^T X problems in one launch of a
+    256x256-tile kernel, with the bias
     gradient (column sums of dY) produced by the same kernel; small-integer data, so every result is exact. Covers ragged
     M / N (not multiples of 256), accumulate into an existing dW / db, and a problem without column sums."""
     import numpy as np
@@ -249,40 +249,104 @@ def test_g4_tn_tile_exact_and_random():
 
 
 @pytest.mark.parametrize("tb", [False, True])
-def test_stream_k_variant_matches_data_parallel(tb):
-    """evp_gemm tile 12 (stream-K form of the 128x128 bf16 kernel: partial tiles handed over through the caller's
-    workspace): exact on small-integer operands, equal to the data-parallel result to f32 rounding with every epilogue,
-    identical run to run, flag page left clean (so a replayed HIP graph can reuse it), refused when it cannot apply."""
+@pytest.mark.parametrize("tile", [20, 21, 22])
+def test_g4_forward_dgrad_tiles_exact_on_integers(tb, tile):
+    """evp_gemm tiles 20 / 21 / 22 (G4 bodies for forward = NT and data gradient = NN: 256x256, 256x128, 128x256; bf16 C parked
+    in LDS and written as whole rows): exact on small-integer operands, ragged M (not a multiple of the tile) and ragged N
+    (multiple of 8 only), K from the minimum (96) up, untouched columns beyond N, and a run-to-run identical result."""
+    from eventpretrain_amd import ops
+    gen = torch.Generator().manual_seed(41 + tile)
+    for (M, N, K) in [(256, 256, 96), (520, 264, 160), (1000, 1032, 768), (6272, 2304, 768), (300, 8, 128)]:
+        a, b, al, bl = _mk(M, N, K, False, tb, torch.bfloat16, gen, ints=True)
+        ldc = N + 8
+        out = torch.full((M, ldc), 7.0, dtype=torch.bfloat16, device="cuda")
+        kw = dict(M=M, N=N, K=K, trans_b=tb, ldb=(N if tb else K), ldc=ldc, tile=tile)
+        ops.gemm(a.cuda(), b.cuda(), out, **kw)
+        ref = (al @ bl.t()).float().to(torch.bfloat16).double()      # integer sums are exact in the f32 accumulator: one rounding, to bf16
+        assert torch.equal(out[:, :N].cpu().double(), ref), (M, N, K, (out[:, :N].cpu().double() - ref).abs().max())
+        assert (out[:, N:].float() == 7.0).all(), "wrote outside N"
+        out2 = torch.full((M, ldc), 7.0, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(a.cuda(), b.cuda(), out2, **kw)
+        assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("tile", [20, 21, 22])
+def test_g4_epilogues_match_the_128_tile_kernel(tile):
+    """Bias, GELU + pre-activation store (forward layout) and GELU' (data-gradient layout) of the G4 bodies on random data:
+    against float64, and against the 128x128 kernel (same operand rounding, same polynomial GELU: equal up to the f32
+    summation order inside the MFMA chain, i.e. at most one bf16 ulp of the output)."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd._lib import ACT_DGELU, ACT_GELU, ACT_RELU, ACT_DRELU
+    gen = torch.Generator().manual_seed(50 + tile)
+    M, N, K = 1544, 1032, 416
+
+    def ulp_close(x, y):                       # bf16 outputs: within 2 ulp of each other
+        x, y = x.float(), y.float()
+        return bool(((x - y).abs() <= 2.0 ** -7 * torch.maximum(x.abs(), y.abs()) + 1e-6).all())
+
+    a, b, al, bl = _mk(M, N, K, False, False, torch.bfloat16, gen)
+    b = (b * 0.1)
+    bl = b.float().double()
+    bias = torch.randn(N, generator=gen)
+    base = 0.5 * (al @ bl.t()) + bias.double()
+    outs = {}
+    for t in (1, tile):
+        c = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(a.cuda(), b.cuda(), c, M=M, N=N, K=K, alpha=0.5, bias=bias.cuda(), tile=t)
+        h = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        x = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(a.cuda(), b.cuda(), h, M=M, N=N, K=K, alpha=0.5, bias=bias.cuda(), act=ACT_GELU, aux=x, tile=t)
+        r = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(a.cuda(), b.cuda(), r, M=M, N=N, K=K, alpha=0.5, bias=bias.cuda(), act=ACT_RELU, tile=t)
+        outs[t] = (c, h, x, r)
+    for got, ref in zip(outs[tile], (base, torch.nn.functional.gelu(base), base, torch.relu(base))):
+        assert ((got.cpu().double() - ref).abs() / (ref.abs() + 1.0)).max().item() <= 2e-2
+    for g_, o_ in zip(outs[tile], outs[1]):
+        assert ulp_close(g_, o_)
+    # data-gradient layout with GELU' / ReLU' of a stored pre-activation
+    bt = b.t().contiguous()
+    hpre = torch.randn(M, N, generator=gen).to(torch.bfloat16)
+    hd = hpre.float().double().requires_grad_(True)
+    torch.nn.functional.gelu(hd).sum().backward()
+    res = {}
+    for t in (1, tile):
+        o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(a.cuda(), bt.cuda(), o, M=M, N=N, K=K, trans_b=True, ldb=N, act=ACT_DGELU, aux=hpre.cuda(), tile=t)
+        o2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(a.cuda(), bt.cuda(), o2, M=M, N=N, K=K, trans_b=True, ldb=N, act=ACT_DRELU, aux=hpre.cuda(), tile=t)
+        res[t] = (o, o2)
+    ref = (al @ bl.t()) * hd.grad
+    assert ((res[tile][0].cpu().double() - ref).abs() / (ref.abs() + 1.0)).max().item() <= 2e-2
+    assert ulp_close(res[tile][0], res[1][0]) and ulp_close(res[tile][1], res[1][1])
+
+
+def test_g4_forward_tiles_refuse_what_they_do_not_take():
     from eventpretrain_amd import EvpError, ops
-    from eventpretrain_amd._lib import ACT_GELU
-    gen = torch.Generator().manual_seed(31)
-    for (M, N, K) in [(6272, 768, 3072), (2000, 520, 2048), (12544, 512, 512)]:
-        a, b, a_log, b_log = _mk(M, N, K, False, tb, torch.bfloat16, gen, ints=True)
-        a, b = a.cuda(), b.cuda()
-        out = torch.empty(M, N, dtype=torch.float32, device="cuda")
-        kw = dict(M=M, N=N, K=K, trans_b=tb, ldb=(N if tb else K))
-        ops.gemm(a, b, out, tile=12, **kw)
-        assert torch.equal(out.cpu().double(), a_log @ b_log.t()), (M, N, K)
-        # random data + bias + residual / GELU + aux, against the data-parallel kernel
+    a = torch.zeros(256, 128, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(EvpError):          # f32 C
+        ops.gemm(a, a, torch.empty(256, 256, device="cuda"), M=256, N=256, K=128, tile=20)
+    with pytest.raises(EvpError):          # K not a multiple of 32
+        ops.gemm(a, a, torch.empty(256, 256, dtype=torch.bfloat16, device="cuda"), M=256, N=256, K=72, lda=128, ldb=128, tile=21)
+    with pytest.raises(EvpError):          # removed variants say so
+        ops.gemm(a, a, torch.empty(256, 256, device="cuda"), M=256, N=256, K=128, tile=12)
+
+
+def test_wide_outputs_take_the_g4_bodies_by_default():
+    """The automatic tile choice sends one-round wide forward GEMMs (256x256 tiles) and wide data gradients (128x256) to the G4
+    bodies: same result as forcing tile 20 / 22, and evp_gemm_set_variant(10) switches the routing off (A/B aid)."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd._lib import call
+    gen = torch.Generator().manual_seed(77)
+    for (M, N, K, tb, forced) in [(2304, 1024, 256, False, 20), (12544, 1536, 128, True, 22)]:
         a, b, _, _ = _mk(M, N, K, False, tb, torch.bfloat16, gen)
-        a, b = a.cuda(), (b * 0.05).cuda()
-        bias = torch.randn(N, generator=gen).cuda()
-        res = torch.randn(M, N, generator=gen).cuda()
-        o1, o2, o3 = (torch.empty(M, N, dtype=torch.float32, device="cuda") for _ in range(3))
-        ops.gemm(a, b, o1, tile=1, bias=bias, residual=res, **kw)
-        ops.gemm(a, b, o2, tile=12, bias=bias, residual=res, **kw)
-        ops.gemm(a, b, o3, tile=12, bias=bias, residual=res, **kw)
-        assert torch.equal(o2, o3)
-        assert (o1 - o2).abs().max().item() <= 2e-5 * max(1.0, o1.abs().max().item())
-        if not tb:
-            h1, h2 = (torch.empty(M, N, dtype=torch.bfloat16, device="cuda") for _ in range(2))
-            x1, x2 = (torch.empty(M, N, dtype=torch.bfloat16, device="cuda") for _ in range(2))
-            ops.gemm(a, b, h1, tile=1, bias=bias, act=ACT_GELU, aux=x1, **kw)
-            ops.gemm(a, b, h2, tile=12, bias=bias, act=ACT_GELU, aux=x2, **kw)
-            assert (h1.float() - h2.float()).abs().max().item() <= 1e-2 * max(1.0, h1.float().abs().max().item())
-            assert (x1.float() - x2.float()).abs().max().item() <= 1e-2 * max(1.0, x1.float().abs().max().item())
-    flags = next(iter(ops._sk_ws.values()))[:4096].view(torch.int32)
-    assert int((flags != 0).sum()) == 0
-    small = torch.zeros(128, 64, dtype=torch.bfloat16, device="cuda")
-    with pytest.raises(EvpError):
-        ops.gemm(small, small, torch.empty(128, 128, device="cuda"), M=128, N=128, K=64, tile=12)
+        c0, c1, c2 = (torch.empty(M, N, dtype=torch.bfloat16, device="cuda") for _ in range(3))
+        kw = dict(M=M, N=N, K=K, trans_b=tb, ldb=(N if tb else K))
+        ops.gemm(a.cuda(), b.cuda(), c0, **kw)
+        ops.gemm(a.cuda(), b.cuda(), c1, tile=forced, **kw)
+        assert torch.equal(c0, c1)
+        call("evp_gemm_set_variant", 10)
+        try:
+            ops.gemm(a.cuda(), b.cuda(), c2, **kw)
+        finally:
+            call("evp_gemm_set_variant", 11)
+        assert (c0.float() - c2.float()).abs().max().item() <= 2.0 ** -7 * c0.float().abs().max().item()

@@ -1,0 +1,347 @@
+"""Round-3 additions on the GPU: stochastic depth / dropout of the fine-tuning recipe, checked against the
+CPU oracle for GIVEN draws and masks; the fine-tune step with the reference's default drop_path_rate."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import assert_checksums, jl, rec_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _block(dim=64, heads=4, drop=0.0, drop_path=0.0):
+    from eventpretrain_amd.model.sub_module.vit_block import ViTBlock
+    from eventpretrain_amd.testing import det_fill_module_
+    blk = ViTBlock(dim=dim, num_heads=heads, mlp_ratio=4., qkv_bias=True, drop=drop, drop_path=drop_path)
+    det_fill_module_(blk)
+    return blk.cuda().train()
+
+
+def _oracle_block(blk, x, drops):
+    from oracle import model_oracle as mo
+    sd = {"b." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    xo = x.detach().cpu().clone().requires_grad_(True)
+    y = mo.vit_block(sd, "b.", xo, blk.attn.num_heads, eps=blk.norm1.eps, drops=drops)
+    return sd, xo, y
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.25])
+def test_vit_block_drop_path_and_dropout_match_oracle_for_given_draws(p_drop):
+    """x + drop_path(proj_drop(attn(LN x))) and x + drop_path(drop(fc2(drop(GELU(fc1(LN x)))))) with explicit per-sample draws
+    (one sample dropped in each branch, one kept in both) and explicit element masks: output and every gradient equal the oracle's
+    (f32 mode). The timm DropPath formula is restated there; the random stream is not pinned, the arithmetic is."""
+    from eventpretrain_amd import ops
+    ops.set_compute_dtype(torch.float32)
+    B, N, D = 4, 24, 64
+    blk = _block(D, 4, drop=p_drop, drop_path=0.3)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, N, D, generator=g).cuda().requires_grad_(True)
+    u1 = torch.tensor([0.05, 0.9, 0.5, 0.2])         # keep_prob 0.7: floor(0.7 + u) -> 0, 1, 1, 0
+    u2 = torch.tensor([0.95, 0.1, 0.31, 0.6])        #                              -> 1, 0, 1, 1
+    masks = None
+    if p_drop:
+        masks = {k: (torch.rand(B * N * w, generator=g) >= p_drop).to(torch.uint8) for k, w in (("proj", D), ("hidden", 4 * D), ("fc2", D))}
+    rd = ops.BlockDrop(u1.cuda(), u2.cuda(), keep_prob=0.7, drop=p_drop, seed=1,
+                       masks=None if masks is None else {k: v.cuda() for k, v in masks.items()})
+    y = blk(x, block_drop=rd)
+    w = torch.randn(B, N, D, generator=g)
+    (y * w.cuda()).sum().backward()
+    drops = dict(u1=u1, u2=u2, keep_prob=0.7)
+    if p_drop:
+        drops.update(p=p_drop, proj=masks["proj"].float(), hidden=masks["hidden"].float(), fc2=masks["fc2"].float())
+    sd, xo, yo = _oracle_block(blk, x, drops)
+    (yo * w).sum().backward()
+    assert torch.allclose(y.detach().cpu(), yo.detach(), atol=2e-5, rtol=1e-4)
+    assert torch.allclose(x.grad.cpu(), xo.grad, atol=2e-5 * xo.grad.abs().max().item() + 1e-6, rtol=1e-3)
+    for k, v in blk.named_parameters():
+        ref = sd["b." + k].grad
+        assert torch.allclose(v.grad.cpu(), ref, atol=3e-5 * ref.abs().max().item() + 1e-6, rtol=2e-3), k
+    # a sample dropped in BOTH branches of a block would pass through unchanged; here sample 0 loses the attention branch only:
+    # its output differs from the input by the MLP branch alone
+    assert not torch.allclose(y[0].detach(), x[0].detach())
+
+
+def test_drop_path_statistics_and_eval_mode():
+    """Training mode draws per-sample masks with P(keep) = 1 - rate and rescales kept samples by 1 / keep_prob; eval mode is the
+    deterministic fused block. bf16 mode (the throughput path) takes the same code."""
+    from eventpretrain_amd import ops
+    ops.set_compute_dtype(torch.bfloat16)
+    B, N, D = 256, 8, 64
+    blk = _block(D, 4, drop_path=0.5)
+    torch.manual_seed(3)
+    x = torch.randn(B, N, D, device="cuda")
+    blk.eval()
+    y_eval = blk(x)
+    assert torch.equal(y_eval, blk(x))
+    blk.train()
+    y = blk(x)
+    # samples whose BOTH branches were dropped come back bit-identical to the input: expected fraction 0.25
+    same = (y == x).flatten(1).all(1).float().mean().item()
+    assert 0.12 < same < 0.40, same
+    rd = ops.BlockDrop(torch.full((B,), 0.99, device="cuda"), torch.full((B,), 0.99, device="cuda"), keep_prob=0.999)
+    y_keep = blk(x, block_drop=rd)               # everything kept, scale 1/0.999: close to the eval result
+    assert (y_keep - y_eval).abs().max().item() <= 2e-2 * y_eval.abs().max().item()
+
+
+def test_dropout_kernel_mask_rate_and_backward():
+    from eventpretrain_amd import ops
+    ops.set_compute_dtype(torch.float32)
+    x = torch.randn(64, 1000, device="cuda", requires_grad=True)
+    y = ops.DropoutFn.apply(x, 0.3, 1234)
+    kept = (y != 0).float().mean().item()
+    assert abs(kept - 0.7) < 0.01, kept
+    nz = y != 0
+    assert torch.allclose(y[nz], x.detach()[nz] / 0.7, rtol=1e-6, atol=0)
+    y.sum().backward()
+    assert torch.equal(x.grad != 0, nz) and torch.allclose(x.grad[nz], torch.full_like(x.grad[nz], 1 / 0.7))
+    y2 = ops.DropoutFn.apply(x, 0.3, 1234)
+    assert torch.equal(y, y2)                    # same (seed, offset) -> same mask
+    assert not torch.equal(y, ops.DropoutFn.apply(x, 0.3, 1235))
+
+
+@pytest.mark.parametrize("bt", ["vit", "convvit", "swin"])
+def test_finetune_step_runs_with_the_reference_default_drop_path(bt):
+    """main_finetune_cls.py:151-153 defaults: drop_rate 0, attn_drop_rate 0, drop_path_rate 0.1 -- the recipe that used to raise.
+    One bf16 training step per backbone: finite loss and gradients, eval-mode forward deterministic, attn_drop still refused."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.model.finetune_cls import ft_cls_hub_model as ft
+    from eventpretrain_amd.testing import make_args
+    size = {"vit": "small", "convvit": "small", "swin": "tiny"}[bt]
+    a = make_args(phase="finetune_cls", model_size=size, backbone_type=bt, num_classes=10, mask_ratio=0.0, device="cuda",
+                  dataset_type="n-caltech101", clip_grad=None, smoothing=0, drop_path_rate=0.1, drop_rate=0.05)
+    fac = {"vit": "finetune_cls_hub_model_small_patch16", "convvit": "finetune_cls_hub_model_small_patch16", "swin": "finetune_cls_hub_model_swin_tiny_window7"}[bt]
+    torch.manual_seed(0)
+    m = getattr(ft, fac)(a).cuda().train()
+    rates = [b.drop_path_rate for b in m.modules() if hasattr(b, "drop_path_rate")]
+    assert rates and rates[0] == 0.0 and abs(max(rates) - 0.1) < 1e-6 and rates == sorted(rates)      # linspace(0, rate, depth)
+    ops.set_compute_dtype(torch.bfloat16)
+    x = torch.randn(4, 5, 224, 224, device="cuda") * 0.5
+    label = torch.tensor([1, 3, 5, 7], device="cuda")
+    out = m(x)
+    loss = ops.CrossEntropyFn.apply(out[-2], label)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert math.isfinite(loss.item())
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m.parameters())
+    m.eval()
+    with torch.no_grad():
+        p1, p2 = m(x)[-2], m(x)[-2]
+    assert torch.equal(p1, p2)
+    a.attn_drop_rate = 0.1
+    with pytest.raises(NotImplementedError):
+        getattr(ft, fac)(a)
+
+
+def test_voxel_batch_with_many_empty_clips():
+    """the verified mode keeps one int32 flag per clip behind the cut table; with n_clips >> n_total (64 clips, 5 events
+    in all, most clips empty) the flags used to run past the end of the workspace the wrapper allocated."""
+    from eventpretrain_amd.dataset.dataset_utils.events_to_voxel_grid import voxel_grid_batch
+    from oracle.voxel_oracle import voxel_grid
+    rng = np.random.default_rng(0)
+    n_clips = 64
+    counts = np.zeros(n_clips, dtype=np.int64)
+    counts[[3, 17, 17, 40, 63]] += 1               # clip 17 gets two events
+    evs, off = [], [0]
+    for c in counts:
+        e = np.stack([rng.integers(0, 32, c).astype(np.float64), rng.integers(0, 32, c).astype(np.float64),
+                      np.sort(rng.uniform(0, 0.05, c)), rng.integers(0, 2, c).astype(np.float64)], 1).reshape(c, 4)
+        evs.append(e)
+        off.append(off[-1] + c)
+    ev = torch.from_numpy(np.concatenate(evs, 0)).cuda()
+    out = voxel_grid_batch(ev, torch.tensor(off, dtype=torch.int64, device="cuda"), 5, (32, 32))
+    torch.cuda.synchronize()
+    for i in range(n_clips):
+        ref = voxel_grid(evs[i], 5, (32, 32)) if counts[i] else np.zeros((5, 32, 32), np.float32)
+        assert np.abs(out[i].cpu().numpy() - ref).max() <= 1e-6, i
+    empty = voxel_grid_batch(torch.zeros(0, 4, dtype=torch.float64, device="cuda"), torch.zeros(9, dtype=torch.int64, device="cuda"), 5, (32, 32))
+    assert float(empty.abs().max()) == 0.0
+
+
+def test_gradient_path_switches_agree():
+    """the A/B switches of the backward path (gradient side information from the LayerNorm backward, G4 grouped weight
+    gradients, XCD-aware item order, deferred grouped gradients, G4 forward routing) change HOW a gradient is computed, never what:
+    every parameter gradient of a bf16 ViT-Small step agrees with the default configuration."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd._lib import call
+    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
+    from eventpretrain_amd.testing import det_fill_module_, make_args
+    a = make_args(model_size="small", pr_phase="rec", device="cuda")
+    m = hub.pretrain_hub_model_small_patch16(a, emb_frames_dim=512, queue_length=8, T=0.07)
+    det_fill_module_(m)
+    m = m.cuda().train()
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(8, 5, 224, 224, generator=g) * 0.5).cuda()
+    y = torch.randn(8, 1, 224, 224, generator=g).cuda()
+    noise = torch.rand(8, 196, generator=g).cuda()
+
+    def grads():
+        ops.set_compute_dtype(torch.bfloat16)
+        for p in m.parameters():
+            p.grad = None
+        loss = m(x, y, is_rec=True, noise=noise)[0]
+        loss.backward()
+        ops.flush_deferred_grads()
+        torch.cuda.synchronize()
+        return loss.item(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    base_loss, base = grads()
+    variants = {"no_side": lambda: ops.set_grad_side(False), "no_g4_wgrad": lambda: ops.set_wgrad_g4(False),
+                "no_xcd_order": lambda: ops.set_wgrad_xcd_order(False), "no_deferred": lambda: ops.set_deferred_grads(False),
+                "no_g4_fwd": lambda: call("evp_gemm_set_variant", 10)}
+    for name, switch in variants.items():
+        switch()
+        try:
+            loss, got = grads()
+        finally:
+            ops.set_grad_side(True); ops.set_wgrad_g4(True); ops.set_wgrad_xcd_order(True); ops.set_deferred_grads(True)
+            call("evp_gemm_set_variant", 11)
+        assert abs(loss - base_loss) <= 2e-3 * abs(base_loss), (name, loss, base_loss)
+        assert got.keys() == base.keys(), name
+        for k in base:
+            ref = base[k].float()
+            err = (got[k].float() - ref).abs().max().item()
+            assert err <= 2e-2 * ref.abs().max().item() + 1e-7, (name, k, err, ref.abs().max().item())
+
+
+def _convbase_hub():
+    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
+    from eventpretrain_amd.testing import det_fill_module_, make_args
+    a = make_args(model_size="base", pr_phase="rec", backbone_type="convvit", device="cuda")
+    m = hub.pretrain_hub_model_base_patch16(a, emb_frames_dim=512, queue_length=1024, T=0.07)
+    det_fill_module_(m)
+    return a, m.cuda().train()
+
+
+def test_convvit_base_rec_step_f32_matches_reference():
+    """BASELINE config 4 at the size the bench line quotes (ConvViT-Base + base decoder), f32 mode, against the fixture made from
+    the reference's convvit_base_patch16 + pretrain_rec_decoder_base_patch16: ids bit-exact, loss <= 1e-4 rel, taps, gradient norms."""
+    from eventpretrain_amd import ops
+    d = load_golden("rec_convbase")
+    a, m = _convbase_hub()
+    got_keys = {k: list(v.shape) for k, v in m.state_dict().items() if k.startswith(("backbone.", "pretrain_rec_decoder."))}
+    assert got_keys == jl(d["state_keys"])
+    x, y, noise = rec_inputs("convbase", dict(B=2, input=224, patch=16))
+    ops.set_compute_dtype(torch.float32)
+    loss, l1, l2, lh, pred, mask, restore = m(x.cuda(), y.cuda(), is_rec=True, noise=noise.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert np.array_equal(mask.cpu().numpy(), d["mask"]) and np.array_equal(restore.cpu().numpy(), d["ids_restore"])
+    rel = abs(loss.item() - float(d["loss"])) / abs(float(d["loss"]))
+    assert rel <= 1e-4, rel
+    assert tuple(l1.shape) == (2, 256, 56, 56) and tuple(l2.shape) == (2, 384, 28, 28)
+    assert_checksums(l1.contiguous(), d["emb_l1_checksums"], 1e-4)
+    assert_checksums(l2.contiguous(), d["emb_l2_checksums"], 1e-4)
+    assert_checksums(lh, d["emb_lh_checksums"], 1e-4)
+    assert_checksums(pred, d["pred_checksums"], 1e-4)
+    params = dict(m.named_parameters())
+    worst = 0.0
+    for n, gn in zip(jl(d["grad_names"]), d["grad_norms"]):
+        assert params[n].grad is not None, n
+        e = abs(params[n].grad.double().norm().item() - gn) / (gn + 1e-9)
+        worst = max(worst, e)
+        assert e <= 3e-3, (n, e)
+    print(f"[convvit-base] f32 loss rel err {rel:.2e}, worst grad-norm rel err {worst:.2e}")
+
+
+def test_convvit_base_rec_step_bf16_reported():
+    from eventpretrain_amd import ops
+    d = load_golden("rec_convbase")
+    a, m = _convbase_hub()
+    x, y, noise = rec_inputs("convbase", dict(B=2, input=224, patch=16))
+    ops.set_compute_dtype(torch.bfloat16)
+    out = m(x.cuda(), y.cuda(), is_rec=True, noise=noise.cuda())
+    out[0].backward()
+    torch.cuda.synchronize()
+    assert np.array_equal(out[5].cpu().numpy(), d["mask"])
+    rel = abs(out[0].item() - float(d["loss"])) / abs(float(d["loss"]))
+    print(f"[convvit-base] bf16 loss rel err vs the reference's f32 loss {rel:.2e}")
+    assert rel <= 2e-2
+    tot = math.sqrt(sum(p.grad.double().pow(2).sum().item() for p in m.parameters() if p.grad is not None))
+    assert abs(tot - float(d["total_grad_norm"])) / float(d["total_grad_norm"]) <= 5e-2
+
+
+def test_default_epoch_loop_is_the_graphed_fast_path_and_follows_the_reference_trajectory():
+    """pr_rec_one_epoch with nothing but the reference's arguments captures its own step executor on the first
+    batch. (a) On the tiny model with the fixture's noise sequence fed to the executor, the 5 steps reproduce the losses, the LR
+    and the final parameters of the reference's own trainer + torch.optim.AdamW (tests/golden/train_tiny.npz) -- after the capture
+    warm-up, i.e. the executor's snapshot / restore is part of what is tested. (b) Per-step wall time of the default loop is
+    within 10 % (+ the loop's own .item() sync) of calling GraphedStep.step() directly, far from the eager loop."""
+    import time
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
+    from eventpretrain_amd.optim import FusedAdamW
+    from eventpretrain_amd.testing import det_fill_module_, det_normalish, make_args
+    from eventpretrain_amd.trainer.pretrain import pr_trainer
+    from eventpretrain_amd.utils import lr_decay as lrd
+    from eventpretrain_amd.utils.misc import NativeScalerWithGradNormCount
+    from helpers import checksums
+    d = load_golden("train_tiny")
+    ops.set_compute_dtype(torch.float32)
+    a = make_args(model_size="tiny", pr_phase="rec", patch_size=16, device="cuda", input_size=64)
+    a.batch_size, a.epochs, a.warmup_epochs, a.accum_iter = 2, int(d["epochs"]), int(d["warmup_epochs"]), 1
+    a.lr, a.min_lr = float(d["lr"]), float(d["min_lr"])
+    m = hub.pretrain_hub_model_tiny_patch16_64(a, emb_frames_dim=512, queue_length=8, T=0.07)
+    det_fill_module_(m)
+    m = m.cuda().train()
+    opt = FusedAdamW(lrd.param_groups_lrd(a, m, a.weight_decay, layer_decay=1), lr=a.lr, betas=(0.9, 0.95))
+    n = len(d["losses"])
+    batches = [dict(events_voxel_grid=det_normalish(f"train.voxels.{s}", (2, 5, 64, 64)) * 0.5,
+                    sub_frame=det_normalish(f"train.sub_frame.{s}", (2, 1, 64, 64)), image_name=[f"s{s}"] * 2) for s in range(n)]
+    scaler = NativeScalerWithGradNormCount()
+    x0, y0 = batches[0]["events_voxel_grid"].cuda(), batches[0]["sub_frame"].cuda()
+    ex = pr_trainer.auto_step_executor(a, m, opt, scaler, (x0, y0), "reconstruct_loss")
+    assert ex is not None and ex.note == "hip-graph", getattr(ex, "note", None)
+    ex.noise_feed = iter(torch.from_numpy(d["noise"]))
+    losses = []
+    real_item = torch.Tensor.item
+    stats = pr_trainer.pr_rec_one_epoch(a, m, batches, opt, 0, scaler)        # finds the executor it would have built itself
+    assert m._evp_auto_executor[1] is ex and ex.eager_fallbacks == 0
+    ref_stats = jl(d["stats"])
+    assert stats["lr"] == pytest.approx(ref_stats["lr"], rel=1e-9)
+    assert stats["reconstruct_loss"] == pytest.approx(ref_stats["reconstruct_loss"], rel=2e-4)
+    params = dict(m.named_parameters())
+    for name, ws in zip(jl(d["param_names"]), d["param_wsums"]):
+        tol = 5e-4 if name.endswith("attn.qkv.bias") else 2e-5
+        assert checksums(params[name])[2] == pytest.approx(ws, rel=2e-4, abs=tol), name
+
+    # (b) timing on a model large enough for the launch overhead to matter: ViT-Small, B = 16, bf16
+    ops.set_compute_dtype(torch.bfloat16)
+    a2 = make_args(model_size="small", pr_phase="rec", device="cuda")
+    a2.batch_size, a2.epochs, a2.warmup_epochs, a2.accum_iter, a2.lr, a2.min_lr = 16, 4, 1, 1, 1e-4, 1e-6
+    a2.print_freq = 1000
+    torch.manual_seed(0)
+    m2 = hub.pretrain_hub_model_small_patch16(a2, emb_frames_dim=512, queue_length=8, T=0.07).cuda().train()
+    opt2 = FusedAdamW(lrd.param_groups_lrd(a2, m2, a2.weight_decay, layer_decay=1), lr=a2.lr, betas=(0.9, 0.95))
+    xs, ys = torch.randn(16, 5, 224, 224) * 0.5, torch.randn(16, 1, 224, 224)
+    loader = [dict(events_voxel_grid=xs, sub_frame=ys, image_name=["i"] * 16)] * 12
+    pr_trainer.pr_rec_one_epoch(a2, m2, loader[:2], opt2, 0, scaler)       # builds and caches the executor
+    ex2 = m2._evp_auto_executor[1]
+    assert ex2.note == "hip-graph"
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pr_trainer.pr_rec_one_epoch(a2, m2, loader, opt2, 1, scaler)
+    torch.cuda.synchronize()
+    t_loop = (time.perf_counter() - t0) / len(loader)
+    xd, yd = xs.cuda(), ys.cuda()
+    t0 = time.perf_counter()
+    for _ in range(len(loader)):
+        ex2.step(xd, yd).item()
+    torch.cuda.synchronize()
+    t_direct = (time.perf_counter() - t0) / len(loader)
+    a2.graph_step = False
+    m3 = hub.pretrain_hub_model_small_patch16(a2, emb_frames_dim=512, queue_length=8, T=0.07).cuda().train()
+    opt3 = FusedAdamW(lrd.param_groups_lrd(a2, m3, a2.weight_decay, layer_decay=1), lr=a2.lr, betas=(0.9, 0.95))
+    pr_trainer.pr_rec_one_epoch(a2, m3, loader[:2], opt3, 0, scaler)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pr_trainer.pr_rec_one_epoch(a2, m3, loader[:6], opt3, 1, scaler)
+    torch.cuda.synchronize()
+    t_eager = (time.perf_counter() - t0) / 6
+    assert not hasattr(m3, "_evp_auto_executor")
+    print(f"[default loop] per step: default {t_loop * 1e3:.2f} ms, GraphedStep.step {t_direct * 1e3:.2f} ms, graph_step=False {t_eager * 1e3:.2f} ms")
+    # the loop adds the H2D copy of the batch (16 x 5 x 224 x 224 f32 from pageable memory) and its bookkeeping to the replay
+    assert t_loop <= 1.10 * t_direct + 2.5e-3, (t_loop, t_direct)
+    assert t_loop < 0.8 * t_eager, (t_loop, t_eager)

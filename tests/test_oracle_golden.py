@@ -130,6 +130,31 @@ def test_rec_convvit_small_matches_reference():
         assert abs(sd[n].grad.double().norm().item() - gn) <= 2e-4 * gn + 1e-9, n
 
 
+def test_rec_convvit_base_matches_reference():
+    """ConvViT-Base (the size bench.py --config convvit_base_rec times; reference convvit.py:218-224 + pr_rec_decoder.py:89-95)
+    through the oracle: loss, ids, taps, every gradient norm."""
+    from eventpretrain_amd.testing import det_value_for
+    d = load_golden("rec_convbase")
+    cfg = jl(d["cfg"])
+    sd = {}
+    for k, shp in jl(d["state_keys"]).items():
+        if k.endswith("pos_embed"):
+            sd[k] = torch.from_numpy(mo.sincos_2d(shp[-1], 14)).float().unsqueeze(0)
+        else:
+            sd[k] = det_value_for(k, shp).requires_grad_(True)
+    x, y, noise = rec_inputs("convbase", dict(B=2, input=224, patch=16))
+    loss, l1, l2, lh, pred, mask, restore = mo.convvit_rec_step(sd, x, y, noise, cfg)
+    assert np.array_equal(mask.numpy(), d["mask"]) and np.array_equal(restore.numpy(), d["ids_restore"])
+    assert abs(loss.item() - float(d["loss"])) <= 2e-6 * abs(float(d["loss"]))
+    assert_checksums(l1, d["emb_l1_checksums"], 2e-5)
+    assert_checksums(lh, d["emb_lh_checksums"], 2e-5)
+    assert_checksums(pred, d["pred_checksums"], 2e-5)
+    loss.backward()
+    for n, gn in zip(jl(d["grad_names"]), d["grad_norms"]):
+        assert sd[n].grad is not None, n
+        assert abs(sd[n].grad.double().norm().item() - gn) <= 2e-4 * gn + 1e-9, n
+
+
 def swin_state_dict(d):
     from eventpretrain_amd.testing import det_value_for
     sd = {}

@@ -22,15 +22,15 @@ VARIANTS = {
     "noside": {"set_grad_side": False},
     "noxcd": {"set_wgrad_xcd_order": False},
     "nodefer": {"set_deferred_grads": False},
-    "now256": {"set_wgrad256": False},
     "nog4": {"set_wgrad_g4": False},
+    "nog4fwd": {"_variant": 10},            # wide forward / data-gradient GEMMs on 128x128 tiles instead of the G4 bodies
     "no96": {"_no96": True},                  # 128x128 tiles where the launcher would pick 96x128 (257..384 tiles)
     "noguard": {"_guard_tables": False},     # host free to run ahead (the scalar-table race the guard closes)
 }
 
 
 def apply(cfg):
-    defaults = {"set_grad_side": True, "set_wgrad_xcd_order": True, "set_deferred_grads": True, "set_wgrad256": True, "set_wgrad_g4": True}
+    defaults = {"set_grad_side": True, "set_wgrad_xcd_order": True, "set_deferred_grads": True, "set_wgrad_g4": True}
     for k, v in {**defaults, **cfg}.items():
         if hasattr(ops, k):
             getattr(ops, k)(v)
@@ -49,8 +49,10 @@ def _gemm_no96(a, b, out, *, M, N, K, tile=0, trans_a=False, **kw):
 
 
 def build(B, cfg):
+    from eventpretrain_amd._lib import call
     ops.gemm = _gemm_no96 if cfg.get("_no96") else _orig_gemm
     apply(cfg)
+    call("evp_gemm_set_variant", cfg.get("_variant", 11))      # the routing is decided at launch time, i.e. baked in at capture
     a = make_args(model_size="base", pr_phase="rec", device="cuda", batch_size=B)
     torch.manual_seed(1)
     m = hub.pretrain_hub_model_base_patch16(a, emb_frames_dim=512, queue_length=1024, T=0.07).cuda().train()
@@ -63,6 +65,7 @@ def build(B, cfg):
     ex.guard_tables = cfg.get("_guard_tables", True)
     ops.gemm = _orig_gemm
     apply({})
+    call("evp_gemm_set_variant", 11)
     return ex
 
 
