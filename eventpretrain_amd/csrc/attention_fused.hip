@@ -241,7 +241,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16_t *qkv, bf
 template <int DH, int NT, int NW, bool BIAS>
 __device__ __forceinline__ void attn_bwd_body(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse, bf16_t *dqkv, int N,
                                               int heads, float scale, const float *addm, const float *addmT, int nG, const int b, const int h,
-                                              f32x4 (&dacc)[NT]) {
+                                              f32x4 (&dacc)[NT], unsigned long long *dbg = nullptr) {
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  if (dbg) t0 = __builtin_readcyclecounter();
   #ifndef ATTN_CH
 #define ATTN_CH 4
 #endif
@@ -294,6 +296,7 @@ __device__ __forceinline__ void attn_bwd_body(const bf16_t *qkv, const bf16_t *o
     }
   }
   __syncthreads();
+  if (dbg) t1 = __builtin_readcyclecounter();
   const float c2 = scale * 1.44269504088896340736f, l2e = 1.44269504088896340736f;
 
   // ---- pass 1, query on the lane: dQ ----
@@ -366,6 +369,7 @@ __device__ __forceinline__ void attn_bwd_body(const bf16_t *qkv, const bf16_t *o
     }
   }
 
+  if (dbg) t2 = __builtin_readcyclecounter();
   // ---- pass 2, key on the lane: dK, dV ---- (strips dealt to the waves in the opposite order of pass 1: with 13 strips
   // the wave that took four in pass 1 takes three here)
   for (int strip = NW - 1 - wave; strip * 16 < N; strip += NW) {
@@ -427,15 +431,20 @@ __device__ __forceinline__ void attn_bwd_body(const bf16_t *qkv, const bf16_t *o
       }
     }
   }
+  if (dbg && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) {      // measurement aid: per wave {staging, pass 1, pass 2} cycles
+    const unsigned long long t3 = __builtin_readcyclecounter();
+    unsigned long long *o = dbg + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 3;
+    o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2;
+  }
 }
 
 template <int DH, int NT, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse,
-                                                       bf16_t *dqkv, int N, int heads, float scale) {
+                                                       bf16_t *dqkv, int N, int heads, float scale, unsigned long long *dbg) {
   int b, h;
   head_of_block<DH>(blockIdx.x, gridDim.x, heads, b, h);
   f32x4 unused[NT];
-  attn_bwd_body<DH, NT, NW, false>(qkv, out, dout, lse, dqkv, N, heads, scale, nullptr, nullptr, 1, b, h, unused);
+  attn_bwd_body<DH, NT, NW, false>(qkv, out, dout, lse, dqkv, N, heads, scale, nullptr, nullptr, 1, b, h, unused, dbg);
 }
 
 // Windowed form: workgroup = (group, head, batch chunk). It walks `per` batch items of its (group, head), keeping the d logits of
@@ -511,7 +520,7 @@ int launch_bwd(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const f
   constexpr int smem = 4 * 16 * NT * DH * 2 + 2 * 16 * NT * 4;
   auto go = [&](auto kfn, int nthr) {
     if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(kfn, dim3(B * heads), dim3(nthr), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale);
+    hipLaunchKernelGGL(kfn, dim3(B * heads), dim3(nthr), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale, g_attn_dbg);
   };
   const int nw = attn_bwd_waves();
   if (nw == 16) go(attn_bwd_kernel<DH, NT, 16>, 1024);

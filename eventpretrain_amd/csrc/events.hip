@@ -23,7 +23,7 @@ struct SortKey {
 __device__ __forceinline__ bool key_less(const SortKey &a, const SortKey &b) { return a.t < b.t || (a.t == b.t && a.j < b.j); }
 
 // one workgroup per clip: gather + perturb + clip the added rows, bitonic-sort them by (t, draw order) in LDS
-__global__ __launch_bounds__(1024) void build_added_kernel(const double *events, const int64_t *clip_offsets, const int64_t *add_idx,
+__global__ __launch_bounds__(1024) void build_added_kernel(const double *events, const int64_t *clip_begin, const int64_t *add_idx,
                                                            const double *add_noise, const int64_t *add_offsets, double sensor_w,
                                                            double sensor_h, double *add_rows) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(1024) void build_added_kernel(const double *events,
   const int64_t a0 = add_offsets[c];
   const int na = (int)(add_offsets[c + 1] - a0);
   if (na <= 0) return;
-  const double *ev = events + clip_offsets[c] * 4;
+  const double *ev = events + clip_begin[c] * 4;
   int np2 = 1;
   while (np2 < na) np2 <<= 1;
   for (int j = threadIdx.x; j < np2; j += blockDim.x) {
@@ -85,11 +85,11 @@ __device__ __forceinline__ int lower_bound_i64(const int64_t *a, int n, int64_t 
 }
 
 // grid (chunks, clips): kept rows and added rows scatter themselves to their merged positions
-__global__ __launch_bounds__(256) void merge_kernel(const double *events, const int64_t *clip_offsets, const int64_t *erase_idx,
+__global__ __launch_bounds__(256) void merge_kernel(const double *events, const int64_t *clip_begin, const int64_t *clip_end, const int64_t *erase_idx,
                                                     const int64_t *erase_offsets, const int64_t *add_offsets, const double *add_rows,
                                                     const int64_t *out_offsets, double *out) {
   const int c = blockIdx.y;
-  const int64_t beg = clip_offsets[c], n = clip_offsets[c + 1] - beg;
+  const int64_t beg = clip_begin[c], n = clip_end[c] - beg;
   const int64_t e0 = erase_offsets[c];
   const int ne = (int)(erase_offsets[c + 1] - e0);
   const int64_t a0 = add_offsets[c];
@@ -133,19 +133,17 @@ __global__ __launch_bounds__(256) void merge_kernel(const double *events, const 
 
 }  // namespace
 
-extern "C" int evp_events_erase_add_f64(const double *events, const int64_t *clip_offsets, int n_clips, const int64_t *erase_idx,
-                                        const int64_t *erase_offsets, const int64_t *add_idx, const double *add_noise,
-                                        const int64_t *add_offsets, int max_add_per_clip, double sensor_w, double sensor_h,
-                                        double *add_rows_ws, const int64_t *out_offsets, double *out_events, void *stream) {
-  EVP_CHECK_ARG(events && clip_offsets && erase_offsets && add_offsets && out_offsets && out_events, EVP_EINVAL,
-                "evp_events_erase_add_f64: null pointer");
-  EVP_CHECK_ARG(n_clips > 0, EVP_ESHAPE, "evp_events_erase_add_f64: n_clips must be positive");
-  EVP_CHECK_ARG(max_add_per_clip >= 0 && max_add_per_clip <= EA_MAX_ADD, EVP_ESHAPE,
-                "evp_events_erase_add_f64: at most %d added rows per clip (got %d)", EA_MAX_ADD, max_add_per_clip);
+static int erase_add_launch(const double *events, const int64_t *clip_begin, const int64_t *clip_end, int n_clips, const int64_t *erase_idx,
+                            const int64_t *erase_offsets, const int64_t *add_idx, const double *add_noise, const int64_t *add_offsets,
+                            int max_add_per_clip, double sensor_w, double sensor_h, double *add_rows_ws, const int64_t *out_offsets,
+                            double *out_events, void *stream, const char *who) {
+  EVP_CHECK_ARG(events && clip_begin && clip_end && erase_offsets && add_offsets && out_offsets && out_events, EVP_EINVAL, "%s: null pointer", who);
+  EVP_CHECK_ARG(n_clips > 0, EVP_ESHAPE, "%s: n_clips must be positive", who);
+  EVP_CHECK_ARG(max_add_per_clip >= 0 && max_add_per_clip <= EA_MAX_ADD, EVP_ESHAPE, "%s: at most %d added rows per clip (got %d)", who, EA_MAX_ADD,
+                max_add_per_clip);
   EVP_CHECK_ARG(max_add_per_clip == 0 || (add_idx && add_noise && add_rows_ws), EVP_EINVAL,
-                "evp_events_erase_add_f64: add_idx, add_noise and the workspace are required when rows are added");
-  EVP_CHECK_ARG((((uintptr_t)events | (uintptr_t)out_events) & 15) == 0, EVP_EINVAL,
-                "evp_events_erase_add_f64: event buffers must be 16-byte aligned");
+                "%s: add_idx, add_noise and the workspace are required when rows are added", who);
+  EVP_CHECK_ARG((((uintptr_t)events | (uintptr_t)out_events) & 15) == 0, EVP_EINVAL, "%s: event buffers must be 16-byte aligned", who);
   hipStream_t s = (hipStream_t)stream;
   if (max_add_per_clip > 0) {
     int np2 = 1;
@@ -153,14 +151,31 @@ extern "C" int evp_events_erase_add_f64(const double *events, const int64_t *cli
     const size_t smem = (size_t)np2 * sizeof(SortKey);
     if (smem > 48 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(build_added_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_events_erase_add_f64: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
+      EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "%s: cannot reserve %zu B of LDS: %s", who, smem, hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(build_added_kernel, dim3(n_clips), dim3(1024), smem, s, events, clip_offsets, add_idx, add_noise, add_offsets,
-                       sensor_w, sensor_h, add_rows_ws);
-    EVP_CHECK_LAUNCH("evp_events_erase_add_f64(build)");
+    hipLaunchKernelGGL(build_added_kernel, dim3(n_clips), dim3(1024), smem, s, events, clip_begin, add_idx, add_noise, add_offsets, sensor_w, sensor_h,
+                       add_rows_ws);
+    EVP_CHECK_LAUNCH(who);
   }
-  hipLaunchKernelGGL(merge_kernel, dim3(64, n_clips), dim3(256), 0, s, events, clip_offsets, erase_idx, erase_offsets, add_offsets,
-                     add_rows_ws, out_offsets, out_events);
-  EVP_CHECK_LAUNCH("evp_events_erase_add_f64(merge)");
+  hipLaunchKernelGGL(merge_kernel, dim3(64, n_clips), dim3(256), 0, s, events, clip_begin, clip_end, erase_idx, erase_offsets, add_offsets, add_rows_ws,
+                     out_offsets, out_events);
+  EVP_CHECK_LAUNCH(who);
   return EVP_OK;
+}
+
+extern "C" int evp_events_erase_add_f64(const double *events, const int64_t *clip_offsets, int n_clips, const int64_t *erase_idx,
+                                        const int64_t *erase_offsets, const int64_t *add_idx, const double *add_noise,
+                                        const int64_t *add_offsets, int max_add_per_clip, double sensor_w, double sensor_h,
+                                        double *add_rows_ws, const int64_t *out_offsets, double *out_events, void *stream) {
+  EVP_CHECK_ARG(clip_offsets, EVP_EINVAL, "evp_events_erase_add_f64: null pointer");
+  return erase_add_launch(events, clip_offsets, clip_offsets + 1, n_clips, erase_idx, erase_offsets, add_idx, add_noise, add_offsets, max_add_per_clip,
+                          sensor_w, sensor_h, add_rows_ws, out_offsets, out_events, stream, "evp_events_erase_add_f64");
+}
+
+extern "C" int evp_events_erase_add_win_f64(const double *events, const int64_t *win_begin, const int64_t *win_end, int n_clips,
+                                            const int64_t *erase_idx, const int64_t *erase_offsets, const int64_t *add_idx, const double *add_noise,
+                                            const int64_t *add_offsets, int max_add_per_clip, double sensor_w, double sensor_h, double *add_rows_ws,
+                                            const int64_t *out_offsets, double *out_events, void *stream) {
+  return erase_add_launch(events, win_begin, win_end, n_clips, erase_idx, erase_offsets, add_idx, add_noise, add_offsets, max_add_per_clip, sensor_w,
+                          sensor_h, add_rows_ws, out_offsets, out_events, stream, "evp_events_erase_add_win_f64");
 }

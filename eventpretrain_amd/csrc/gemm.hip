@@ -12,7 +12,11 @@
 #include "gemm_common.h"
 
 static int g_gemm_variant = 1;
-static int g_gemm_g4_fwd = 1;      // A/B switch: wide forward / data-gradient GEMMs on the G4 bodies (default) or on 128x128 tiles
+// A/B switch, bit 0: one-round 256x256 G4 tiles for wide forward GEMMs, bit 1: 128x256 G4 tiles for wide data gradients. OFF by
+// default: re-launched back to back the G4 bodies win 5-20 % on those shapes (tools/gemm_g4_sweep.py), but in the replayed step
+// they lose -- same-box A/B (tools/ab_step.py, ViT-Base rec, 3 x 15 steps): all off 11.17 ms, 256x256 forward only 11.20, 128x256
+// data gradients only 11.31, both 11.31. The tiles stay selectable (evp_gemm_desc::tile 20-22).
+static int g_gemm_g4_fwd = 0;
 static int g_gemm_dbg = 0;
 static unsigned long long *g_stamp_buf = nullptr;   // measurement aid, see gemm_common.h "in-kernel wall-clock stamps"
 static long long g_stamp_slots = 0, g_stamp_next = 0;
@@ -373,6 +377,11 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[MI][NI], const GemmP
 // residual / accumulate loads and the pre-activation store -- covers whole contiguous rows (BN*4 B of f32, BN*2 B of
 // bf16) instead of 16 rows x 32-64 B. The direct form above ran the bf16 stores at ~2.6 TB/s and was a quarter of a
 // K = 768 GEMM's time.
+// (Round 3, tried and removed: requesting the epilogue's READ operands -- the f32 residual of a proj / fc2 forward, the stored
+// pre-activation of a GELU' data gradient, cold in the replayed step -- before the K loop and holding them in registers through it,
+// 64 VGPRs at two workgroups per CU. The launches that read such operands run 15-25 % slower in the step than re-launched on warm
+// caches, the others 2-10 %; same-box A/B of the prefetch: 11.471 against 11.454 ms per ViT-Base step -- nothing. The loads are
+// older than the first K tile's LDS-DMA, so the first counted vmcnt waits for them: the latency moves, it does not disappear.)
 template <typename TC, int EPI, int BM, int BN, int NT, bool RES, bool ACC, bool AUXST>
 __device__ __forceinline__ void epilogue_lds_rows(const float4 *tile, const GemmParams &p, int64_t coff, int m0, int n, int ch, int r0, float4 bias4,
                                                   bool fast) {
@@ -769,7 +778,7 @@ template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(cons
     if constexpr (sizeof(T) == 2 && !TA) {
       if (g_gemm_g4_fwd && g_gemm_variant != 2) {
         const int shape = evp_g4_gemm_pick(d);
-        if (shape) return evp_g4_gemm(d, s, shape, g_gemm_dbg);
+        if ((shape == 20 && (g_gemm_g4_fwd & 1)) || (shape == 22 && (g_gemm_g4_fwd & 2))) return evp_g4_gemm(d, s, shape, g_gemm_dbg);
       }
     }
     const int64_t t128 = (int64_t)((d->M + 127) / 128) * ((d->N + 127) / 128) * nb;
@@ -813,6 +822,8 @@ template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(cons
       // 96 x 128: for launches whose 128 x 128 tiling leaves most CUs with one workgroup and a few with two (294 tiles of a
       // 6272 x 768 output -> 396 tiles): the launch ends when the doubly loaded CUs do, and their tiles are 25 % smaller
       if (tile == 4) return launch<T, TC, EPI, TA, TB, 96, 128, 2, 2, true, 2>(d, s);
+      // (round 3: 64 x 128 and 128 x 64 half tiles at three workgroups per CU were instantiated and swept on every narrow-output shape
+      //  of the step -- N = 768 / 512, tools/gemm_narrow_sweep.py -- and lost to the choice below by 5-30 %: removed again)
       if (tile == 1) return launch<T, TC, EPI, TA, TB, 128, 128, 2, 2, true, 2>(d, s);
       return launch<T, TC, EPI, TA, TB, 64, 64, 2, 2, true, 2>(d, s);
     }
@@ -875,7 +886,7 @@ extern "C" int evp_gemm_set_variant(int v) {
   const int old = g_gemm_variant;
   if (v >= 100 && v <= 102) g_gemm_dbg = v - 100;
   if (v == 1 || v == 2) g_gemm_variant = v;
-  if (v == 10 || v == 11) g_gemm_g4_fwd = v - 10;
+  if (v >= 10 && v <= 13) g_gemm_g4_fwd = v == 11 ? 3 : v == 10 ? 0 : v - 11;     // 10 off (default), 11 on, 12 = 256x256 only, 13 = 128x256 only
   return old;
 }
 

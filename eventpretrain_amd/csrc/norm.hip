@@ -136,51 +136,87 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const void *dy, int 
 #pragma unroll
   for (int i = 0; i < (CS ? VPL : 1); ++i) dc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  for (int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; r < M; r += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
-    Row<VPL> xr, gr;
-    xr.load(x + r * D, D, lane);
-    if (x2) xr.add(x2 + r * D, D, lane);
-    if (x3) xr.add(x3 + r * D, D, lane);
-    gr.load_any(dy, dy_dtype, r * D, D, lane);
-    const float mu = mean[r], rs = rstd[r];
-    float s1 = 0.f, s2 = 0.f;
+  // TWO rows per wave and iteration, every load of both rows (x, dy, the residual-stream gradient, the row statistics) requested
+  // before anything is reduced: the one-row form issued x and dy, ran two shuffle reductions, and only then asked for gres -- 6-9
+  // loads in flight per wave and a dependent HBM round trip in the middle of every row (42 launches at 3.8-4.4 TB/s).
+  // Same-box A/B against the one-row form (tools/ab_step.py, round 3): 11.366 against 11.387 ms per ViT-Base step -- inside the noise;
+  // the kernel is not bound by its loads in flight.
+  // (rows wider than 1024 floats per 64 lanes -- VPL > 4 -- keep one row per iteration: two would spill)
+  constexpr int NR = VPL <= 4 ? 2 : 1;
+  const int64_t stride = (int64_t)gridDim.x * ROWS_PER_BLOCK;
+  for (int64_t r0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; r0 < M; r0 += NR * stride) {
+    const int64_t rr[2] = {r0, r0 + stride};
+    const bool live[2] = {true, r0 + stride < M};
+    Row<VPL> xr[NR], gr[NR], qr[NR];
+    float mu[NR], rs[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int64_t r = live[k] ? rr[k] : r0;          // a dead second row re-reads the first (never stored, never summed)
+      xr[k].load(x + r * D, D, lane);
+      gr[k].load_any(dy, dy_dtype, r * D, D, lane);
+      if (gres) qr[k].load(gres + r * D, D, lane);
+      mu[k] = mean[r];
+      rs[k] = rstd[r];
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int64_t r = live[k] ? rr[k] : r0;
+      if (x2) xr[k].add(x2 + r * D, D, lane);
+      if (x3) xr[k].add(x3 + r * D, D, lane);
+    }
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};      // (entries >= NR stay 0)
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int c = lane + 64 * i;
       if (c * 4 < D) {
         const float4 g = *reinterpret_cast<const float4 *>(gamma + c * 4);
-        float4 xh;
-        xh.x = (xr.v[i].x - mu) * rs; xh.y = (xr.v[i].y - mu) * rs;
-        xh.z = (xr.v[i].z - mu) * rs; xh.w = (xr.v[i].w - mu) * rs;
-        const float4 d = gr.v[i];
-        dg[i].x += d.x * xh.x; dg[i].y += d.y * xh.y; dg[i].z += d.z * xh.z; dg[i].w += d.w * xh.w;
-        db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
-        float4 t;  // dy * gamma
-        t.x = d.x * g.x; t.y = d.y * g.y; t.z = d.z * g.z; t.w = d.w * g.w;
-        s1 += (t.x + t.y) + (t.z + t.w);
-        s2 += (t.x * xh.x + t.y * xh.y) + (t.z * xh.z + t.w * xh.w);
-        gr.v[i] = t;
-        xr.v[i] = xh;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          float4 xh;
+          xh.x = (xr[k].v[i].x - mu[k]) * rs[k]; xh.y = (xr[k].v[i].y - mu[k]) * rs[k];
+          xh.z = (xr[k].v[i].z - mu[k]) * rs[k]; xh.w = (xr[k].v[i].w - mu[k]) * rs[k];
+          const float4 d = gr[k].v[i];
+          if (live[k]) {
+            dg[i].x += d.x * xh.x; dg[i].y += d.y * xh.y; dg[i].z += d.z * xh.z; dg[i].w += d.w * xh.w;
+            db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+          }
+          float4 t;  // dy * gamma
+          t.x = d.x * g.x; t.y = d.y * g.y; t.z = d.z * g.z; t.w = d.w * g.w;
+          s1[k] += (t.x + t.y) + (t.z + t.w);
+          s2[k] += (t.x * xh.x + t.y * xh.y) + (t.z * xh.z + t.w * xh.w);
+          gr[k].v[i] = t;
+          xr[k].v[i] = xh;
+        }
       }
     }
-    s1 = wave_sum(s1) / (float)D;
-    s2 = wave_sum(s2) / (float)D;
+    // four reductions interleaved: the shuffles of one hide under the others' latency
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      const int c = lane + 64 * i;
-      if (c * 4 < D) {
-        float4 o;
-        o.x = rs * (gr.v[i].x - s1 - xr.v[i].x * s2);
-        o.y = rs * (gr.v[i].y - s1 - xr.v[i].y * s2);
-        o.z = rs * (gr.v[i].z - s1 - xr.v[i].z * s2);
-        o.w = rs * (gr.v[i].w - s1 - xr.v[i].w * s2);
-        if (gres) {
-          const float4 q = *reinterpret_cast<const float4 *>(gres + r * D + c * 4);
-          o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+    for (int o = 32; o > 0; o >>= 1) {
+      const float a0 = __shfl_xor(s1[0], o, 64), a1 = __shfl_xor(s2[0], o, 64), a2 = __shfl_xor(s1[1], o, 64), a3 = __shfl_xor(s2[1], o, 64);
+      s1[0] += a0; s2[0] += a1; s1[1] += a2; s2[1] += a3;
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      if (!live[k]) continue;
+      const int64_t r = rr[k];
+      const float m1 = s1[k] / (float)D, m2 = s2[k] / (float)D;
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c * 4 < D) {
+          float4 o;
+          o.x = rs[k] * (gr[k].v[i].x - m1 - xr[k].v[i].x * m2);
+          o.y = rs[k] * (gr[k].v[i].y - m1 - xr[k].v[i].y * m2);
+          o.z = rs[k] * (gr[k].v[i].z - m1 - xr[k].v[i].z * m2);
+          o.w = rs[k] * (gr[k].v[i].w - m1 - xr[k].v[i].w * m2);
+          if (gres) {
+            const float4 q = qr[k].v[i];
+            o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+          }
+          if (dx) *reinterpret_cast<float4 *>(dx + r * D + c * 4) = o;
+          if (dx_lp) store4_any(dx_lp, EVP_BF16, r * D + c * 4, o);
+          if constexpr (CS) { dc[i].x += o.x; dc[i].y += o.y; dc[i].z += o.z; dc[i].w += o.w; }
         }
-        if (dx) *reinterpret_cast<float4 *>(dx + r * D + c * 4) = o;
-        if (dx_lp) store4_any(dx_lp, EVP_BF16, r * D + c * 4, o);
-        if constexpr (CS) { dc[i].x += o.x; dc[i].y += o.y; dc[i].z += o.z; dc[i].w += o.w; }
       }
     }
   }

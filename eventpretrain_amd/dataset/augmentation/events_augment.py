@@ -82,15 +82,24 @@ def draw_erase_add_batch(seed, step, sizes, first_sample=0):
     return out
 
 
-def events_augment_batch(events, clip_offsets, decisions, size):
+def events_augment_batch(events, clip_offsets, decisions, size, windows=None):
     """events: float64 CUDA tensor [n_total,4] (x,y,t,p), every clip time-sorted; clip_offsets: int64 host sequence /
     array [n_clips+1]; decisions: one `draw_erase_add` result (or None) per clip; size = (sensor_h, sensor_w).
+    `windows`: optional int64 host array [n_clips,2] of clip-relative [start, end) rows -- `get_random_index`'s pick; the
+    decisions' indices are then relative to the window and the output holds the augmented windows only.
     Returns (augmented events float64 CUDA [n_total',4], new clip_offsets int64 CUDA [n_clips+1])."""
     _lib.require_device()
     if not events.is_cuda or events.dtype != torch.float64 or events.dim() != 2 or events.shape[1] != 4 or not events.is_contiguous():
         raise _lib.EvpError("events_augment_batch: events must be a contiguous float64 [N,4] tensor in device memory")
     offs = np.asarray(clip_offsets.cpu() if torch.is_tensor(clip_offsets) else clip_offsets, dtype=np.int64)
     n_clips = offs.shape[0] - 1
+    if windows is not None:
+        win = np.asarray(windows, dtype=np.int64).reshape(n_clips, 2)
+        if (win[:, 0] < 0).any() or (win[:, 1] < win[:, 0]).any() or (win[:, 1] > offs[1:] - offs[:-1]).any():
+            raise _lib.EvpError("events_augment_batch: a window leaves its clip")
+        w_beg, w_end = offs[:-1] + win[:, 0], offs[:-1] + win[:, 1]
+    else:
+        w_beg, w_end = offs[:-1], offs[1:]
     if len(decisions) != n_clips:
         raise _lib.EvpError("events_augment_batch: one decision entry per clip")
     dev = events.device
@@ -98,7 +107,7 @@ def events_augment_batch(events, clip_offsets, decisions, size):
     er_off, ad_off, out_off = np.zeros(n_clips + 1, np.int64), np.zeros(n_clips + 1, np.int64), np.zeros(n_clips + 1, np.int64)
     max_add = 0
     for c, d in enumerate(decisions):
-        n = int(offs[c + 1] - offs[c])
+        n = int(w_end[c] - w_beg[c])
         e = a = 0
         if d is not None:
             er, ai, nz = d
@@ -119,13 +128,14 @@ def events_augment_batch(events, clip_offsets, decisions, size):
 
     # one packed upload for the index tables
     er_d, ai_d, nz_d = up(er_l, np.int64, (0,)), up(ai_l, np.int64, (0,)), up(nz_l, np.float64, (0, 3))
-    tabs = torch.from_numpy(np.stack([offs, er_off, ad_off, out_off])).to(dev)
+    pad = lambda v: np.concatenate([v, np.zeros(n_clips + 1 - v.shape[0], np.int64)])
+    tabs = torch.from_numpy(np.stack([pad(w_beg), pad(w_end), er_off, ad_off, out_off])).to(dev)
     n_add, n_out = int(ad_off[-1]), int(out_off[-1])
     ws = torch.empty(max(n_add, 1), 4, dtype=torch.float64, device=dev)
     out = torch.empty(n_out, 4, dtype=torch.float64, device=dev)
-    call("evp_events_erase_add_f64", ptr(events), ptr(tabs[0]), n_clips, ptr(er_d), ptr(tabs[1]), ptr(ai_d), ptr(nz_d), ptr(tabs[2]),
-         max_add, float(size[1]), float(size[0]), ptr(ws), ptr(tabs[3]), ptr(out), stream_ptr())
-    return out, tabs[3]
+    call("evp_events_erase_add_win_f64", ptr(events), ptr(tabs[0]), ptr(tabs[1]), n_clips, ptr(er_d), ptr(tabs[2]), ptr(ai_d), ptr(nz_d),
+         ptr(tabs[3]), max_add, float(size[1]), float(size[0]), ptr(ws), ptr(tabs[4]), ptr(out), stream_ptr())
+    return out, tabs[4]
 
 
 def erase_and_add_events(args, events, size=None):

@@ -122,6 +122,8 @@ def make_args(**overrides) -> SimpleNamespace:
         blr=1e-3, lr=None, min_lr=0.0, warmup_epochs=20, epochs=5, weight_decay=0.05,
         layer_decay=0.75, use_layer_decay=False, use_layer_grafted=False,
         batch_size=2, seed=0, start_epoch=0, world_size=1, rank=0,
+        # loader-side fields (main_pretrain.py:56,61,141-142)
+        crop_min=0.8, fix_events_num=15000, val_fix_events_num=15000, img_sensor_w=640, img_sensor_h=480, graph_step=True,
     )
     a.update(overrides)
     return SimpleNamespace(**a)

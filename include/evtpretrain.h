@@ -78,6 +78,13 @@ int evp_events_erase_add_f64(const double *events, const int64_t *clip_offsets, 
                              const int64_t *erase_offsets, const int64_t *add_idx, const double *add_noise,
                              const int64_t *add_offsets, int max_add_per_clip, double sensor_w, double sensor_h,
                              double *add_rows_ws, const int64_t *out_offsets, double *out_events, void *stream);
+/* The same on a WINDOW of every clip: clip c is rows [win_begin[c], win_end[c]) of `events` (int64 [n_clips] each) -- the loader's
+ * `get_random_index` pick (events_augment.py:5-20, pr_n_imagenet_dataset.py:83-84) taken on clips already resident in HBM; all
+ * indices stay relative to the window. The merge pass compacts the windows into out_events while it erases / adds. */
+int evp_events_erase_add_win_f64(const double *events, const int64_t *win_begin, const int64_t *win_end, int n_clips,
+                                 const int64_t *erase_idx, const int64_t *erase_offsets, const int64_t *add_idx, const double *add_noise,
+                                 const int64_t *add_offsets, int max_add_per_clip, double sensor_w, double sensor_h, double *add_rows_ws,
+                                 const int64_t *out_offsets, double *out_events, void *stream);
 /* sorted_flags[c] = 1 if clip c's stamps are non-decreasing, else 0 (device int32 [n_clips]). */
 int evp_events_sorted_check(const double *events, const int64_t *clip_offsets, int n_clips, int is_txyp,
                             int32_t *sorted_flags, void *stream);
@@ -120,8 +127,8 @@ typedef struct {
   int tile;                             /* 0 auto; 1 = 128x128, 2 = 64x64, 4 = 96x128 (LDS-staged 16x16x32 body, two workgroups per CU);
                                          * 9 = G4 256x256 (bf16 TN, f32 C, K % 32 == 0); 20 / 21 / 22 = G4 forward / data-gradient bodies
                                          * 256x256 / 256x128 / 128x256 (bf16 operands and C, A row-major, K % 32 == 0, K >= 96, N % 8 == 0,
-                                         * linear or activation epilogue, no residual). Auto sends wide outputs (N >= 1024, M >= 2048) to the
-                                         * G4 bodies, 257..384-tile outputs to 96x128, small outputs to 64x64, the rest to 128x128. */
+                                         * linear or activation epilogue, no residual). Auto sends 257..384-tile outputs to 96x128, small outputs
+                                         * to 64x64, the rest to 128x128 (and, with evp_gemm_set_variant(11), wide outputs to the G4 bodies). */
   int splitk;                           /* 0 auto, n = cut K into n slices summed with f32 atomics (plain f32 C only) */
 } evp_gemm_desc;
 int evp_gemm(const evp_gemm_desc *d, void *stream);
@@ -144,8 +151,9 @@ int evp_gemm_grouped_tn_g4_bf16(const void *problems, const void *items, int n_i
  * entered into the grouped launch as several K-slice problems writing to a workspace (ConvViT stage 1: K = B*56*56). */
 int evp_sum_slices_f32(const float *ws, float *out, int n_slices, int64_t numel, int accumulate, void *stream);
 /* Tuning switches for A/B measurements (results are identical up to f32 summation order): 1 = LDS-DMA (buffer_load ... lds)
- * staging for bf16 (default), 2 = register staging; 10 / 11 = wide forward / data-gradient GEMMs on 128x128 tiles / on the G4
- * bodies (default). Returns the previous staging variant; any other argument only queries. */
+ * staging for bf16 (default), 2 = register staging; 10 = wide forward / data-gradient GEMMs on 128x128 tiles (default: the G4
+ * bodies lose inside the replayed step), 11 = on the G4 bodies, 12 / 13 = only the one-round 256x256 forward
+ * tiles / only the 128x256 data-gradient tiles. Returns the previous staging variant; any other argument only queries. */
 int evp_gemm_set_variant(int v);
 /* Measurement aid: in-kernel wall-clock stamps. `buf` = device uint64 [n_slots][2 * 4096] (NULL switches stamping off and resets
  * the slot counter): every following GEMM launch (evp_gemm, the grouped entries) takes the next slot (mod n_slots) and each of its

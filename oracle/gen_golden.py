@@ -14,7 +14,7 @@ module object supplying `to_2tuple`, `trunc_normal_` and a `DropPath` that is
 never executed (all drop rates are 0 -> nn.Identity, vit_block.py:241) is put
 in sys.modules for the duration of this script.
 
-Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin,swincon,augment,evaug,ftcls,density,autocast,conbase,swinbase,convbase]
+Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin,swincon,augment,evaug,ftcls,density,autocast,conbase,swinbase,convbase,chain]
 """
 import argparse
 import json
@@ -557,6 +557,45 @@ def gen_swincon():
     save("con_swin_tiny_queue", **out)
 
 
+def gen_chain():
+    """The loader's whole per-sample chain run by the reference itself (dataset/pretrain/pr_n_imagenet_dataset.py:82-89 on the running
+    numpy stream, then the seeded evg_augment / frame_augment pair of pr_ef_imagenet_dataset.py:187-206):
+        np.random.seed(s); get_random_index -> events[start:end] -> events_augment -> events_reshape -> events_to_voxel_grid ->
+        seed2 = np.random.randint(1000); evg_augment(seed=seed2); frame_augment(seed=seed2, time_flip_flag)
+    on synthetic sensor-shaped clips (640 x 480, as N-ImageNet). The fixture keeps the seeds, the decisions' observable results
+    (window, clip length after augmentation, time-flip flag) and checksums + every 7th value of the two outputs."""
+    _ref()
+    from dataset.augmentation.events_augment import events_augment, events_reshape, get_random_index
+    from dataset.augmentation.view_augment import evg_augment, frame_augment
+    from dataset.dataset_utils.events_to_voxel_grid import events_to_voxel_grid
+    from eventpretrain_amd.testing import synthetic_events
+    torch.set_num_threads(1)
+    out = {}
+    cases = [("a", 101, 40_000, 15_000), ("b", 102, 150_000, 100_000), ("c", 103, 9_000, 15_000), ("d", 104, 150_000, 100_000)]
+    for tag, seed, n_ev, fix in cases:
+        a = make_args(crop_min=0.8, input_size=224, fix_events_num=fix, img_sensor_w=640, img_sensor_h=480)
+        a.num_bins = 5
+        ev = synthetic_events(7000 + seed, n_ev, width=640, height=480)
+        frame = det_normalish(f"chain.frame.{tag}", (1, 480, 640))
+        np.random.seed(seed)
+        s0, s1 = get_random_index(a, ev, is_train=True)
+        e = ev[s0:s1].copy()
+        e = events_augment(a, e, size=(480, 640))
+        n_aug = e.shape[0]
+        e = events_reshape(e, 640, 480, 224, 224)
+        evg = events_to_voxel_grid(a, e, size=(224, 224))
+        seed2 = np.random.randint(1000)
+        evg, tflag = evg_augment(a, evg, size=(224, 224), seed=seed2)
+        fr = frame_augment(a, frame.clone(), seed=seed2, time_flip_flag=tflag)
+        evg, fr = evg.contiguous(), fr.contiguous()
+        out[f"{tag}_seed"], out[f"{tag}_n"], out[f"{tag}_fix"] = np.array(seed), np.array(n_ev), np.array(fix)
+        out[f"{tag}_window"], out[f"{tag}_n_aug"], out[f"{tag}_tflip"] = np.array([s0, s1]), np.array(n_aug), np.array(int(tflag))
+        out[f"{tag}_evg_checksums"], out[f"{tag}_evg_sample"] = checksums(evg), evg.flatten()[::7].clone()
+        out[f"{tag}_frame_checksums"], out[f"{tag}_frame_sample"] = checksums(fr), fr.flatten()[::7].clone()
+    out["tags"] = np.array(json.dumps([c[0] for c in cases]))
+    save("loader_chain", **out)
+
+
 def gen_augment():
     """evg_augment of the reference itself (dataset/augmentation/view_augment.py:84-95) under np.random.seed(seed), for
     sensor-shaped and input-shaped grids; the fixture keeps inputs' generator seeds, outputs and time-flip flags."""
@@ -863,7 +902,7 @@ def gen_swin_base():
 GENS = dict(voxel=gen_voxel, pos=gen_pos, mask=gen_mask, tiny=lambda: gen_composed("tiny"), small=gen_small,
             base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall, swin=gen_swin, swincon=gen_swincon, augment=gen_augment, evaug=gen_evaug, ftcls=gen_ftcls,
             frameaug=gen_frameaug, density=gen_density, autocast=gen_autocast, conbase=gen_con_base, swinbase=gen_swin_base,
-            convbase=gen_convbase)
+            convbase=gen_convbase, chain=gen_chain)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -50,6 +50,6 @@ def _restore_global_switches(request):
         ops.set_deferred_grads(True)
         from eventpretrain_amd._lib import call
         call("evp_gemm_set_variant", 1)
-        call("evp_gemm_set_variant", 11)
+        call("evp_gemm_set_variant", 10)
     except Exception:
         pass

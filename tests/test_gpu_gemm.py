@@ -331,9 +331,10 @@ def test_g4_forward_tiles_refuse_what_they_do_not_take():
         ops.gemm(a, a, torch.empty(256, 256, device="cuda"), M=256, N=256, K=128, tile=12)
 
 
-def test_wide_outputs_take_the_g4_bodies_by_default():
-    """The automatic tile choice sends one-round wide forward GEMMs (256x256 tiles) and wide data gradients (128x256) to the G4
-    bodies: same result as forcing tile 20 / 22, and evp_gemm_set_variant(10) switches the routing off (A/B aid)."""
+def test_wide_outputs_take_the_g4_bodies_when_switched_on():
+    """evp_gemm_set_variant(11): the automatic tile choice sends one-round wide forward GEMMs (256x256 tiles) and wide data gradients
+    (128x256) to the G4 bodies -- same result as forcing tile 20 / 22; variant 10 (the default: the G4 bodies lose inside the
+    replayed step) keeps them on 128x128 tiles."""
     from eventpretrain_amd import ops
     from eventpretrain_amd._lib import call
     gen = torch.Generator().manual_seed(77)
@@ -341,12 +342,14 @@ def test_wide_outputs_take_the_g4_bodies_by_default():
         a, b, _, _ = _mk(M, N, K, False, tb, torch.bfloat16, gen)
         c0, c1, c2 = (torch.empty(M, N, dtype=torch.bfloat16, device="cuda") for _ in range(3))
         kw = dict(M=M, N=N, K=K, trans_b=tb, ldb=(N if tb else K))
-        ops.gemm(a.cuda(), b.cuda(), c0, **kw)
+        call("evp_gemm_set_variant", 11)
+        try:
+            ops.gemm(a.cuda(), b.cuda(), c0, **kw)
+        finally:
+            call("evp_gemm_set_variant", 10)
         ops.gemm(a.cuda(), b.cuda(), c1, tile=forced, **kw)
         assert torch.equal(c0, c1)
-        call("evp_gemm_set_variant", 10)
-        try:
-            ops.gemm(a.cuda(), b.cuda(), c2, **kw)
-        finally:
-            call("evp_gemm_set_variant", 11)
+        ops.gemm(a.cuda(), b.cuda(), c2, **kw)
+        ops.gemm(a.cuda(), b.cuda(), c1, tile=1, **kw)
+        assert torch.equal(c1, c2)
         assert (c0.float() - c2.float()).abs().max().item() <= 2.0 ** -7 * c0.float().abs().max().item()

@@ -353,6 +353,7 @@ def test_trainer_with_graph_executor_matches_eager():
         for graphed in (False, True):
             a = make_args(model_size="tiny", pr_phase="rec", patch_size=16, device="cuda", input_size=64)
             a.lr, a.min_lr, a.warmup_epochs, a.epochs, a.batch_size = 1e-3, 1e-6, 1, 4, 2
+            a.graph_step = graphed          # the eager arm opts out of the loop's own executor (the default since round 3)
             m = hub.pretrain_hub_model_tiny_patch16_64(a, emb_frames_dim=512, queue_length=1024, T=0.07)
             det_fill_module_(m)
             m = m.cuda().train()

@@ -23,7 +23,9 @@ VARIANTS = {
     "noxcd": {"set_wgrad_xcd_order": False},
     "nodefer": {"set_deferred_grads": False},
     "nog4": {"set_wgrad_g4": False},
-    "nog4fwd": {"_variant": 10},            # wide forward / data-gradient GEMMs on 128x128 tiles instead of the G4 bodies
+    "g4fwd": {"_variant": 11},              # wide forward / data-gradient GEMMs on the G4 bodies instead of 128x128 tiles
+    "g4fwd256": {"_variant": 12},           # only the one-round 256x256 forward tiles (encoder qkv)
+    "g4dgrad": {"_variant": 13},            # only the 128x256 data-gradient tiles (fc2 data gradient with GELU')
     "no96": {"_no96": True},                  # 128x128 tiles where the launcher would pick 96x128 (257..384 tiles)
     "noguard": {"_guard_tables": False},     # host free to run ahead (the scalar-table race the guard closes)
 }
@@ -52,7 +54,7 @@ def build(B, cfg):
     from eventpretrain_amd._lib import call
     ops.gemm = _gemm_no96 if cfg.get("_no96") else _orig_gemm
     apply(cfg)
-    call("evp_gemm_set_variant", cfg.get("_variant", 11))      # the routing is decided at launch time, i.e. baked in at capture
+    call("evp_gemm_set_variant", cfg.get("_variant", 10))      # the routing is decided at launch time, i.e. baked in at capture
     a = make_args(model_size="base", pr_phase="rec", device="cuda", batch_size=B)
     torch.manual_seed(1)
     m = hub.pretrain_hub_model_base_patch16(a, emb_frames_dim=512, queue_length=1024, T=0.07).cuda().train()
@@ -65,7 +67,7 @@ def build(B, cfg):
     ex.guard_tables = cfg.get("_guard_tables", True)
     ops.gemm = _orig_gemm
     apply({})
-    call("evp_gemm_set_variant", 11)
+    call("evp_gemm_set_variant", 10)
     return ex
 
 

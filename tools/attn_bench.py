@@ -50,3 +50,20 @@ for name, B, N, h, dh in [("enc", 64, 98, 12, 64), ("dec", 64, 196, 16, 32)]:
     call("evp_attention_set_debug_buffer", None)
     d = dbg.cpu().numpy().reshape(-1, 2).astype(float)
     print(f"{name} fwd: staging cycles mean {d[:, 0].mean():.0f} max {d[:, 0].max():.0f}; strips cycles per wave mean {d[:, 1].mean():.0f} max {d[:, 1].max():.0f}")
+
+# per-wave cycle split of the fused backward (staging / query-on-lane pass / key-on-lane pass)
+for name, B, N, h, dh in [("enc", 64, 98, 12, 64), ("dec", 64, 196, 16, 32)]:
+    C = h * dh
+    qkv = (torch.randn(B * N, 3 * C, device="cuda") * 0.8).bfloat16()
+    dout = torch.randn(B * N, C, device="cuda").bfloat16()
+    out, lse, _ = ops.attention_fused_fwd(qkv, B, N, h, dh)
+    dbg = torch.zeros(B * h * 8 * 3, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    call("evp_attention_set_debug_buffer", dbg.data_ptr())
+    for _ in range(3):
+        ops.attention_fused_bwd(qkv, out, dout, lse, B, N, h, dh)
+    torch.cuda.synchronize()
+    call("evp_attention_set_debug_buffer", None)
+    d = dbg.cpu().numpy().reshape(-1, 3).astype(float)
+    print(f"{name} bwd cycles per wave: staging mean {d[:, 0].mean():.0f} max {d[:, 0].max():.0f}; pass 1 (dQ) mean {d[:, 1].mean():.0f} max {d[:, 1].max():.0f}; "
+          f"pass 2 (dK, dV) mean {d[:, 2].mean():.0f} max {d[:, 2].max():.0f}")
