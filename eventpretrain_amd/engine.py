@@ -19,6 +19,25 @@ import torch
 from . import ops
 
 
+class BackwardCut:
+    """Splits one backward pass at a tensor: forward calls cut(t) where the model hands `t` from one part to the next, and gets a
+    detached leaf in its place; loss.backward() then stops at the leaf (gradients of everything AFTER the cut, and the leaf's own),
+    resume() runs the rest: t.backward(leaf.grad). Numerically the same backward, as two autograd calls -- which is what lets the
+    data-parallel executor capture them as two HIP graphs and put a collective between them."""
+
+    def __init__(self):
+        self.src = self.leaf = None
+
+    def __call__(self, t):
+        self.src = t
+        self.leaf = t.detach().requires_grad_(True)
+        return self.leaf
+
+    def resume(self):
+        self.src.backward(self.leaf.grad)
+        self.src = self.leaf = None
+
+
 class GraphedStep:
     def __init__(self, model, optimizer, forward, static_inputs, noise_shape=None, generator=None, reducer=None,
                  use_graph=True, warmup=2, wgrad_chunks=4, step_prepare=None, host_generator=None):
@@ -49,7 +68,7 @@ class GraphedStep:
             self._noise_events, self._noise_turn, self._noise_cpu = [None] * 3, 0, None
         self.eager_fallbacks = 0
         self.noise_feed = None         # optional iterator of (B, L) noise tensors used instead of a draw (tests: a given noise sequence)
-        self.graph = self.graph0 = self.graph2 = self.plan = None
+        self.graph = self.graph0 = self.graph2 = self.graphB = self.plan = None
         self.parts = False
         self.loss = None
         self._tables_read = None       # event: the last replay's H2D nodes have read the pinned scalar tables
@@ -167,7 +186,15 @@ class GraphedStep:
             g1 = torch.cuda.CUDAGraph()
             # thread_local: RCCL's watchdog thread polls its events while this thread captures
             ops.hold_deferred_grads(self.multi)      # N ranks: the grouped weight-gradient launches stay out of the graph
+            # N ranks, masked modeling: the backward is cut at the encoder / decoder boundary (BackwardCut) and captured as two
+            # graphs, so that the decoder's weight gradients -- complete after the first -- are computed and all-reduced on side
+            # streams while the second (the encoder's backward, ~3 ms) replays: the window that hides the collective grows from the
+            # step's last ~2 ms to ~5 ms (unmeasured on more than one GPU)
+            cut = BackwardCut() if (self.multi and hasattr(self.model, "set_backward_cut")) else None
+            early_steps = ()
             try:
+                if cut is not None:
+                    self.model.set_backward_cut(cut)
                 with torch.cuda.graph(g1, stream=side, capture_error_mode="thread_local"):
                     out = self.forward(self.model, *self.inputs, self.noise)
                     out[0].backward()
@@ -176,8 +203,17 @@ class GraphedStep:
                         self.opt.launch()
                     self.loss = out[0].detach()
                     del out
+                if cut is not None and cut.src is not None:        # the forward used the cut: second half of the backward
+                    with torch.cuda.stream(side):
+                        early_steps = ops.build_deferred_plan(1)   # the decoder side's queued weight / bias gradients
+                    gB = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gB, stream=side, pool=g1.pool(), capture_error_mode="thread_local"):
+                        cut.resume()
+                    self.graphB = gB
             finally:
                 ops.hold_deferred_grads(False)
+                if cut is not None:
+                    self.model.set_backward_cut(None)
             if not self.multi:
                 # the per-step scalar tables (lr, weight decay, bias corrections) travel in a graph of their own, replayed in
                 # FRONT of the step: the host may then prepare step N+1 as soon as step N has started (see step())
@@ -193,7 +229,7 @@ class GraphedStep:
             if self.multi:
                 # chunked weight-gradient launches interleaved with their all-reduces (parallel.OverlappedPlan)
                 with torch.cuda.stream(side):
-                    self.plan = self.reducer.make_overlapped_plan(self.wgrad_chunks)
+                    self.plan = self.reducer.make_overlapped_plan(self.wgrad_chunks, early_steps=early_steps)
                 # AdamW in parts, each launched as soon as its gradient buffer is reduced (the graph then only holds the
                 # H2D copies of the per-step scalar tables); one launch after the last all-reduce otherwise
                 self.parts = self.plan.streams is not None
@@ -207,11 +243,13 @@ class GraphedStep:
                         self.plan.attach_optimizer(self.opt, [p for p in self.model.parameters() if p.requires_grad])
                 side.synchronize()
                 self.graph2 = g2
-                self.note = ("hip-graph (fwd+bwd) + %d weight-gradient chunks on two streams, each all-reduced (RCCL) while the next "
+                self.note = (("hip-graph (fwd + decoder bwd) + decoder weight gradients all-reduced under hip-graph (encoder bwd) + " if self.graphB is not None
+                              else "hip-graph (fwd+bwd) + ") +
+                             "%d weight-gradient chunks on two streams, each all-reduced (RCCL) while the next "
                              "computes, AdamW per reduced buffer" % self.wgrad_chunks) if self.parts else \
                             ("hip-graph (fwd+bwd) + %d weight-gradient chunks overlapped with RCCL all-reduce + hip-graph (AdamW)" % self.wgrad_chunks)
         except Exception as e:               # keep training; say what happened
-            self.graph = self.graph0 = self.graph2 = self.plan = None
+            self.graph = self.graph0 = self.graph2 = self.graphB = self.plan = None
             self.note = "eager (graph capture failed: %r)" % (e,)
             self.opt.zero_grad(set_to_none=True)
             ops.flush_deferred_grads()
@@ -249,11 +287,15 @@ class GraphedStep:
         if self.graph0 is not None:
             self.graph0.replay()
             self._mark_tables_read()
+        if self.plan is not None and self.parts:
+            self.graph2.replay()             # this step's lr / bias-correction tables -> device, ahead of everything that updates
+            self._mark_tables_read()
         self.graph.replay()
         if self.plan is not None:
+            if self.graphB is not None:
+                self.plan.run_early()        # decoder weight gradients + their all-reduce (+ update) on side streams ...
+                self.graphB.replay()         # ... under the encoder's backward
             if self.parts:
-                self.graph2.replay()         # this step's lr / bias-correction tables -> device
-                self._mark_tables_read()
                 self.plan.run()              # weight gradients, all-reduces and the update, part by part
             else:
                 self.plan.run()

@@ -94,6 +94,14 @@ class PrHubModel(nn.Module):
             raise ValueError("queue_policy must be all_gather, rank0_broadcast or local")
         return pol if _dist_ready() else "local"
 
+    _backward_cut = None
+
+    def set_backward_cut(self, cut):
+        """engine.BackwardCut (or None): the masked-modeling forward then hands the encoder output to the decoder through it, so
+        that the decoder's backward and the encoder's backward can be run -- and captured -- as two calls. The data-parallel step
+        executor uses this to start the all-reduce of the decoder's gradients under the encoder's backward."""
+        self._backward_cut = cut
+
     def forward_has_collective(self):
         """True when forward() talks to other ranks: the key all-gather of the queue / of the in-batch InfoNCE (pr_hub_model.py:
         248-259) or the reference-faithful buffer broadcast. The step executor keeps collectives outside captured HIP graphs,
@@ -139,12 +147,16 @@ class PrHubModel(nn.Module):
         if is_rec and swin_:
             (emb_l1, emb_l2, emb_l3, emb_l4, emb_lh, coords_l1, coords_l2, coords_l3, coords_l4, mask, ids_restore,
              attn) = self.backbone(events_voxel_grid, mask=True, noise=noise)
+            if self._backward_cut is not None:
+                emb_lh = self._backward_cut(emb_lh)
             reconstruct_pred = self.pretrain_rec_decoder(emb_lh, ids_restore)
             reconstruct_loss = self.reconstruct_loss(reconstruct_pred, supp_data, mask)
             return (reconstruct_loss, emb_l1, emb_l2, emb_l3, emb_l4, emb_lh, coords_l1, coords_l2, coords_l3, coords_l4,
                     reconstruct_pred, mask, ids_restore, attn)
         if is_rec:
             emb_l1, emb_l2, emb_lh, mask, ids_restore = self.backbone(events_voxel_grid, mask=True, noise=noise)
+            if self._backward_cut is not None:          # data-parallel step executor: decoder backward and encoder backward apart
+                emb_lh = self._backward_cut(emb_lh)
             reconstruct_pred = self.pretrain_rec_decoder(emb_lh, ids_restore)
             reconstruct_loss = self.reconstruct_loss(reconstruct_pred, supp_data, mask)
             return reconstruct_loss, emb_l1, emb_l2, emb_lh, reconstruct_pred, mask, ids_restore

@@ -39,8 +39,14 @@ class OverlappedPlan:
     chunk's all-reduce is exposed. The small gradients autograd produced inside the graph go through the packed bucket
     first."""
 
-    def __init__(self, steps, others, bucket, views, group, two_streams=True):
+    def __init__(self, steps, others, bucket, views, group, two_streams=True, early_steps=()):
+        """`early_steps`: weight-gradient launches whose operands are complete before the rest of the backward has run -- the
+        DECODER's, once the step executor has cut the backward at the encoder / decoder boundary (engine.BackwardCut). run_early()
+        launches them and their all-reduces on a side stream; the caller then replays the encoder's backward on the main stream,
+        so these buffers cross xGMI under ~3 ms of compute instead of competing for the step's tail."""
         self.steps, self.others, self.bucket, self.views, self.group = steps, others, bucket, views, group
+        self.early_steps = list(early_steps)
+        self._early_works, self._early_done = [], False
         self.srcs = [p.grad for p in others]
         for p, v in zip(others, views):
             p.grad = v
@@ -62,16 +68,55 @@ class OverlappedPlan:
             spans = [(f.data_ptr(), f.data_ptr() + f.numel() * f.element_size()) for f in flats]
             return [p for p in params if p.grad is not None and any(lo <= p.grad.data_ptr() < hi for lo, hi in spans)]
 
-        lists = [list(self.others)] + [owners(st.flats) for st in self.steps]
+        lists = [list(self.others)] + [owners(st.flats) for st in self.early_steps] + [owners(st.flats) for st in self.steps]
         self.n_parts = opt.build_parts(lists)
         self.opt, self.update_stream = opt, torch.cuda.Stream()
         return True
 
+    def run_early(self):
+        """After the forward + decoder-backward graph: the early weight-gradient launches and their all-reduces (and, with the
+        optimizer attached, the update of their parameters) on side streams. Returns at once; run() joins."""
+        self._early_works, self._early_done = [], True
+        if not self.early_steps:
+            return
+        if self.streams is None:
+            for st in self.early_steps:
+                st.run()
+                for f in st.flats:
+                    self._early_works.append(dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        cur = torch.cuda.current_stream()
+        side, upd = self.streams[1], self.update_stream
+        side.wait_stream(cur)
+        if upd is not None:
+            upd.wait_stream(cur)                      # this step's lr / bias-correction tables are on the device
+        for k, st in enumerate(self.early_steps):
+            mine = []
+            with torch.cuda.stream(side):
+                st.run()
+                for f in st.flats:
+                    mine.append(dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._early_works += mine
+            if upd is not None:
+                with torch.cuda.stream(upd):
+                    for w in mine:
+                        w.wait()
+                    if not mine:
+                        upd.wait_stream(side)
+                    self.opt.launch_part(1 + k)
+
     def run(self):
-        works = []
+        if self.early_steps and not self._early_done:
+            self.run_early()                          # a caller without a split backward: everything after the one graph
+        self._early_done = False
+        works = list(self._early_works)
+        self._early_works = []
+        n_early = len(self.early_steps)
+        bucket_work = None
         if self.others:
             torch._foreach_copy_(self.views, self.srcs)
-            works.append(dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            bucket_work = dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            works.append(bucket_work)
         if self.streams is None:
             for st in self.steps:
                 st.run()
@@ -84,11 +129,11 @@ class OverlappedPlan:
             upd = self.update_stream
             if upd is not None:
                 upd.wait_stream(cur)                  # this step's lr / bias-correction tables are on the device
-                if works:
+                if bucket_work is not None:
                     with torch.cuda.stream(upd):
-                        works[0].wait()
+                        bucket_work.wait()
                         self.opt.launch_part(0)
-            prev_round, k = None, 0
+            prev_round, k = None, n_early
             for st in self.steps:
                 r = getattr(st, "round", 0)
                 if prev_round is not None and r != prev_round:      # a later round accumulates onto the earlier one's results
@@ -185,11 +230,12 @@ class BucketedGradReducer:
         """Eager mode: call after every backward. All-reduces (SUM) every gradient, waits on the current stream."""
         _Plan(*self._collect(), self.group).run()
 
-    def make_overlapped_plan(self, n_chunks=4):
-        """HIP-graph mode with overlap: call once after a forward+backward captured under ops.hold_deferred_grads(True)."""
+    def make_overlapped_plan(self, n_chunks=4, early_steps=()):
+        """HIP-graph mode with overlap: call once after a forward+backward captured under ops.hold_deferred_grads(True).
+        `early_steps`: ops.build_deferred_plan(...) of what an earlier part of a split backward queued (OverlappedPlan)."""
         from . import ops
         steps = ops.build_deferred_plan(n_chunks)
-        if any(getattr(st, "round", 0) != 0 for st in steps):
+        if any(getattr(st, "round", 0) != 0 for st in list(steps) + list(early_steps)):
             # a parameter with several contributions per backward (rec+con) would be all-reduced before its later rounds
             raise RuntimeError("overlapped data-parallel plan: parameters with more than one gradient contribution per step "
                                "are not supported; use the eager reducer (BucketedGradReducer.finish)")
@@ -202,7 +248,7 @@ class BucketedGradReducer:
             bucket = torch.zeros(sum(sizes), dtype=torch.float32, device=others[0].device)
             offs = [sum(sizes[:i]) for i in range(len(sizes))]
             views = [bucket[o:o + p.numel()].view_as(p) for o, p in zip(offs, others)]
-        return OverlappedPlan(steps, others, bucket, views, self.group)
+        return OverlappedPlan(steps, others, bucket, views, self.group, early_steps=early_steps)
 
     def make_static_plan(self):
         """HIP-graph mode: call once after the captured backward; the returned plan's run() reduces the same buffers

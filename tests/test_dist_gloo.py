@@ -140,8 +140,33 @@ def _overlapped_plan_streamless(rank):
     plan = OverlappedPlan([mk(0, 0), mk(1, 0)], [p1, p2], bucket, views, None, two_streams=False)
     assert plan.streams is None
     plan.run()
-    return {"plan_log": log, "plan_flats": [f[0].item() for f in flats], "plan_small": [p1.grad[0].item(), p2.grad[0, 0].item()],
-            "plan_grad_is_view": p1.grad.data_ptr() == bucket.data_ptr()}
+    out = {"plan_log": list(log), "plan_flats": [f[0].item() for f in flats], "plan_small": [p1.grad[0].item(), p2.grad[0, 0].item()],
+           "plan_grad_is_view": p1.grad.data_ptr() == bucket.data_ptr()}
+    # split backward (engine.BackwardCut): an EARLY step -- the decoder's weight gradients -- is launched and all-reduced by
+    # run_early() before the rest of the backward; run() then does the remaining chunks and must not repeat it. A caller that
+    # never calls run_early() still gets every step exactly once.
+    early = torch.zeros(4)
+
+    def early_run():
+        log.append("e")
+        early.add_(float(rank + 1) * 7.0)
+
+    for call_early in (True, False):
+        del log[:]
+        for f in flats:
+            f.zero_()
+        early.zero_()
+        q1 = torch.nn.Parameter(torch.zeros(3))
+        q1.grad = torch.full((3,), float(rank + 1))
+        b2 = torch.zeros(64)
+        plan2 = OverlappedPlan([mk(0, 0), mk(1, 0)], [q1], b2, [b2[0:3].view_as(q1)], None, two_streams=False,
+                               early_steps=[SimpleNamespace(run=early_run, flats=[early], round=0)])
+        if call_early:
+            plan2.run_early()
+            log.append("|")                 # ... where the encoder's backward graph replays
+        plan2.run()
+        out["plan_early_%d" % int(call_early)] = ("".join(str(x) for x in log), early[0].item(), [f[0].item() for f in flats], q1.grad[0].item())
+    return out
 
 
 def _epoch_with_reducer(rank):
@@ -249,6 +274,9 @@ def test_world_size_2_gloo():
         assert res[r]["plan_log"] == [0, 1]
         assert res[r]["plan_flats"] == [3.0, 6.0]
         assert res[r]["plan_small"] == [3.0, 30.0] and res[r]["plan_grad_is_view"]
+        # early step first (before the point where the second backward graph replays), every buffer reduced once over the 2 ranks
+        assert tuple(res[r]["plan_early_1"]) == ("e|01", 21.0, [3.0, 6.0], 3.0), res[r]["plan_early_1"]
+        assert tuple(res[r]["plan_early_0"]) == ("e01", 21.0, [3.0, 6.0], 3.0), res[r]["plan_early_0"]
     # epoch loop with the reducer: identical weights on both ranks, equal to the single-process mean-gradient run
     assert res[0]["epoch_w"] == pytest.approx(res[1]["epoch_w"], abs=0)
     assert res[0]["epoch_w"] == pytest.approx(res[0]["epoch_ref_w"], rel=1e-5, abs=1e-6)
