@@ -387,12 +387,17 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python each step (no HIP graph)")
     ap.add_argument("--wgrad-chunks", type=int, default=4,
                     help="N > 1: weight-gradient launches per step (each chunk's buffer is all-reduced while the next computes)")
+    ap.add_argument("--gemm-variant", type=int, action="append", default=[],
+                    help="A/B aid: evp_gemm_set_variant codes applied before the model is built (11/12/13: G4 forward / data-gradient routing)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (process group, reducer, split graphs) even with one rank")
     args = ap.parse_args()
 
     from eventpretrain_amd import _lib
     _lib.require_device()
+    for v_ in args.gemm_variant:
+        _lib.call("evp_gemm_set_variant", v_)
+    GemmTimer.g4_fwd = 11 in args.gemm_variant
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn the per-kernel summaries that tools/gpu_round2_profile.sh leaves under gpurun_out/ into the committed profiles/rNN_* files:
+"""Turn the per-kernel summaries that tools/gpu_round3_profile.sh (round 2: gpu_round2_profile.sh) leaves under gpurun_out/ into the committed profiles/rNN_* files:
 kernel stats CSV (copied), pmc_traffic.json (gfx950 correction: reads x 2; the 128x128 / 96x128 forward + data-gradient family as a
 launch-weighted mean; the two voxel_bin launches of the verified mode summed per batch), SQ counter summary.
 usage: make_profiles.py [r02]"""
@@ -14,7 +14,7 @@ P = os.path.join(ROOT, "profiles")
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     t = json.load(open(os.path.join(G, "pmc_traffic_kernels.json")))
     v = json.load(open(os.path.join(G, "pmc_voxel_kernels.json")))
     sq = json.load(open(os.path.join(G, "pmc_sq_kernels.json")))
@@ -31,7 +31,7 @@ def main():
     if g4:
         k["gemm_g4_grouped_tn_kernel"] = ent(g4[0], "all weight gradients of the ViT-Base rec step in one launch (256x256 tiles, 4-stage ring of 32-k "
                                                     "stages); r01's ring body moved 11.69 GB per launch")
-    fam = [(n, x) for n, x in t.items() if n.startswith("gemm_kernel<") and ("128, 128" in n or "96, 128" in n)]
+    fam = [(n, x) for n, x in t.items() if (n.startswith("gemm_kernel<") and ("128, 128" in n or "96, 128" in n)) or n.startswith("g4x_kernel<")]
     L = sum(x["launches"] for _, x in fam)
     f = dict(fetch_kib_raw=sum(x["FETCH_SIZE"] * x["launches"] for _, x in fam) / L, write_kib=sum(x["WRITE_SIZE"] * x["launches"] for _, x in fam) / L,
              launches_averaged=L, note="launch-weighted mean over the %d instantiations of the forward / data-gradient body (128x128 and 96x128 tiles)" % len(fam))
@@ -53,7 +53,7 @@ def main():
                     "tools/pmc_kernels.py on the GPU box. Per MI355X_MICROARCH.md 'HBM': on gfx950 FETCH_SIZE tallies the 128-B requests of "
                     "16-B-per-lane loads at 64 B, so reads are doubled (traffic_bytes = (2 x fetch + write) x 1024); WRITE_SIZE is exact. "
                     "Infinity-Cache hits are included in these fabric-side counters.",
-               commands=["tools/gpu_round2_profile.sh (rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py "
+               commands=["tools/gpu_round3_profile.sh (rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py "
                          "--no-cpu-baseline --no-kernel-timing --steps 3 --warmup 2; same for tools/voxel_pmc.py)"], kernels=k)
     json.dump(out, open(os.path.join(P, tag + "_pmc_traffic.json"), "w"), indent=1)
     json.dump(dict(note="rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT "
@@ -62,7 +62,11 @@ def main():
               open(os.path.join(P, tag + "_pmc_sq_kernels.json"), "w"), indent=1)
     shutil.copy(os.path.join(G, "pmc_sq_kernels.txt"), os.path.join(P, tag + "_pmc_sq_kernels.txt"))
     shutil.copy(os.path.join(G, "pmc_traffic_kernels.txt"), os.path.join(P, tag + "_pmc_traffic_kernels.txt"))
-    shutil.copy(os.path.join(G, "prof_r2_stats", "r2_kernel_stats.csv"), os.path.join(P, tag + "_bench_kernel_stats.csv"))
+    st = "r3" if tag >= "r03" else "r2"
+    shutil.copy(os.path.join(G, "prof_%s_stats" % st, "%s_kernel_stats.csv" % st), os.path.join(P, tag + "_bench_kernel_stats.csv"))
+    for extra, name in (("prof_r3_check.txt", "_roofline_check.txt"), (os.path.join("prof_r3_stats", "r3_memory_copy_stats.csv"), "_bench_memory_copy_stats.csv")):
+        if st == "r3" and os.path.exists(os.path.join(G, extra)):
+            shutil.copy(os.path.join(G, extra), os.path.join(P, tag + name))
     for n in ("gemm_g4_grouped_tn_kernel", "gemm_kernel<", "voxel_bin_kernel"):
         if n in k:
             print(n, round(k[n]["traffic_bytes"] / 1e6, 1), "MB")
