@@ -17,6 +17,11 @@ static int g_gemm_variant = 1;
 // they lose -- same-box A/B (tools/ab_step.py, ViT-Base rec, 3 x 15 steps): all off 11.17 ms, 256x256 forward only 11.20, 128x256
 // data gradients only 11.31, both 11.31. The tiles stay selectable (evp_gemm_desc::tile 20-22).
 static int g_gemm_g4_fwd = 0;
+// (Round 3, measured and removed again -- tools/gemm_rounds_probe.py, DESIGN.md section 4 "rounds":
+//  * the rows beyond the last whole round of 512 tiles as 64x64 tiles on a forked stream: bit-identical, but the fork / join pair costs
+//    more inside a captured graph than the partial round it saves (enc.fc1 48.0 -> 56.4 us, dec.dfc2 57.5 -> 61.7; step 11.34 -> 11.68 ms);
+//  * the second workgroup of a CU starting half a tile period late, so that one computes while the other writes: every launch got
+//    slower by exactly the delay (dec.dfc2 3 rounds 49.8 -> 55.0 us, 4 rounds 65.1 -> 70.3): the rounds themselves do not speed up.)
 static int g_gemm_dbg = 0;
 static unsigned long long *g_stamp_buf = nullptr;   // measurement aid, see gemm_common.h "in-kernel wall-clock stamps"
 static long long g_stamp_slots = 0, g_stamp_next = 0;

@@ -314,6 +314,7 @@ class _DeferredGrads:
         self._capture_pins = []     # pinned tables owned by captured HIP graphs (never rewritten; see _stage)
         self.flat_buffers = []      # flat f32 buffers holding the gradients written by the last flush(es)
         self._flat_consumer = None  # weakref to the data-parallel reducer: without a live consumer the list must not grow
+        self.join_streams = []      # side streams that ran part of the backward (split-batch step): flush() waits for them
 
     def track_flats(self):
         c = self._flat_consumer
@@ -384,6 +385,8 @@ class _DeferredGrads:
         self.armed = False
         if self.hold:
             return
+        for s_ in self.join_streams:
+            torch.cuda.current_stream().wait_stream(s_)
         if self.flat_buffers and not self.track_flats():
             self.flat_buffers = []          # leftovers of a reducer that is gone
         for st in self._build(n_chunks=1, static=False):

@@ -27,6 +27,8 @@ VARIANTS = {
     "g4fwd256": {"_variant": 12},           # only the one-round 256x256 forward tiles (encoder qkv)
     "g4dgrad": {"_variant": 13},            # only the 128x256 data-gradient tiles (fc2 data gradient with GELU')
     "no96": {"_no96": True},                  # 128x128 tiles where the launcher would pick 96x128 (257..384 tiles)
+    "split2": {"_split": 2},                 # two half-batches on two streams inside the captured step (kernels of one half fill the other's tails)
+    "split4": {"_split": 4},
     "noguard": {"_guard_tables": False},     # host free to run ahead (the scalar-table race the guard closes)
 }
 
@@ -62,10 +64,35 @@ def build(B, cfg):
     x = torch.randn(B, 5, 224, 224, device="cuda") * 0.5
     y = torch.randn(B, 1, 224, 224, device="cuda")
     fwd = lambda mm, xx, yy, noise: mm(xx, yy, is_rec=True, noise=noise)
+    n_split = cfg.get("_split", 1)
+    if n_split > 1:
+        sides = [torch.cuda.Stream() for _ in range(n_split - 1)]
+        ops._deferred.join_streams = sides
+
+        def fwd(mm, xx, yy, noise):
+            cur = torch.cuda.current_stream()
+            h = xx.shape[0] // n_split
+            losses = []
+            for s_ in sides:
+                s_.wait_stream(cur)           # fork BEFORE anything of this step is queued on the main stream
+            for i in range(n_split):
+                sl = slice(i * h, (i + 1) * h)
+                if i == 0:
+                    losses.append(mm(xx[sl], yy[sl], is_rec=True, noise=noise[sl])[0])
+                else:
+                    with torch.cuda.stream(sides[i - 1]):
+                        losses.append(mm(xx[sl], yy[sl], is_rec=True, noise=noise[sl])[0])
+            for s_ in sides:
+                cur.wait_stream(s_)
+            tot = losses[0]
+            for l_ in losses[1:]:
+                tot = tot + l_
+            return (tot / n_split,)
     ex = GraphedStep(m, opt, fwd, [x, y], noise_shape=(B, 196), generator=torch.Generator(device="cuda").manual_seed(1), warmup=3)
     assert ex.note.startswith("hip-graph"), ex.note
     ex.guard_tables = cfg.get("_guard_tables", True)
     ops.gemm = _orig_gemm
+    ops._deferred.join_streams = []
     apply({})
     call("evp_gemm_set_variant", 10)
     return ex
