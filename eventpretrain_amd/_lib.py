@@ -10,7 +10,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libevtpretrain.so")
+LIB_PATH = os.environ.get("EVP_LIB") or os.path.join(_HERE, "libevtpretrain.so")     # EVP_LIB: another build of the same ABI (A/B runs)
 CSRC = os.path.join(_HERE, "csrc")
 
 EVP_F32, EVP_BF16 = 0, 1
@@ -43,6 +43,7 @@ SIGNATURES = {
     "evp_gemm_grouped_tn_g4_bf16": [_vp, _vp, _i, _vp],
     "evp_sum_slices_f32": [_vp, _vp, _i, _i64, _i, _vp],
     "evp_gemm_set_variant": [_i],
+    "evp_voxel_set_debug": [_i],
     "evp_gemm_set_stamp_buffer": [_vp, C.c_longlong],
     "evp_gemm_stamp_count": [],
     "evp_attention_set_debug_buffer": [_vp],
@@ -113,7 +114,7 @@ SIGNATURES = {
     "evp_abi_version": [],
 }
 _OTHER_RESTYPE = {"evp_last_error": C.c_char_p, "evp_target_arch": C.c_char_p}
-_NO_STATUS = {"evp_dwconv5x5_bwd_nslab", "evp_gemm_set_variant", "evp_gemm_stamp_count", "evp_attention_fused_supported", "evp_layernorm_bwd_nblk", "evp_colsum_nblk", "evp_batchnorm_nblk", "evp_abi_version",
+_NO_STATUS = {"evp_dwconv5x5_bwd_nslab", "evp_gemm_set_variant", "evp_voxel_set_debug", "evp_gemm_stamp_count", "evp_attention_fused_supported", "evp_layernorm_bwd_nblk", "evp_colsum_nblk", "evp_batchnorm_nblk", "evp_abi_version",
               "evp_window_attention_fused_np", "evp_window_attention_fused_nchunk"}
 
 _lib = None

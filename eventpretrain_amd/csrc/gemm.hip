@@ -386,7 +386,14 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[MI][NI], const GemmP
 // pre-activation of a GELU' data gradient, cold in the replayed step -- before the K loop and holding them in registers through it,
 // 64 VGPRs at two workgroups per CU. The launches that read such operands run 15-25 % slower in the step than re-launched on warm
 // caches, the others 2-10 %; same-box A/B of the prefetch: 11.471 against 11.454 ms per ViT-Base step -- nothing. The loads are
-// older than the first K tile's LDS-DMA, so the first counted vmcnt waits for them: the latency moves, it does not disappear.)
+// older than the first K tile's LDS-DMA, so the first counted vmcnt waits for them: the latency moves, it does not disappear.
+// Also round 3: requesting the read operands of ALL sixteen rows of a thread at the top of the epilogue instead of four rows per trip
+// (fully unrolled, 2 waves per SIMD pinned): per-workgroup epilogue 6.27 against 6.43 us (GELU'), 3.43 against 3.45 (f32 + residual),
+// step 11.47-11.58 against 11.43-11.46 ms -- the epilogue is not a chain of dependent round trips either. What it is: a chip-wide
+// burst. tools/native/tile_store_probe.hip replays just the memory pattern of a round of 512 tiles behind an 8 us stand-in for the K loop:
+// +2.4 us per round for the bf16 tile store (16.8 MB at 7 TB/s), +3.6 for two tensors, +5.1..6.7 for load + store, +11.4 for the f32
+// load + store -- the same figures the GEMM pays (2.0 / 5.0 / 6.4 / 3.5 us per workgroup, tools/gemm_epilogue_probe.py); 8- and 16-byte
+// pieces per lane cost the same.)
 template <typename TC, int EPI, int BM, int BN, int NT, bool RES, bool ACC, bool AUXST>
 __device__ __forceinline__ void epilogue_lds_rows(const float4 *tile, const GemmParams &p, int64_t coff, int m0, int n, int ch, int r0, float4 bias4,
                                                   bool fast) {
@@ -649,6 +656,9 @@ __device__ __forceinline__ void gemm_body(const GemmParams &p, const int tile_m,
   }
 
   // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + (lane>>4)*4
+  if (p.dbg == 3 && p.stamp && tid == 0 && gridDim.x * gridDim.y * gridDim.z <= (unsigned)EVP_STAMP_WGS)   // measurement aid: the start
+    p.stamp[2 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z))] =                           // stamp moves to the end of the K loop
+        ~(unsigned long long)__builtin_amdgcn_s_memrealtime();
   const int64_t coff = b0 * p.sC0 + b1 * p.sC1;
   const int li = lane & 15, lg = lane >> 4;
   if constexpr (STAGES * (A_BYTES + B_BYTES) >= BM * BN * 4 && EPI == 0 && sizeof(TC) == 4) {
@@ -889,7 +899,7 @@ extern "C" long long evp_gemm_stamp_count(void) { return g_stamp_next; }
 
 extern "C" int evp_gemm_set_variant(int v) {
   const int old = g_gemm_variant;
-  if (v >= 100 && v <= 102) g_gemm_dbg = v - 100;
+  if (v >= 100 && v <= 103) g_gemm_dbg = v - 100;
   if (v == 1 || v == 2) g_gemm_variant = v;
   if (v >= 10 && v <= 13) g_gemm_g4_fwd = v == 11 ? 3 : v == 10 ? 0 : v - 11;     // 10 off (default), 11 on, 12 = 256x256 only, 13 = 128x256 only
   return old;

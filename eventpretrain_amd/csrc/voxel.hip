@@ -118,16 +118,25 @@ __device__ __forceinline__ bool in_safe_range(double v) {
 //   j = 1..bins-2: plane j over R_(j-1) then R_j for odd j, R_j then R_(j-1) for even j (rows ascending in both)
 // so that, for odd `bins`, the two planes that need a region stream it during the same half of their lifetime and the
 // second reader finds the rows in the XCD's L2 instead of fetching them again (all blocks of a clip share an XCD).
-template <bool TXYP>
+// CELL: the accumulator type of the LDS tile: float (default) or double (algo 3, A/B). Round 3 found `ds_add_f32` to serialise its lanes
+// on gfx950 (3 cycles per lane, 192 per full wave instruction; `ds_add_f64` ~22, `ds_add_u32` ~8 per wave instruction;
+// tools/native/lds_atomic_probe.hip: 197 / 1431 / 2992 G lane-adds/s chip-wide) and SQ_LDS_IDX_ACTIVE at 74 % of this kernel's cycles --
+// yet the atomics are NOT what the kernel waits for: without them it runs 101 -> 93 us, and with f64 cells (three y-tiles instead of two
+// at 224 x 224, i.e. 6 instead of 4 visits per row) 124 us. What it does wait for is the rows themselves: "rows only loaded" is 76 of the
+// 101 us (tools/voxel_parts.py) -- 820 MB through the L1s at 11 TB/s, 70 % of what the eight L2s deliver.
+template <bool TXYP, typename CELL, bool DBG>
 __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *events, const int64_t *offsets, const int64_t *cuts,
                                                                int n_clips, int bins, int H, int W, int mode, int tile_rows,
-                                                               int n_yt, double sx, double sy, float *out, int32_t *flags) {
+                                                               int n_yt, double sx, double sy, float *out, int32_t *flags, int dbg_arg) {
+  const int dbg = DBG ? dbg_arg : 0;          // the measurement build is a separate instantiation: the product kernel carries no test
+  // dbg (measurement aid, evp_voxel_set_debug; results are garbage when set): 1 = no LDS atomics, 2 = no time normalisation (every row
+  // in the tile adds 1), 3 = rows are only loaded
   // mode 0: any row order (every block scans its whole clip); 1: sorted stamps promised (slabs between the cuts);
   // 2: as 1, but every row that is normalised is checked to lie in the region its POSITION says (floor(ts) == k for a row
   //    of slab [cuts[k], cuts[k+1])) -- the only property of sortedness the slab schedule uses -- and flags[clip] is
   //    cleared otherwise; 3: repair pass = mode 0 for the clips whose flag is 0, nothing for the others.
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float *tile = reinterpret_cast<float *>(smem_raw);
+  CELL *tile = reinterpret_cast<CELL *>(smem_raw);
   const int n_j = bins > 1 ? bins - 1 : 1;
   const int per_clip = n_j * n_yt;
   int clip, sub;
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *eve
     const bool swapped = (j > 0) && ((j & 1) == 0);
     const double bd = (double)b;
     if (job) __syncthreads();  // the previous plane's flush has read the tile
-    for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) tile[i] = 0.f;
+    for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) tile[i] = (CELL)0;
     __syncthreads();
     if (n > 0) {
       // sorted: only rows with floor(ts) in {b-1, b} can touch plane b -- two regions, each walked upward, the upper
@@ -177,6 +186,9 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *eve
         const int64_t lo = assume_sorted ? (upper ? cc[b] : cc[b > 0 ? b - 1 : 0]) : 0;
         const int64_t hi = assume_sorted ? (upper ? cc[b + 1] : cc[b]) : n;
         const double region = upper ? bd : bd - 1.0;      // floor(ts) of every row of this slab if the stamps are sorted
+        // (Round 3, measured and removed: reading each 64-row block with two fully coalesced instructions -- lane l takes the 16 bytes at
+        // 16 l, then at 1024 + 16 l -- and swapping the halves between lane pairs by DPP. Half the cache-line accesses per instruction, yet
+        // slower: rows only loaded 84 against 76 us, whole kernel 124 against 101 us; tools/voxel_parts.py.)
         for (int64_t k0 = threadIdx.x; k0 < hi - lo; k0 += (int64_t)VB_THREADS * VB_UNROLL) {
           double2 ra[VB_UNROLL], rb[VB_UNROLL];
           bool live[VB_UNROLL];
@@ -192,12 +204,14 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *eve
           for (int u = 0; u < VB_UNROLL; ++u) {
             const double x = (TXYP ? ra[u].y : ra[u].x) * sx, y = (TXYP ? rb[u].x : ra[u].y) * sy;
             const double t = TXYP ? ra[u].x : rb[u].x, pd = rb[u].y;
+            if (dbg == 3) { if (x == 1.2345e300 && pd == t) inconsistent = true; continue; }
             int64_t pix;
             if (__builtin_fabs(x) < 2147483648.0 && __builtin_fabs(y) < 2147483648.0)
               pix = (int64_t)(int)x + (int64_t)(int)y * (int64_t)W;  // same truncation as the int64 conversion below
             else
               pix = (int64_t)x + (int64_t)y * (int64_t)W;
             if (!live[u] || pix < pix0 || pix >= pix1) continue;
+            if (dbg == 2) { atomicAdd(&tile[pix - pix0], (CELL)1); continue; }
             const double a = scale * (t - t0);
             const double ts = (clip_fast && in_safe_range(a)) ? div_by_clip_constant(a, dT, rT) : a / dT;
             const double tf = floor(ts);
@@ -210,7 +224,8 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *eve
             if (tf == bd) val = p * (1.0f - dt);          // left neighbour, valid since b < bins
             else if (tf + 1.0 == bd) val = p * dt;         // right neighbour
             else continue;
-            atomicAdd(&tile[pix - pix0], val);
+            if (dbg == 1) { if (val == 1.2345e30f) inconsistent = true; continue; }
+            atomicAdd(&tile[pix - pix0], (CELL)val);
           }
         }
       }
@@ -219,9 +234,9 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *eve
     float *dst = out + (((int64_t)clip * bins + b) * H + y0) * W;
     if ((W & 3) == 0) {
       for (int i = threadIdx.x; i < tile_elems / 4; i += VB_THREADS)
-        reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(tile)[i];
+        reinterpret_cast<float4 *>(dst)[i] = make_float4((float)tile[4 * i], (float)tile[4 * i + 1], (float)tile[4 * i + 2], (float)tile[4 * i + 3]);
     } else {
-      for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) dst[i] = tile[i];
+      for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) dst[i] = (float)tile[i];
     }
   }
   if (inconsistent) flags[clip] = 0;       // every writer stores 0: no atomic needed
@@ -361,6 +376,9 @@ __global__ __launch_bounds__(256) void sorted_check_kernel(const double *events,
 
 }  // namespace
 
+static int g_voxel_dbg = 0;
+extern "C" int evp_voxel_set_debug(int v) { const int old = g_voxel_dbg; g_voxel_dbg = v; return old; }
+
 extern "C" int evp_voxel_scatter_scaled_f32(const double *events, const int64_t *clip_offsets, int n_clips, int64_t n_events_total,
                                             int bins, int H, int W, int is_txyp, int assume_sorted, int algo, int tile_rows,
                                             double scale_x, double scale_y, int64_t *workspace, float *out, void *stream) {
@@ -377,21 +395,24 @@ extern "C" int evp_voxel_scatter_scaled_f32(const double *events, const int64_t 
     EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(atomic)");
     return EVP_OK;
   }
-  EVP_CHECK_ARG(algo == 0 || algo == 2, EVP_EINVAL, "evp_voxel_scatter_f32: unknown algo %d", algo);
+  EVP_CHECK_ARG(algo == 0 || algo == 2 || algo == 3, EVP_EINVAL, "evp_voxel_scatter_f32: unknown algo %d", algo);
+  const bool f64_cells = algo == 3;                 // algo 3: float64 cells in the LDS tile (A/B; see voxel_bin_kernel)
+  const size_t cell = f64_cells ? sizeof(double) : sizeof(float);
   EVP_CHECK_ARG(workspace, EVP_EINVAL, "evp_voxel_scatter_f32: workspace required for the LDS-binned algorithms");
   EVP_CHECK_ARG(algo != 2 || (n_events_total > 0 && (int64_t)H * W <= (1 << 24)), EVP_ESHAPE,
                 "evp_voxel_scatter_f32: algo 2 needs n_events_total and H*W <= 2^24");
   if (tile_rows <= 0) {
-    const int max_rows = (100 * 1024) / (W * 4);  // <= 100 KiB of LDS: big tiles halve the slab re-reads (measured best)
+    // f32 cells: <= 100 KiB of LDS (big tiles halve the slab re-reads; measured best); f64 cells: <= 150 KiB, three y-tiles at 224 x 224
+    const int max_rows = (int)(((f64_cells ? 150 : 100) * 1024) / ((size_t)W * cell));
     tile_rows = max_rows < 1 ? 1 : (max_rows > H ? H : max_rows);
     const int nyt = (H + tile_rows - 1) / tile_rows;
     tile_rows = (H + nyt - 1) / nyt;  // balance the tiles
   }
-  EVP_CHECK_ARG((size_t)tile_rows * W * 4 <= 160 * 1024, EVP_ESHAPE, "evp_voxel_scatter_f32: tile of %d rows x %d exceeds LDS", tile_rows, W);
+  EVP_CHECK_ARG((size_t)tile_rows * W * cell <= 160 * 1024, EVP_ESHAPE, "evp_voxel_scatter_f32: tile of %d rows x %d exceeds LDS", tile_rows, W);
   const int n_yt = (H + tile_rows - 1) / tile_rows;
-  const size_t smem = (size_t)tile_rows * W * sizeof(float);
+  const size_t smem = (size_t)tile_rows * W * (algo == 2 ? sizeof(float) : cell);
   EVP_CHECK_ARG(assume_sorted >= 0 && assume_sorted <= 2, EVP_EINVAL, "evp_voxel_scatter_f32: assume_sorted must be 0, 1 or 2");
-  EVP_CHECK_ARG(assume_sorted != 2 || algo == 0, EVP_EUNSUPPORTED, "evp_voxel_scatter_f32: the verified mode (assume_sorted = 2) is built for algo 0");
+  EVP_CHECK_ARG(assume_sorted != 2 || algo == 0 || algo == 3, EVP_EUNSUPPORTED, "evp_voxel_scatter_f32: the verified mode (assume_sorted = 2) is built for algo 0 / 3");
   int32_t *flags = assume_sorted == 2 ? reinterpret_cast<int32_t *>(workspace + (int64_t)n_clips * (bins + 2)) : nullptr;
   if (assume_sorted) {
     hipLaunchKernelGGL(voxel_cuts_kernel, dim3(n_clips), dim3(512), 0, s, events, clip_offsets, bins, is_txyp, workspace, flags);
@@ -412,20 +433,20 @@ extern "C" int evp_voxel_scatter_scaled_f32(const double *events, const int64_t 
     EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(bin packed)");
     return EVP_OK;
   }
+  auto kern = f64_cells ? (is_txyp ? voxel_bin_kernel<true, double, false> : voxel_bin_kernel<false, double, false>)
+                        : (is_txyp ? voxel_bin_kernel<true, float, false> : voxel_bin_kernel<false, float, false>);
+  if (g_voxel_dbg)
+    kern = f64_cells ? (is_txyp ? voxel_bin_kernel<true, double, true> : voxel_bin_kernel<false, double, true>)
+                     : (is_txyp ? voxel_bin_kernel<true, float, true> : voxel_bin_kernel<false, float, true>);
   if (smem > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(is_txyp ? voxel_bin_kernel<true> : voxel_bin_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_voxel_scatter_f32: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
   }
   const int n_blocks = n_clips * (bins > 1 ? bins - 1 : 1) * n_yt;  // plane 0 and plane bins-1 share a workgroup
   for (int pass = 0; pass < (assume_sorted == 2 ? 2 : 1); ++pass) {
     const int mode = pass ? 3 : assume_sorted;      // verified mode: fast pass, then the repair pass for flagged clips
-    if (is_txyp)
-      hipLaunchKernelGGL(voxel_bin_kernel<true>, dim3(n_blocks), dim3(VB_THREADS), smem, s, events, clip_offsets, workspace, n_clips, bins,
-                         H, W, mode, tile_rows, n_yt, scale_x, scale_y, out, flags);
-    else
-      hipLaunchKernelGGL(voxel_bin_kernel<false>, dim3(n_blocks), dim3(VB_THREADS), smem, s, events, clip_offsets, workspace, n_clips, bins,
-                         H, W, mode, tile_rows, n_yt, scale_x, scale_y, out, flags);
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(VB_THREADS), smem, s, events, clip_offsets, workspace, n_clips, bins, H, W, mode, tile_rows,
+                       n_yt, scale_x, scale_y, out, flags, g_voxel_dbg);
     EVP_CHECK_LAUNCH("evp_voxel_scatter_f32(bin)");
   }
   return EVP_OK;

@@ -33,7 +33,7 @@ def voxel_grid_batch(events, clip_offsets, num_bins, size, is_txyp=False, assume
     if assume_sorted == "trust":
         mode = 1
     else:
-        mode = (2 if algo == 0 else 1) if assume_sorted else 0
+        mode = (2 if algo in (0, 3) else 1) if assume_sorted else 0
     # cuts [n_clips][bins + 2] int64, then the larger of the decode-once records (algo 2) and the verified mode's per-clip int32
     # flags -- with many empty / tiny clips (n_total << n_clips) the flags are the larger part
     ws = torch.empty(n_clips * (num_bins + 2) + max((3 * n_total + 1) // 2 + 2, (n_clips + 1) // 2), dtype=torch.int64, device=dev)

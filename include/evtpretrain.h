@@ -41,13 +41,15 @@ const char *evp_target_arch(void);
  * [clip_offsets[c], clip_offsets[c+1]). out: float32 [n_clips,bins,H,W], fully overwritten.
  * assume_sorted == 1: rows of each clip are non-decreasing in t (what every reference dataset produces; the
  * reference itself relies on it for t0/t1, :19-22) -> each block scans only its time slab; NOT checked.
- * assume_sorted == 2 (algo 0): the same fast path, VERIFIED on the device with no host sync: while binning, every row is
+ * assume_sorted == 2 (algo 0 / 3): the same fast path, VERIFIED on the device with no host sync: while binning, every row is
  * checked to lie in the time slab its position says (the one property of sortedness the slab schedule uses); clips that
  * fail are redone by a repair pass that scans the whole clip, the others cost one extra empty launch. The result is the
  * reference's for any row order. workspace then also holds int32 [n_clips] flags after the cuts.
  * assume_sorted == 0: correct for any row order (every block scans the whole clip).
  * n_events_total = clip_offsets[n_clips] (known to the host that built the offsets).
- * algo 0 (default) = single-pass LDS-binned straight from the float64 rows, workspace int64 [n_clips*(bins+2) + (n_clips+1)/2].
+ * algo 0 (default) = single-pass LDS-binned straight from the float64 rows, workspace int64 [n_clips*(bins+2) + (n_clips+1)/2];
+ * algo 3 = the same with float64 cells in the LDS tile (`ds_add_f64`; an order-independent sum rounded to float32 once; three y-tiles
+ * instead of two at 224 x 224: measured 1.2x slower, kept for A/B).
  * algo 2 = decode-once two-pass form: pass A packs every event into 12 bytes (pixel/bin key + the two float32
  * contributions), pass B bins the packed streams; workspace int64 [n_clips*(bins+2) + (3*n_events_total + 1)/2]
  * (measured 1.3x slower than algo 0 on MI355X; kept for A/B). algo 1 = memset + global float atomics, no workspace
@@ -56,6 +58,9 @@ const char *evp_target_arch(void);
 int evp_voxel_scatter_f32(const double *events, const int64_t *clip_offsets, int n_clips, int64_t n_events_total, int bins,
                           int H, int W, int is_txyp, int assume_sorted, int algo, int tile_rows, int64_t *workspace,
                           float *out, void *stream);
+/* Measurement aid (tools/voxel_parts.py): 1 = no LDS atomics, 2 = no time normalisation, 3 = rows are only loaded; results are garbage
+ * while set. Returns the previous value; 0 = off. */
+int evp_voxel_set_debug(int v);
 /* The same with the loader's sensor -> input rescale fused in (reference dataset/augmentation/events_augment.py:22-26,
  * `events[:,0] *= input_w/sensor_w; events[:,1] *= input_h/sensor_h`, applied by pr_n_imagenet_dataset.py:85-86 between
  * the event-level augmentation and the voxelisation): x and y are multiplied by scale_x / scale_y in float64 before

@@ -16,6 +16,7 @@ out = torch.empty(B, 5, 224, 224, device="cuda")
 ref = voxel_grid_batch(ev, off, 5, (224, 224), algo=1).clone()
 bytes_ = B * (n * 32 + 5 * 224 * 224 * 4)
 for label, kw in [("single-pass auto", {}), ("single-pass 112", dict(tile_rows=112)), ("single-pass 75", dict(tile_rows=75)), ("single-pass 56", dict(tile_rows=56)),
+                  ("single-pass trust", dict(assume_sorted="trust")), ("f64 cells auto", dict(algo=3)), ("f64 cells 56", dict(algo=3, tile_rows=56)),
                   ("packed auto", dict(algo=2)), ("packed tile 56", dict(algo=2, tile_rows=56)),
                   ("global atomics", dict(algo=1)), ("single-pass unsorted", dict(assume_sorted=False))]:
     for _ in range(3): voxel_grid_batch(ev, off, 5, (224, 224), out=out, **kw)
@@ -24,4 +25,4 @@ for label, kw in [("single-pass auto", {}), ("single-pass 112", dict(tile_rows=1
     for _ in range(20): voxel_grid_batch(ev, off, 5, (224, 224), out=out, **kw)
     e1.record(); torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / 20 * 1e-3
-    print(f"{label:16s} {t*1e6:8.1f} us  {bytes_/t/1e9:8.1f} GB/s  max|diff vs atomics| {(out-ref).abs().max().item():.2e}")
+    print(f"{label:20s} {t*1e6:8.1f} us  {bytes_/t/1e9:8.1f} GB/s  max|diff vs atomics| {(out-ref).abs().max().item():.2e}")
