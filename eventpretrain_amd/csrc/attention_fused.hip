@@ -554,9 +554,12 @@ __global__ __launch_bounds__(256) void win_bias_build_kernel(const float *__rest
 // N x N pairs), the table privatised in LDS, at most R global atomics per workgroup (dtable zeroed by the launcher)
 __global__ __launch_bounds__(256) void win_bias_reduce_kernel(const float *__restrict__ dA, const int32_t *__restrict__ rel, float *__restrict__ dtable,
                                                               int N, int NP, int H, int R, int nchunk, int nplanes) {
-  extern __shared__ float tab[];
+  // float64 cells: `ds_add_f32` serialises its lanes on gfx950 (3 cycles each), `ds_add_f64` does not (tools/native/lds_atomic_probe.hip),
+  // and this table takes every add of the workgroup on R <= 169 addresses. (Measured in the Swin-B step: 14.0 us per launch either way --
+  // the kernel is bound by reading the dA planes; the f64 table stays because its sum does not depend on the order of the adds.)
+  extern __shared__ double tab[];
   const int g = blockIdx.x / H, h = blockIdx.x % H;
-  for (int r = threadIdx.x; r < R; r += 256) tab[r] = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) tab[r] = 0.0;
   __syncthreads();
   // a thread takes 4 consecutive keys of one query row (16-byte loads of every chunk's plane); slices of the N x (NP / 4) pieces
   const int Q4 = NP / 4, total = N * Q4;
@@ -576,12 +579,12 @@ __global__ __launch_bounds__(256) void win_bias_reduce_kernel(const float *__res
     for (int u = 0; u < 4; ++u)
       if (j0 + u < N) {
         const int r = rrow[u];
-        if (r >= 0) atomicAdd(&tab[r], vv[u]);
+        if (r >= 0) atomicAdd(&tab[r], (double)vv[u]);
       }
   }
   __syncthreads();
   for (int r = threadIdx.x; r < R; r += 256) {
-    const float t = tab[r];
+    const float t = (float)tab[r];
     if (t != 0.f) unsafeAtomicAdd(dtable + (int64_t)r * H + h, t);
   }
 }
@@ -728,7 +731,7 @@ extern "C" int evp_window_bias_reduce(const float *dA, const int32_t *rel, int B
   EVP_CHECK_ARG(nchunk > 0, EVP_ESHAPE, "evp_window_bias_reduce: Bg must be a positive multiple of nG");
   int split = (256 + nG * heads - 1) / (nG * heads);          // ~256 workgroups
   if (split > 16) split = 16;
-  hipLaunchKernelGGL(win_bias_reduce_kernel, dim3((unsigned)(nG * heads), (unsigned)split), dim3(256), (size_t)R * sizeof(float), s, dA, rel, dtable, N,
+  hipLaunchKernelGGL(win_bias_reduce_kernel, dim3((unsigned)(nG * heads), (unsigned)split), dim3(256), (size_t)R * sizeof(double), s, dA, rel, dtable, N,
                      evp_window_attention_fused_np(N), heads, R, nchunk, nG * heads);
   EVP_CHECK_LAUNCH("evp_window_bias_reduce");
   return EVP_OK;
