@@ -29,6 +29,9 @@ VARIANTS = {
     "no96": {"_no96": True},                  # 128x128 tiles where the launcher would pick 96x128 (257..384 tiles)
     "split2": {"_split": 2},                 # two half-batches on two streams inside the captured step (kernels of one half fill the other's tails)
     "split4": {"_split": 4},
+    "split2s100": {"_split": 2, "_skew_us": 100},   # the second half starts (forward and backward) that much later: a GEMM of one half meets
+    "split2s200": {"_split": 2, "_skew_us": 200},   # a LayerNorm / attention kernel of the other instead of its own twin
+    "split2s400": {"_split": 2, "_skew_us": 400},
     "noguard": {"_guard_tables": False},     # host free to run ahead (the scalar-table race the guard closes)
 }
 
@@ -68,6 +71,18 @@ def build(B, cfg):
     if n_split > 1:
         sides = [torch.cuda.Stream() for _ in range(n_split - 1)]
         ops._deferred.join_streams = sides
+        skew_cycles = int(cfg.get("_skew_us", 0) * 2100)          # torch.cuda._sleep counts shader cycles (~2.1 GHz)
+
+        class Delay(torch.autograd.Function):                     # identity; its backward runs on the stream of its forward and spins first
+            @staticmethod
+            def forward(ctx, t):
+                return t.view_as(t)
+
+            @staticmethod
+            def backward(ctx, g):
+                if skew_cycles:
+                    torch.cuda._sleep(skew_cycles)
+                return g
 
         def fwd(mm, xx, yy, noise):
             cur = torch.cuda.current_stream()
@@ -81,7 +96,9 @@ def build(B, cfg):
                     losses.append(mm(xx[sl], yy[sl], is_rec=True, noise=noise[sl])[0])
                 else:
                     with torch.cuda.stream(sides[i - 1]):
-                        losses.append(mm(xx[sl], yy[sl], is_rec=True, noise=noise[sl])[0])
+                        if skew_cycles:
+                            torch.cuda._sleep(skew_cycles * i)
+                        losses.append(Delay.apply(mm(xx[sl], yy[sl], is_rec=True, noise=noise[sl])[0]))
             for s_ in sides:
                 cur.wait_stream(s_)
             tot = losses[0]
