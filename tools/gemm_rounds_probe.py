@@ -12,6 +12,11 @@ from eventpretrain_amd import ops  # noqa: E402
 from eventpretrain_amd._lib import ACT_DGELU, ACT_GELU  # noqa: E402
 
 ops.set_compute_dtype(torch.bfloat16)
+TILE = 0
+for v in list(sys.argv[1:]):
+    if v.startswith("tile="):
+        TILE = int(v[5:])
+        sys.argv.remove(v)
 for v in sys.argv[1:]:          # 101: the epilogue is skipped (what the K loops alone cost)
     from eventpretrain_amd._lib import call
     call("evp_gemm_set_variant", int(v))
@@ -29,11 +34,11 @@ for name, kind, N, K, Ms in [("dec.dfc2", "d", 2048, 512, (8192, 12288, 12544, 1
 
         def one():
             if kind == "f":
-                ops.gemm(a, w, c, M=M, N=N, K=K, bias=bias, tile=0)
+                ops.gemm(a, w, c, M=M, N=N, K=K, bias=bias, tile=TILE)
             elif kind == "g":
-                ops.gemm(a, w, c, M=M, N=N, K=K, bias=bias, act=ACT_GELU, aux=aux, tile=0)
+                ops.gemm(a, w, c, M=M, N=N, K=K, bias=bias, act=ACT_GELU, aux=aux, tile=TILE)
             else:
-                ops.gemm(a, wt, c, M=M, N=N, K=K, trans_b=True, ldb=N, act=ACT_DGELU, aux=aux, tile=0)
+                ops.gemm(a, wt, c, M=M, N=N, K=K, trans_b=True, ldb=N, act=ACT_DGELU, aux=aux, tile=TILE)
 
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):

@@ -17,8 +17,11 @@ __global__ __launch_bounds__(256) void tile_io(unsigned short *c, unsigned short
   const int tile = blockIdx.x, tm = tile / tiles_n, tn = tile % tiles_n;
   const int tid = threadIdx.x;
   if (spin) {                                       // stand-in for the K loop: keeps rounds apart like the GEMM does
+    // spin < 0: de-phased -- every second workgroup of the FIRST round (two land on a CU back to back: hwid_probe) computes 1.5 periods
+    int ticks = spin < 0 ? -spin : spin;
+    if (spin < 0 && blockIdx.x < 512 && ((blockIdx.x >> 3) & 1)) ticks += ticks / 2;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)spin) __builtin_amdgcn_s_sleep(8);
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(8);
   }
   if (tid == 0) smem[0] = 1;
   if constexpr (MODE == 0 || MODE == 2 || MODE == 4) {
@@ -84,13 +87,13 @@ int main() {
   const char *names[8] = {"bf16 store 8 B/lane", "bf16 store 16 B/lane", "2 x bf16 store 8 B", "2 x bf16 store 16 B", "bf16 load + store 8 B", "bf16 load + store 16 B",
                           "f32 store 16 B/lane", "f32 load + store 16 B"};
   for (int tiles : {256, 512, 1024, 2048})
-    for (int spin : {0, 800}) {
+    for (int spin : {0, 800, -800}) {
       float t[8];
       t[0] = run<0>(c, aux, cf, rf, N, tiles, spin); t[1] = run<1>(c, aux, cf, rf, N, tiles, spin);
       t[2] = run<2>(c, aux, cf, rf, N, tiles, spin); t[3] = run<3>(c, aux, cf, rf, N, tiles, spin);
       t[4] = run<4>(c, aux, cf, rf, N, tiles, spin); t[5] = run<5>(c, aux, cf, rf, N, tiles, spin);
       t[6] = run<6>(c, aux, cf, rf, N, tiles, spin); t[7] = run<7>(c, aux, cf, rf, N, tiles, spin);
-      printf("%4d tiles (%.1f rounds), stand-in K loop %4.1f us:", tiles, tiles / 512.0, spin * 0.01);
+      printf("%4d tiles (%.1f rounds), stand-in K loop %4.1f us%s:", tiles, tiles / 512.0, (spin < 0 ? -spin : spin) * 0.01, spin < 0 ? " de-phased" : "");
       for (int m = 0; m < 8; ++m) printf("  [%s] %.1f", names[m], t[m]);
       printf("  us per launch\n");
     }
