@@ -188,7 +188,11 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *eve
         const double region = upper ? bd : bd - 1.0;      // floor(ts) of every row of this slab if the stamps are sorted
         // (Round 3, measured and removed: reading each 64-row block with two fully coalesced instructions -- lane l takes the 16 bytes at
         // 16 l, then at 1024 + 16 l -- and swapping the halves between lane pairs by DPP. Half the cache-line accesses per instruction, yet
-        // slower: rows only loaded 84 against 76 us, whole kernel 124 against 101 us; tools/voxel_parts.py.)
+        // slower: rows only loaded 84 against 76 us, whole kernel 124 against 101 us; tools/voxel_parts.py.
+        // Also: software pipelining with a second batch of 4 rows per thread in flight (unconditional prefetch, so that hipcc's counted
+        // waits read vmcnt(14) / (12) / (10) / (8)): 50 against 47 us for 64 workgroups, 105 against 98 us for 512 -- no gain. A workgroup
+        // streams its 1.6 MB in ~45 us whether 64 or 256 CUs are busy (tools/voxel_clips_probe.py): ~40 GB/s per CU is what one CU's
+        // vector-memory path sustains on rows that mostly miss its L1, and more requests queued behind it do not raise that.)
         for (int64_t k0 = threadIdx.x; k0 < hi - lo; k0 += (int64_t)VB_THREADS * VB_UNROLL) {
           double2 ra[VB_UNROLL], rb[VB_UNROLL];
           bool live[VB_UNROLL];
