@@ -26,6 +26,7 @@ VARIANTS = {
     "g4fwd": {"_variant": 11},              # wide forward / data-gradient GEMMs on the G4 bodies instead of 128x128 tiles
     "g4fwd256": {"_variant": 12},           # only the one-round 256x256 forward tiles (encoder qkv)
     "g4dgrad": {"_variant": 13},            # only the 128x256 data-gradient tiles (fc2 data gradient with GELU')
+    "libplain": {"_vendor": True},             # yardstick only: the plain bf16 GEMMs (no epilogue operand) through torch.mm = hipBLASLt
     "no96": {"_no96": True},                  # 128x128 tiles where the launcher would pick 96x128 (257..384 tiles)
     "split2": {"_split": 2},                 # two half-batches on two streams inside the captured step (kernels of one half fill the other's tails)
     "split4": {"_split": 4},
@@ -55,9 +56,30 @@ def _gemm_no96(a, b, out, *, M, N, K, tile=0, trans_a=False, **kw):
     return _orig_gemm(a, b, out, M=M, N=N, K=K, tile=tile, trans_a=trans_a, **kw)
 
 
+_lib_calls = [0, 0]
+
+
+def _gemm_lib(a, b, out, *, M, N, K, trans_a=False, trans_b=False, lda=None, ldb=None, ldc=None, bias=None, act=0, aux=None, residual=None,
+              alpha=1.0, accumulate=False, batch=(1, 1), tile=0, **kw):
+    """torch.mm for the launches that are plain GEMMs on whole contiguous tensors (no bias / activation / residual / batch / offsets)."""
+    plain = (a.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and not trans_a and bias is None and act == 0 and aux is None and
+             residual is None and alpha == 1.0 and not accumulate and batch == (1, 1) and not kw and a.dim() == 2 and b.dim() == 2 and
+             out.dim() == 2 and a.is_contiguous() and b.is_contiguous() and out.is_contiguous() and a.shape == (M, K) and out.shape == (M, N) and
+             lda in (None, K) and ldc in (None, N) and M >= 2048)
+    if plain and not trans_b and b.shape == (N, K) and ldb in (None, K):
+        _lib_calls[0] += 1
+        return torch.mm(a, b.t(), out=out)
+    if plain and trans_b and b.shape == (K, N) and ldb in (None, N):
+        _lib_calls[0] += 1
+        return torch.mm(a, b, out=out)
+    _lib_calls[1] += 1
+    return _orig_gemm(a, b, out, M=M, N=N, K=K, trans_a=trans_a, trans_b=trans_b, lda=lda, ldb=ldb, ldc=ldc, bias=bias, act=act, aux=aux,
+                      residual=residual, alpha=alpha, accumulate=accumulate, batch=batch, tile=tile, **kw)
+
+
 def build(B, cfg):
     from eventpretrain_amd._lib import call
-    ops.gemm = _gemm_no96 if cfg.get("_no96") else _orig_gemm
+    ops.gemm = _gemm_no96 if cfg.get("_no96") else (_gemm_lib if cfg.get("_vendor") else _orig_gemm)
     apply(cfg)
     call("evp_gemm_set_variant", cfg.get("_variant", 10))      # the routing is decided at launch time, i.e. baked in at capture
     a = make_args(model_size="base", pr_phase="rec", device="cuda", batch_size=B)
@@ -139,6 +161,8 @@ def main():
             times[n].append((time.perf_counter() - t0) / ns.steps * 1e3)
             if not torch.isfinite(ex.loss).all():
                 print(f"NON-FINITE loss in variant {n}, round {r}", flush=True)
+    if _lib_calls[0]:
+        print(f"libplain: {_lib_calls[0]} launches through torch.mm, {_lib_calls[1]} through evp_gemm (all eager + capture passes)")
     for n in names:
         t = sorted(times[n])
         print(f"{n:10s} min {t[0]:.3f} ms  median {t[len(t) // 2]:.3f} ms  all {[round(v, 3) for v in times[n]]}  loss {exs[n].loss.item():.4f}", flush=True)
