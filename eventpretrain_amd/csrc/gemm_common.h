@@ -127,12 +127,29 @@ template <> __device__ __forceinline__ float4 ld4<bf16_t>(const bf16_t *p) {
                      __uint_as_float(u.y & 0xFFFF0000u));
 }
 template <typename TC> __device__ __forceinline__ void st4(TC *p, float4 v);
+// Write-through stores (agent-scope relaxed atomic store = `global_store ... sc1`) for 8-byte-per-lane output pieces. A kernel's plain
+// stores stay dirty in the eight XCDs' L2s until the end-of-kernel release writes them back (MI355X_MICROARCH.md price list: a kernel
+// boundary costs + bytes / 6 TB/s for what the predecessor leaves dirty; "tens of KB per workgroup from a 4-8-byte-per-lane epilogue:
+// write-through wins"); written through, they drain while the kernel is still computing. Round 3, same-box A/B of the ViT-Base step
+// (2 x 2 interleaved runs): bf16 GEMM outputs written through 11.14 against 11.36-11.43 ms plain (-2 %); agent and system scope the
+// same; the f32 outputs as two 8-byte write-through stores instead of one 16-byte plain store LOSE (11.68-11.77 against 11.52-11.62), as
+// one `buffer_store_dwordx4 ... sc1` they change nothing (11.145 against 11.139), nor do non-temporal stores, nor write-through outputs of
+// the attention and LayerNorm kernels (11.37-11.43 either way). EVP_WT_STORES=0 builds the plain form for A/B.
+#ifndef EVP_WT_STORES
+#define EVP_WT_STORES 1
+#endif
+__device__ __forceinline__ void st_u64_wt(void *p, unsigned long long v) {
+#if EVP_WT_STORES
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *reinterpret_cast<unsigned long long *>(p) = v;
+#endif
+}
 template <> __device__ __forceinline__ void st4<float>(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t *p, float4 v) {
-  uint2 u;
-  u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-  u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
-  *reinterpret_cast<uint2 *>(p) = u;
+  const uint32_t lo = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+  const uint32_t hi = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+  st_u64_wt(p, (unsigned long long)lo | ((unsigned long long)hi << 32));
 }
 
 // Block -> tile map (speed only, never correctness): (1) blocks b and b+8 share an XCD, so renumber to give every XCD
