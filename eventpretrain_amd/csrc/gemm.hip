@@ -23,6 +23,7 @@ static int g_gemm_g4_fwd = 0;
 //  * the second workgroup of a CU starting half a tile period late, so that one computes while the other writes: every launch got
 //    slower by exactly the delay (dec.dfc2 3 rounds 49.8 -> 55.0 us, 4 rounds 65.1 -> 70.3): the rounds themselves do not speed up.)
 static int g_gemm_dbg = 0;
+static int g_gemm_wt16 = 1;      // bf16 epilogue in 8-column pieces / 16-byte write-through stores (evp_gemm_set_variant(18 off / 19 on))
 static unsigned long long *g_stamp_buf = nullptr;   // measurement aid, see gemm_common.h "in-kernel wall-clock stamps"
 static long long g_stamp_slots = 0, g_stamp_next = 0;
 unsigned long long *evp_gemm_next_stamp_slot() {
@@ -433,6 +434,59 @@ __device__ __forceinline__ void epilogue_lds_rows(const float4 *tile, const Gemm
   }
 }
 
+// bf16 C, interior tile, no residual / accumulate: every thread takes EIGHT columns (two adjacent 16-byte chunks of the parked f32 tile),
+// so that C and the stored pre-activation leave as 16-byte write-through stores and the GELU' operand arrives as 16-byte loads.
+template <int EPI, int BM, int BN, int NT, bool AUXST>
+__device__ __forceinline__ void epilogue_lds_rows8(const float4 *tile, const GemmParams &p, int64_t coff, int m0, int n0, bool fast) {
+  constexpr int CPR = BN / 4, CPR8 = BN / 8, RPP = NT / CPR8, STEPS = BM / RPP, G = (STEPS % 4 == 0) ? 4 : 2;
+  static_assert(STEPS % G == 0, "rows per thread must come in pairs");
+  const int tid = threadIdx.x, ch8 = tid % CPR8, r0 = tid / CPR8, n = n0 + ch8 * 8;
+  bf16_t *Cb = reinterpret_cast<bf16_t *>(p.C), *Ab = reinterpret_cast<bf16_t *>(p.aux);
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  if (p.bias) {
+    b0 = *reinterpret_cast<const float4 *>(p.bias + n);
+    b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
+  }
+#pragma unroll 1
+  for (int s = 0; s < STEPS; s += G) {
+    float4 a0[G], a1[G];
+    uint4 h[G];
+    int m[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int row = r0 + (s + u) * RPP;
+      m[u] = m0 + row;
+      a0[u] = tile[row * CPR + ((2 * ch8) ^ (row & 15))];
+      a1[u] = tile[row * CPR + ((2 * ch8 + 1) ^ (row & 15))];
+      if constexpr (EPI == 2) h[u] = *reinterpret_cast<const uint4 *>(Ab + coff + (int64_t)m[u] * p.ldaux + n);
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      float4 v0 = make_float4(a0[u].x * p.alpha + b0.x, a0[u].y * p.alpha + b0.y, a0[u].z * p.alpha + b0.z, a0[u].w * p.alpha + b0.w);
+      float4 v1 = make_float4(a1[u].x * p.alpha + b1.x, a1[u].y * p.alpha + b1.y, a1[u].z * p.alpha + b1.z, a1[u].w * p.alpha + b1.w);
+      if constexpr (EPI == 1) {
+        if constexpr (AUXST) st8_bf16_wt(Ab, coff + (int64_t)m[u] * p.ldaux + n, v0, v1);
+        if (p.act == EVP_ACT_GELU) { v0 = gelu4(v0, fast); v1 = gelu4(v1, fast); }
+        else {
+          v0 = make_float4(fmaxf(v0.x, 0.f), fmaxf(v0.y, 0.f), fmaxf(v0.z, 0.f), fmaxf(v0.w, 0.f));
+          v1 = make_float4(fmaxf(v1.x, 0.f), fmaxf(v1.y, 0.f), fmaxf(v1.z, 0.f), fmaxf(v1.w, 0.f));
+        }
+      } else if constexpr (EPI == 2) {
+        const float4 h0 = make_float4(__uint_as_float(h[u].x << 16), __uint_as_float(h[u].x & 0xFFFF0000u), __uint_as_float(h[u].y << 16),
+                                      __uint_as_float(h[u].y & 0xFFFF0000u));
+        const float4 h1 = make_float4(__uint_as_float(h[u].z << 16), __uint_as_float(h[u].z & 0xFFFF0000u), __uint_as_float(h[u].w << 16),
+                                      __uint_as_float(h[u].w & 0xFFFF0000u));
+        if (p.act == EVP_ACT_DGELU) { v0 = dgelu_mul4(v0, h0, fast); v1 = dgelu_mul4(v1, h1, fast); }
+        else {
+          v0 = make_float4(h0.x > 0.f ? v0.x : 0.f, h0.y > 0.f ? v0.y : 0.f, h0.z > 0.f ? v0.z : 0.f, h0.w > 0.f ? v0.w : 0.f);
+          v1 = make_float4(h1.x > 0.f ? v1.x : 0.f, h1.y > 0.f ? v1.y : 0.f, h1.z > 0.f ? v1.z : 0.f, h1.w > 0.f ? v1.w : 0.f);
+        }
+      }
+      st8_bf16_wt(Cb, coff + (int64_t)m[u] * p.ldc + n, v0, v1);
+    }
+  }
+}
+
 template <typename TC, int EPI, int BM, int BN, int NT, int MI, int NI>
 __device__ __forceinline__ void epilogue_lds(const f32x4 (&acc)[MI][NI], const GemmParams &p, int64_t coff, char *smem, int m0, int n0,
                                              int wrow, int wcol, bool fast) {
@@ -449,6 +503,14 @@ __device__ __forceinline__ void epilogue_lds(const f32x4 (&acc)[MI][NI], const G
       tile[row * CPR + (ch ^ (row & 15))] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     }
   __syncthreads();
+  if constexpr (sizeof(TC) == 2 && BN % 8 == 0 && (BM % (NT / (BN / 8))) == 0 && (BM / (NT / (BN / 8))) % 2 == 0) {
+    // whole tile inside C, nothing read or added besides the GELU' operand, 16-byte aligned rows: the 8-column form
+    if (p.c_wt16 && m0 + BM <= p.M && n0 + BN <= p.N && !p.residual && !p.accumulate && p.splitk <= 1 && (EPI != 2 || p.aux)) {
+      if (EPI == 1 && p.aux) epilogue_lds_rows8<EPI, BM, BN, NT, true>(tile, p, coff, m0, n0, fast);
+      else epilogue_lds_rows8<EPI, BM, BN, NT, false>(tile, p, coff, m0, n0, fast);
+      return;
+    }
+  }
   const int ch = tid % CPR, r0 = tid / CPR;
   const int n = n0 + ch * 4;
   if (n >= p.N) return;
@@ -714,7 +776,7 @@ __global__ __launch_bounds__(256) void gemm_grouped_tn_kernel(const GroupedProbl
   p.B = g.B; p.ldb = g.ldb; p.sB0 = 0; p.sB1 = 0;
   p.C = g.C; p.c_dtype = EVP_F32; p.ldc = g.ldc; p.sC0 = 0; p.sC1 = 0;
   p.batch1 = 1; p.alpha = 1.0f; p.bias = nullptr; p.act = EVP_ACT_NONE; p.aux = nullptr; p.ldaux = 0;
-  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1; p.dbg = 0; p.colsum = nullptr; p.colsum_acc = 0; p.stamp = nullptr;
+  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1; p.dbg = 0; p.colsum = nullptr; p.colsum_acc = 0; p.stamp = nullptr; p.c_wt16 = 0;
   p.k_per_split = (g.K + 63) / 64 * 64;
   gemm_body<bf16_t, float, 0, true, true, BM, BN, 2, 2, true, 2, 64>(p, it.tile_m, it.tile_n, 0, 0);
   stamp_end(stamp, blockIdx.x, gridDim.x);
@@ -733,6 +795,13 @@ int launch(const evp_gemm_desc *d, hipStream_t s) {
   p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = g_gemm_dbg; p.colsum = nullptr; p.colsum_acc = 0; p.stamp = evp_gemm_next_stamp_slot();
   p.tiles_m = (d->M + BM - 1) / BM;
   const int tiles_n = (d->N + BN - 1) / BN;
+  {
+    // the 8-column epilogue form: bf16 C (and aux) in one piece below 2 GiB, rows and bases 16-byte aligned
+    const int nbz = (d->batch0 > 0 ? d->batch0 : 1) * (d->batch1 > 0 ? d->batch1 : 1);
+    const int64_t span = (int64_t)d->M * (d->ldc > d->ldaux ? d->ldc : d->ldaux) * 2;
+    p.c_wt16 = (g_gemm_wt16 && d->c_dtype == EVP_BF16 && nbz == 1 && span < 0x7FFFFFFFLL && d->ldc % 8 == 0 && (!d->aux || d->ldaux % 8 == 0) &&
+                ((uintptr_t)d->C & 15) == 0 && ((uintptr_t)d->aux & 15) == 0 && (!d->bias || ((uintptr_t)d->bias & 15) == 0)) ? 1 : 0;
+  }
   const int nb = (d->batch0 > 0 ? d->batch0 : 1) * p.batch1;
   // split-K: only for plain f32 outputs without epilogue extras (the weight-gradient GEMMs: few output tiles, long K)
   constexpr int BKc = BK;
@@ -900,6 +969,7 @@ extern "C" long long evp_gemm_stamp_count(void) { return g_stamp_next; }
 extern "C" int evp_gemm_set_variant(int v) {
   const int old = g_gemm_variant;
   if (v >= 100 && v <= 103) g_gemm_dbg = v - 100;
+  if (v == 18 || v == 19) g_gemm_wt16 = v - 18;
   if (v == 1 || v == 2) g_gemm_variant = v;
   if (v >= 10 && v <= 13) g_gemm_g4_fwd = v == 11 ? 3 : v == 10 ? 0 : v - 11;     // 10 off (default), 11 on, 12 = 256x256 only, 13 = 128x256 only
   return old;

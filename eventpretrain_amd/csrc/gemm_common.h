@@ -33,6 +33,7 @@ struct GemmParams {
   int dbg;                   // measurement aid (evp_gemm_set_variant(101): skip the epilogue; results are then garbage)
   float *colsum;             // G4 TN body only: colsum[m] (+)= sum_k A[k][m] (bias gradient), written by the tile_n == 0 workgroups
   int colsum_acc;
+  int c_wt16;                // bf16 C (and aux) below 2 GiB: the LDS-staged epilogue may use 16-byte write-through buffer stores
   unsigned long long *stamp; // measurement aid (evp_gemm_set_stamp_buffer): [2 * workgroup] start / end wall-clock stamps of this launch
 };
 
@@ -146,6 +147,18 @@ __device__ __forceinline__ void st_u64_wt(void *p, unsigned long long v) {
 #endif
 }
 template <> __device__ __forceinline__ void st4<float>(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+// eight bf16 (16 bytes) written through with ONE instruction (`buffer_store_dwordx4 ... sc1`; an 8-byte `sc1` store costs 2.7x the time
+// per byte of a 16-byte one, MI355X_MICROARCH.md "stores of each flavour"); `base` wave-uniform, byte offset below 2 GiB
+typedef unsigned __attribute__((ext_vector_type(4))) st_u32x4;
+__device__ __forceinline__ void st8_bf16_wt(bf16_t *base, int64_t elem_off, float4 a, float4 b) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7FFFFFFF, 0x00020000);
+  st_u32x4 u;
+  u.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
+  u.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
+  u.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
+  u.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+  __builtin_amdgcn_raw_buffer_store_b128(u, rs, (int)(elem_off * 2), 0, 16);
+}
 template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t *p, float4 v) {
   const uint32_t lo = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
   const uint32_t hi = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void gemm_g4_grouped_tn_kernel(const GroupedPr
   p.B = g.B; p.ldb = g.ldb; p.sB0 = 0; p.sB1 = 0;
   p.C = g.C; p.c_dtype = EVP_F32; p.ldc = g.ldc; p.sC0 = 0; p.sC1 = 0;
   p.batch1 = 1; p.alpha = 1.0f; p.bias = nullptr; p.act = EVP_ACT_NONE; p.aux = nullptr; p.ldaux = 0;
-  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1; p.dbg = 0; p.stamp = nullptr;
+  p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1; p.dbg = 0; p.stamp = nullptr; p.c_wt16 = 0;
   p.k_per_split = g.K;
   p.colsum = g.colsum; p.colsum_acc = g.colsum_accumulate;
   gemm_g4_tn_body(p, it.tile_m, it.tile_n);
@@ -51,7 +51,7 @@ void fill_params(GemmParams &p, const evp_gemm_desc *d) {
   p.batch1 = 1; p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
   p.residual = d->residual; p.ldres = d->ldres; p.accumulate = d->accumulate; p.dbg = 0; p.colsum = nullptr; p.colsum_acc = 0;
   p.splitk = 1; p.k_per_split = d->K;
-  p.stamp = evp_gemm_next_stamp_slot();
+  p.stamp = evp_gemm_next_stamp_slot(); p.c_wt16 = 0;
 }
 
 template <bool AKC, bool BKC, int FI, int FJ, int NST, typename TC, int EPI> int launch_g4x(const evp_gemm_desc *d, hipStream_t s, int dbg) {

@@ -52,6 +52,7 @@ def _restore_global_switches(request):
         call("evp_gemm_set_variant", 1)
         call("evp_gemm_set_variant", 10)
         call("evp_gemm_set_variant", 100)
+        call("evp_gemm_set_variant", 19)
         call("evp_voxel_set_debug", 0)
     except Exception:
         pass

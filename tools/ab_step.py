@@ -26,6 +26,7 @@ VARIANTS = {
     "g4fwd": {"_variant": 11},              # wide forward / data-gradient GEMMs on the G4 bodies instead of 128x128 tiles
     "g4fwd256": {"_variant": 12},           # only the one-round 256x256 forward tiles (encoder qkv)
     "g4dgrad": {"_variant": 13},            # only the 128x256 data-gradient tiles (fc2 data gradient with GELU')
+    "nowt16": {"_cwt": 18},                 # bf16 epilogue in 4-column pieces (8-byte write-through stores) instead of 8-column ones
     "libplain": {"_vendor": True},             # yardstick only: the plain bf16 GEMMs (no epilogue operand) through torch.mm = hipBLASLt
     "no96": {"_no96": True},                  # 128x128 tiles where the launcher would pick 96x128 (257..384 tiles)
     "split2": {"_split": 2},                 # two half-batches on two streams inside the captured step (kernels of one half fill the other's tails)
@@ -82,6 +83,7 @@ def build(B, cfg):
     ops.gemm = _gemm_no96 if cfg.get("_no96") else (_gemm_lib if cfg.get("_vendor") else _orig_gemm)
     apply(cfg)
     call("evp_gemm_set_variant", cfg.get("_variant", 10))      # the routing is decided at launch time, i.e. baked in at capture
+    call("evp_gemm_set_variant", cfg.get("_cwt", 19))
     a = make_args(model_size="base", pr_phase="rec", device="cuda", batch_size=B)
     torch.manual_seed(1)
     m = hub.pretrain_hub_model_base_patch16(a, emb_frames_dim=512, queue_length=1024, T=0.07).cuda().train()
@@ -134,6 +136,7 @@ def build(B, cfg):
     ops._deferred.join_streams = []
     apply({})
     call("evp_gemm_set_variant", 10)
+    call("evp_gemm_set_variant", 19)
     return ex
 
 
