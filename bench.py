@@ -213,10 +213,6 @@ class StampedStep:
     replayed and max(end) - min(start) per slot read back. HIP events cannot do this (they would need a node between any
     two kernels of the graph); the warm re-launch figure of GemmTimer is printed beside it as `frac_warm`."""
     STRIDE = 2 * 4096        # uint64 per slot (EVP_STAMP_WGS workgroups x {start, end}), csrc/gemm_common.h
-    # What the stamps cannot see: the dispatch lead-in between the kernel's start as rocprofv3 records it and the first instruction of
-    # its first workgroup. Calibrated against `rocprofv3 --kernel-trace` of the same command (tools/check_roofline.py,
-    # profiles/r03_roofline_check.txt: without it the family reads 1.1-3.8 % short, depending on the box); added per launch.
-    DISPATCH_LEAD_IN_S = 0.8e-6
     GROUPED = {"evp_gemm_grouped_tn_bf16": ("gemm_grouped_tn_kernel<128,128>", 128),
                "evp_gemm_grouped_tn_g4_bf16": ("gemm_g4_grouped_tn_kernel (256x256, one wave per SIMD, 32x32x16)", 256)}
 
@@ -286,7 +282,7 @@ class StampedStep:
             t1 = st[:, :, 1].max(axis=1)
             if not (have.any(axis=1).all() and (t1 > t0).all()):
                 continue
-            acc += torch.from_numpy((t1 - t0).astype(np.float64) * 1e-8 + self.DISPATCH_LEAD_IN_S)       # 100 MHz ticks
+            acc += torch.from_numpy((t1 - t0).astype(np.float64) * 1e-8)       # 100 MHz ticks
             n += 1
         return (acc / max(n, 1)).tolist() if n else None
 
@@ -634,7 +630,7 @@ def main():
                 if ds_step:
                     e_["frac_in_step"] = e_["frac"]
                     e_["method"] = ("achieved = algorithmic 2MNK FLOPs of these launches in one step / the sum of their durations INSIDE the replayed "
-                                    "step graph (in-kernel wall-clock stamps, max(end) - min(start) per launch + 0.8 us dispatch lead-in calibrated against rocprofv3, mean of 6 replays; bench.py StampedStep); "
+                                    "step graph (in-kernel wall-clock stamps, max(end) - min(start) per launch, mean of 6 replays; bench.py StampedStep); "
                                     "frac_warm = the same launches re-launched back to back between two HIP events (operands cache-warm)")
                 if ds_warm:
                     fw, sw = sum(d["flops_per_step"] for d in ds_warm), sum(d["ms_per_step"] for d in ds_warm) * 1e-3
