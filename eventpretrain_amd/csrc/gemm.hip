@@ -21,7 +21,10 @@ static int g_gemm_g4_fwd = 0;
 //  * the rows beyond the last whole round of 512 tiles as 64x64 tiles on a forked stream: bit-identical, but the fork / join pair costs
 //    more inside a captured graph than the partial round it saves (enc.fc1 48.0 -> 56.4 us, dec.dfc2 57.5 -> 61.7; step 11.34 -> 11.68 ms);
 //  * the second workgroup of a CU starting half a tile period late, so that one computes while the other writes: every launch got
-//    slower by exactly the delay (dec.dfc2 3 rounds 49.8 -> 55.0 us, 4 rounds 65.1 -> 70.3): the rounds themselves do not speed up.)
+//    slower by exactly the delay (dec.dfc2 3 rounds 49.8 -> 55.0 us, 4 rounds 65.1 -> 70.3): the rounds themselves do not speed up;
+//  * a K-loop stagger between the two workgroups of a CU (the waves in the odd wave slot of their SIMDs wait 300 / 600 / 1200 / 2400
+//    cycles before their first K tile; MI355X_MICROARCH.md "Two waves per SIMD", item 9): step 10.89 / 10.93 / 10.97 / 10.95 against
+//    10.91 ms -- nothing.)
 static int g_gemm_dbg = 0;
 static int g_gemm_wt16 = 1;      // bf16 epilogue in 8-column pieces / 16-byte write-through stores (evp_gemm_set_variant(18 off / 19 on))
 static unsigned long long *g_stamp_buf = nullptr;   // measurement aid, see gemm_common.h "in-kernel wall-clock stamps"
