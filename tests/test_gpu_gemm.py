@@ -353,3 +353,52 @@ def test_wide_outputs_take_the_g4_bodies_when_switched_on():
         ops.gemm(a.cuda(), b.cuda(), c1, tile=1, **kw)
         assert torch.equal(c1, c2)
         assert (c0.float() - c2.float()).abs().max().item() <= 2.0 ** -7 * c0.float().abs().max().item()
+
+
+def test_eight_column_write_through_epilogue_is_bit_identical_and_falls_back():
+    """bf16 tiles that lie wholly inside C leave the epilogue in 8-column pieces as 16-byte write-through stores
+    (gemm.hip epilogue_lds_rows8; evp_gemm_set_variant(18) keeps the 4-column form). Same arithmetic per element: bit-identical for
+    bias, GELU + stored pre-activation, ReLU, GELU' -- on a shape with whole and ragged tiles (the ragged ones take the old path
+    inside the same launch), on the 96x128 tiling, and with a row stride / base pointer the 16-byte form must refuse (ldc % 8 != 0,
+    aux 8 bytes off): then the launcher falls back by itself and the result is still right."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd._lib import ACT_DGELU, ACT_GELU, ACT_RELU, call
+    gen = torch.Generator().manual_seed(123)
+    for (M, N, K) in [(1000, 600, 160), (6272, 768, 96), (640, 512, 64)]:
+        a, b, al, bl = _mk(M, N, K, False, False, torch.bfloat16, gen)
+        bt = b.t().contiguous()
+        bias = torch.randn(N, generator=gen).cuda()
+        hpre = torch.randn(M, N, generator=gen).to(torch.bfloat16).cuda()
+        a, b, bt = a.cuda(), b.cuda(), bt.cuda()
+
+        def run():
+            c = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            ops.gemm(a, b, c, M=M, N=N, K=K, bias=bias)
+            h = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            x = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            ops.gemm(a, b, h, M=M, N=N, K=K, bias=bias, act=ACT_GELU, aux=x)
+            r = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            ops.gemm(a, b, r, M=M, N=N, K=K, bias=bias, act=ACT_RELU)
+            g = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            ops.gemm(a, bt, g, M=M, N=N, K=K, trans_b=True, ldb=N, act=ACT_DGELU, aux=hpre)
+            return c, h, x, r, g
+
+        new = run()
+        call("evp_gemm_set_variant", 18)
+        try:
+            old = run()
+        finally:
+            call("evp_gemm_set_variant", 19)
+        for t0, t1 in zip(old, new):
+            assert torch.equal(t0, t1)
+        ref = torch.nn.functional.gelu(al @ bl.t() + bias.cpu().double())
+        assert ((new[1].cpu().double() - ref).abs() / (ref.abs() + 1.0)).max().item() <= 2e-2
+        # strides / bases the 16-byte form cannot take
+        wide = torch.zeros(M, N + 4, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(a, b, wide, M=M, N=N, K=K, bias=bias, ldc=N + 4)
+        assert torch.equal(wide[:, :N], new[0]) and (wide[:, N:] == 0).all()
+        buf = torch.zeros(M * N + 4, dtype=torch.bfloat16, device="cuda")
+        aux_off = buf[4:].view(M, N)                      # 8 bytes off a 16-byte boundary
+        h2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(a, b, h2, M=M, N=N, K=K, bias=bias, act=ACT_GELU, aux=aux_off)
+        assert torch.equal(h2, new[1]) and torch.equal(aux_off, new[2])
