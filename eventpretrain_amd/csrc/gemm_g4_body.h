@@ -188,29 +188,55 @@ __device__ __forceinline__ void gemm_g4_tn_body(const GemmParams &p, const int t
   // C[m][n..n+3]: lane m = .. + (lane & 31); register r: n = .. + 8 (r >> 2) + 4 (lane >> 5) + (r & 3)
   float *C = reinterpret_cast<float *>(p.C);
   const int mrow = m0 + wm * 128 + (lane & 31), ncol = n0 + wn * 128 + 4 * (lane >> 5);
+  // The tile leaves through the (now idle) 128 KiB ring, 128 rows at a time: stored straight from the accumulators a wave
+  // instruction wrote 32 rows x 32 bytes -- 64 cache lines touched per instruction, 64 instructions per lane -- and a round of 256
+  // tiles paid 34 us outside its K loop (tools/g4_intercept_probe.py: time against K at 4096 x 4096), most of it this store. Parked
+  // row-major with the 16-byte chunk index XORed with (row & 63), every wave instruction then writes ONE whole 1 KiB row.
+  {
+    (void)mrow; (void)ncol;
+    float4 *tile = reinterpret_cast<float4 *>(smem);          // [128 rows][64 chunks]
+    const bool vec_ok = (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+    const int ncol4 = n0 + 4 * lane;                            // this lane's 4 columns in the row-wise pass
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();                                         // every wave is done with the ring (or with the previous half)
+      if (wm == half) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = mrow + 32 * i;
-    if (m >= p.M) continue;
+        for (int i = 0; i < 4; ++i) {
+          const int row = 32 * i + (lane & 31);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = ncol + 32 * j + 8 * g;
-        if (n >= p.N) continue;
-        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        float *c = C + (int64_t)m * p.ldc + n;
-        if (n + 3 < p.N) {
-          if (p.accumulate) {
-            const float4 o = *reinterpret_cast<const float4 *>(c);
-            v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w);
-          }
-          *reinterpret_cast<float4 *>(c) = v;
-        } else {
-          const float e[4] = {v.x, v.y, v.z, v.w};
-          for (int u = 0; u < 4 && n + u < p.N; ++u) c[u] = p.accumulate ? c[u] + e[u] : e[u];
+            for (int g = 0; g < 4; ++g) {
+              const int chunk = (wn * 128 + 32 * j + 8 * g + 4 * (lane >> 5)) >> 2;
+              tile[row * 64 + (chunk ^ (row & 63))] = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+            }
         }
       }
+      __syncthreads();
+      const int mbase = m0 + half * 128;
+      float *crow = C + (int64_t)mbase * p.ldc + ncol4;
+#pragma unroll 1
+      for (int r0 = wave; r0 < 128; r0 += 16) {                // 4 rows per trip and wave
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = r0 + 4 * u;
+          if (mbase + r >= p.M || ncol4 >= p.N) continue;
+          float4 v = tile[r * 64 + (lane ^ (r & 63))];
+          float *c = crow + (int64_t)r * p.ldc;
+          if (vec_ok && ncol4 + 3 < p.N) {
+            if (p.accumulate) {
+              const float4 o = *reinterpret_cast<const float4 *>(c);
+              v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w);
+            }
+            *reinterpret_cast<float4 *>(c) = v;
+          } else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            for (int w_ = 0; w_ < 4 && ncol4 + w_ < p.N; ++w_) c[w_] = p.accumulate ? c[w_] + e[w_] : e[w_];
+          }
+        }
+      }
+    }
   }
   if (do_colsum) {                               // lanes l and l + 32 hold the two k halves of row (lane & 31)
 #pragma unroll
