@@ -8,7 +8,9 @@ namespace {
 
 constexpr int ROWS_PER_BLOCK = 4;  // 4 waves / 256 threads (8 waves per block measured 10-25 % slower)
 constexpr int LN_THREADS = ROWS_PER_BLOCK * 64;
-constexpr int LN_MAX_BLOCKS = 1024;  // backward: also the number of dgamma/dbeta partial rows
+constexpr int LN_MAX_BLOCKS = 512;   // backward: also the number of dgamma / dbeta / column-sum partial rows. Round 3, same-box A/B of the
+                                     // ViT-Base step: 1024 blocks 10.94-11.00 ms, 768 10.86-10.88, 512 10.84-10.88, 392 10.85-10.88 -- the
+                                     // partial rows (nblk x 3 D floats per launch) are written here and read again by the grouped column sum
 constexpr int LN_FWD_BLOCKS = 2048;  // forward has no partials: one row per wave up to 8192 rows
 
 // Number of float4 chunks a lane holds for a row of D floats
@@ -859,8 +861,10 @@ extern "C" int evp_embed_post_bwd(const float *g, const float *y, const float *g
     hipLaunchKernelGGL(embed_post_bwd_kernel<V>, dim3(gsz), dim3(LN_THREADS), sh, s, g, y, gamma, beta, mean, rstd, M, D, dy, dy_dtype, workspace);
   });
   EVP_CHECK_LAUNCH("evp_embed_post_bwd");
-  hipLaunchKernelGGL(ln_bwd_finalize, dim3((2 * D + 63) / 64), dim3(1024), 0, s, workspace, gsz, D, dgamma, dbeta);
-  EVP_CHECK_LAUNCH("evp_embed_post_bwd(finalize)");
+  if (dgamma || dbeta) {   // both NULL: the caller reduces the per-block partials workspace[g][2][D] itself (deferred, grouped)
+    hipLaunchKernelGGL(ln_bwd_finalize, dim3((2 * D + 63) / 64), dim3(1024), 0, s, workspace, gsz, D, dgamma, dbeta);
+    EVP_CHECK_LAUNCH("evp_embed_post_bwd(finalize)");
+  }
   return EVP_OK;
 }
 

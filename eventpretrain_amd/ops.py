@@ -904,6 +904,7 @@ class PatchEmbedFn(torch.autograd.Function):
         ctx.save_for_backward(cols, y, gamma, beta, mean, rstd)
         ctx.wshape = tuple(w.shape)
         ctx.prm = (w, b)
+        ctx.nprm = (gamma, beta)        # leaf parameters: targets of the deferred (grouped) column sums
         return out.view(B, n_keep, D)
 
     @staticmethod
@@ -914,12 +915,20 @@ class PatchEmbedFn(torch.autograd.Function):
         dev = g.device
         g = _chk(g.contiguous(), torch.float32).view(M, D)
         dy = torch.empty(M, D, dtype=cols.dtype, device=dev)
-        dgamma = torch.empty(D, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(D, dtype=torch.float32, device=dev)
         nb = call("evp_layernorm_bwd_nblk", M)
-        ws = torch.empty(2 * nb * D, dtype=torch.float32, device=dev)
+        ws = torch.empty(nb, 2 * D, dtype=torch.float32, device=dev)
+        # the per-block partials of d gamma / d beta join the step's grouped column-sum launch when the parameters can take deferred
+        # gradients (as layernorm_bwd does); otherwise the kernel's own finalize pass reduces them
+        defer = D % 8 == 0 and _deferred.can_defer(ctx.nprm[0]) and _deferred.can_defer(ctx.nprm[1])
+        dgamma = dbeta = None
+        if not defer:
+            dgamma = torch.empty(D, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(D, dtype=torch.float32, device=dev)
         call("evp_embed_post_bwd", ptr(g), ptr(y), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), M, D, ptr(dy), dt(dy),
              ptr(dgamma), ptr(dbeta), ptr(ws), stream_ptr())
+        if defer:
+            _deferred.colsum(ctx.nprm[0], ws[:, :D])
+            _deferred.colsum(ctx.nprm[1], ws[:, D:])
         dw = _wgrad(dy, cols, D, Kc, M, ctx.prm[0], ctx.wshape) if ctx.needs_input_grad[2] else None
         db = _bgrad(dy, ctx.prm[1]) if ctx.needs_input_grad[3] else None
         return None, None, dw, db, dgamma, dbeta, None, None

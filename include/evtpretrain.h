@@ -241,7 +241,8 @@ int evp_patchify(const float *x, const int64_t *ids_keep, int B, int C, int H, i
  * ids_keep as above (NULL = identity, M = B*L). Saves mean/rstd. out float32 [M,D]. */
 int evp_embed_post_fwd(const float *y, const float *gamma, const float *beta, const float *pos, const int64_t *ids_keep,
                        int B, int n_keep, int L, int D, float eps, float *out, float *mean, float *rstd, void *stream);
-/* dy (dtype [M,D]) = LN'(GELU'(LN(y)) * g); dgamma/dbeta overwritten (workspace as evp_layernorm_bwd). */
+/* dy (dtype [M,D]) = LN'(GELU'(LN(y)) * g); dgamma/dbeta overwritten (workspace as evp_layernorm_bwd); both NULL: the per-block
+ * partials stay in workspace [nblk][2][D] for the caller's grouped column sum, as with evp_layernorm_bwd. */
 int evp_embed_post_bwd(const float *g, const float *y, const float *gamma, const float *beta, const float *mean,
                        const float *rstd, int64_t M, int D, void *dy, int dy_dtype, float *dgamma, float *dbeta,
                        float *workspace, void *stream);
