@@ -122,14 +122,18 @@ def events_augment_batch(events, clip_offsets, decisions, size, windows=None):
     if max_add > MAX_ADD_PER_CLIP:
         raise _lib.EvpError("events_augment_batch: at most %d added rows per clip (got %d)" % (MAX_ADD_PER_CLIP, max_add))
 
-    def up(parts, dtype, shape):
-        arr = np.concatenate(parts) if parts else np.zeros(shape, dtype)
-        return torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype)).to(dev)
-
-    # one packed upload for the index tables
-    er_d, ai_d, nz_d = up(er_l, np.int64, (0,)), up(ai_l, np.int64, (0,)), up(nz_l, np.float64, (0, 3))
+    # ONE upload for the four tables (a pageable source makes every copy wait for the stream: four of them were four stalls of the host
+    # per batch): erase indices | add indices | noise rows (float64 bits) | the five offset rows, all 8-byte words
+    er_a = np.concatenate(er_l).astype(np.int64, copy=False) if er_l else np.zeros(0, np.int64)
+    ai_a = np.concatenate(ai_l).astype(np.int64, copy=False) if ai_l else np.zeros(0, np.int64)
+    nz_a = np.ascontiguousarray(np.concatenate(nz_l), dtype=np.float64).reshape(-1) if nz_l else np.zeros(0, np.float64)
     pad = lambda v: np.concatenate([v, np.zeros(n_clips + 1 - v.shape[0], np.int64)])
-    tabs = torch.from_numpy(np.stack([pad(w_beg), pad(w_end), er_off, ad_off, out_off])).to(dev)
+    tab_a = np.stack([pad(w_beg), pad(w_end), er_off, ad_off, out_off]).astype(np.int64, copy=False).reshape(-1)
+    packed = torch.from_numpy(np.concatenate([er_a, ai_a, nz_a.view(np.int64), tab_a])).to(dev)
+    o1, o2, o3 = er_a.size, er_a.size + ai_a.size, er_a.size + ai_a.size + nz_a.size
+    er_d, ai_d = packed[:o1], packed[o1:o2]
+    nz_d = packed[o2:o3].view(torch.float64).view(-1, 3)
+    tabs = packed[o3:].view(5, n_clips + 1)
     n_add, n_out = int(ad_off[-1]), int(out_off[-1])
     ws = torch.empty(max(n_add, 1), 4, dtype=torch.float64, device=dev)
     out = torch.empty(n_out, 4, dtype=torch.float64, device=dev)

@@ -91,11 +91,22 @@ class GpuInputPipeline:
         H, W = self.sensor
         ev, off = ea.events_augment_batch(events, clip_offsets, decisions, (H, W), windows=windows)
         vox = voxel_grid_batch(ev, off, self.bins, (self.S, self.S), assume_sorted=assume_sorted, scale=(self.S / W, self.S / H))
-        p_dev = torch.from_numpy(np.ascontiguousarray(params, dtype=np.int32)).to(events.device, non_blocking=True)
+        # the grid's and the frames' parameter rows in ONE upload (each pageable copy is a stall of the host)
+        both = frames is not None and frame_params is not None and not torch.is_tensor(frame_params)
+        rows = np.ascontiguousarray(params, dtype=np.int32).reshape(-1, 6)
+        if both:
+            fr = np.ascontiguousarray(frame_params, dtype=np.int32).reshape(-1, 6)
+            B, Hf, Wf = rows.shape[0], int(frames.shape[-2]), int(frames.shape[-1])
+            if ((fr[:, 0] < 0) | (fr[:, 1] < 0) | (fr[:, 2] < 1) | (fr[:, 3] < 1) | (fr[:, 0] + fr[:, 2] > Wf) | (fr[:, 1] + fr[:, 3] > Hf)).any():
+                raise ValueError("GpuInputPipeline.run: frame crop box outside the frame")
+            rows = np.concatenate([rows, fr], 0)
+        p_all = torch.from_numpy(rows).to(events.device, non_blocking=True)
+        p_dev = p_all[:len(params)]
         out = va.evg_augment_batch(vox, p_dev, (self.S, self.S))
         tgt = None
         if frames is not None:
-            tgt = va.frame_augment_batch(frames, p_dev if frame_params is None else frame_params, (self.S, self.S))
+            fp = p_all[len(params):] if both else (p_dev if frame_params is None else frame_params)
+            tgt = va.frame_augment_batch(frames, fp, (self.S, self.S))
         return out, tgt
 
     def batch(self, events, clip_offsets, step, frames=None, first_sample=0, sample_seeds=None):
