@@ -371,6 +371,30 @@ def cpu_voxel_baseline():
                 sample="oracle/voxel_oracle.c, %d x (8 clips x 100k events), %.2f s" % (reps, dt_))
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same args>
+    as a child process, let rank 0's JSON line through on stdout and return the child's exit code. Nothing here initialises the
+    GPU: the parent only counts devices (EVP_BENCH_SHARE_DEVICE=1 skips the count: gloo rehearsals with the ranks on one card)."""
+    import socket
+    import subprocess
+    if not os.environ.get("EVP_BENCH_SHARE_DEVICE"):
+        n_dev = torch.cuda.device_count()
+        if n_dev < n:
+            print("bench.py: --gpus %d needs %d HIP devices on this node, %d visible" % (n, n, n_dev), file=sys.stderr)
+            return 2
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -391,7 +415,15 @@ def main():
                     help="A/B aid: evp_gemm_set_variant codes applied before the model is built (11/12/13: G4 forward / data-gradient routing)")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-GPU code path (process group, reducer, split graphs) even with one rank")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the product path); gloo = rehearsal of the N > 1 control flow with several ranks on ONE card")
     args = ap.parse_args()
+
+    # ---- N > 1 from a plain `python bench.py --gpus N`: start the ranks as a CHILD process group (one rank per GPU over RCCL) and
+    # relay. This runs before anything touches the GPU runtime: no HIP call, no torch.cuda.is_available(), no library load
+    # (torch.cuda.device_count() does not initialise the device on this image); never os.exec*.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     from eventpretrain_amd import _lib
     _lib.require_device()
@@ -400,17 +432,25 @@ def main():
     GemmTimer.g4_fwd = 11 in args.gemm_variant
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
-        raise SystemExit("--gpus does not match WORLD_SIZE")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    n_dev = torch.cuda.device_count()
+    if local >= n_dev and not os.environ.get("EVP_BENCH_SHARE_DEVICE"):
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d HIP device(s) visible" % (rank, local, n_dev))
+    local_dev = local % max(n_dev, 1)            # EVP_BENCH_SHARE_DEVICE=1: several ranks on one card (gloo rehearsal only)
+    torch.cuda.set_device(local_dev)
+    device = torch.device("cuda", local_dev)
     multi = world > 1 or args.force_dist
+    rccl_world = 1
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)     # "nccl" is RCCL over xGMI on ROCm
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world)     # "nccl" is RCCL over xGMI on ROCm
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        rccl_world = dist.get_world_size()
+        if rccl_world != args.gpus:
+            raise SystemExit("process group has %d ranks, --gpus %d" % (rccl_world, args.gpus))
 
     a, model, opt = build(args, device)
     ev, off, vox, tgt, S, n_ev = make_batch(args, device, rank)
@@ -483,7 +523,7 @@ def main():
     workload = label if not headline else "ViT-%s masked modeling (diff-map decoder)" % args.model.capitalize()
     result = {
         "metric": "pretrain samples/sec (masked-ViT step, B=64 224^2)", "value": value, "unit": "samples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "n_gpus": world, "rccl_world": rccl_world, "dist_backend": (args.dist_backend if multi else None), "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "%s, %dx%d 5-bin voxels, batch=%d per GPU, AdamW step included" % (workload, S, S, args.batch),
                    "name": args.config, "global_batch": args.batch * world, "parallelism": "dp%d" % world,

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVP_LIB") or os.path.join(_HERE, "libevtpretrain.so")     # EVP_LIB: another build of the same ABI (A/B runs)
 CSRC = os.path.join(_HERE, "csrc")
 
+ABI_VERSION = 2            # include/evtpretrain.h EVP_ABI_VERSION: checked when the library is loaded (EVP_LIB overrides included)
 EVP_F32, EVP_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_DGELU, ACT_RELU, ACT_DRELU = 0, 1, 2, 3, 4
 
@@ -109,11 +110,12 @@ SIGNATURES = {
     "evp_token_mean_fwd": [_vp, _i, _i, _i, _vp, _vp],
     "evp_token_mean_bwd": [_vp, _i, _i, _i, _vp, _vp],
     "evp_rows_scale_f32": [_vp, _vp, _f, _vp, _i64, _i, _i, _vp, _vp, _vp],
-    "evp_dropout_fwd": [_vp, _i, _vp, _vp, _i64, _f, C.c_uint64, C.c_uint64, _vp],
+    "evp_dropout_fwd": [_vp, _i, _vp, _vp, _i64, _f, C.c_uint64, _vp, C.c_uint64, _vp],
     "evp_dropout_apply": [_vp, _i, _vp, _vp, _i64, _f, _vp],
     "evp_abi_version": [],
 }
 _OTHER_RESTYPE = {"evp_last_error": C.c_char_p, "evp_target_arch": C.c_char_p}
+_INT_RESTYPE = {"evp_gemm_stamp_count": C.c_longlong}
 _NO_STATUS = {"evp_dwconv5x5_bwd_nslab", "evp_gemm_set_variant", "evp_voxel_set_debug", "evp_gemm_stamp_count", "evp_attention_fused_supported", "evp_layernorm_bwd_nblk", "evp_colsum_nblk", "evp_batchnorm_nblk", "evp_abi_version",
               "evp_window_attention_fused_np", "evp_window_attention_fused_nchunk"}
 
@@ -144,10 +146,15 @@ def load():
         raise EvpError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(eventpretrain_amd has no CPU or PyTorch fallback for its kernels)")
     lib = C.CDLL(LIB_PATH)
+    lib.evp_abi_version.restype, lib.evp_abi_version.argtypes = C.c_int, []
+    have = lib.evp_abi_version()
+    if have != ABI_VERSION:
+        raise EvpError(f"{LIB_PATH} has ABI version {have}, this binding expects {ABI_VERSION} (include/evtpretrain.h): rebuild it "
+                       "(`python -c 'import __graft_entry__ as g; g.build()'`)")
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = _INT_RESTYPE.get(name, C.c_int)
     for name, rt in _OTHER_RESTYPE.items():
         getattr(lib, name).restype = rt
         getattr(lib, name).argtypes = []

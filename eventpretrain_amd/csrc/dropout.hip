@@ -54,7 +54,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
 // 4 elements per thread: keep_i = (bits_i * 2^-32 >= p); out = x * keep / (1 - p); mask byte = keep
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_fwd_kernel(const T *__restrict__ x, T *__restrict__ out, uint8_t *__restrict__ mask, int64_t n, float p,
-                                                          uint64_t seed, uint64_t offset) {
+                                                          uint64_t seed, const uint64_t *__restrict__ seed_dev, uint64_t offset) {
+  // seed_dev: a device scalar added to the key -- drawn per step ON the device, so that a replayed HIP graph (whose kernel
+  // arguments are frozen at capture) still draws fresh masks every replay
+  if (seed_dev) seed += *seed_dev;
   const float inv = 1.f / (1.f - p);
   const int64_t n4 = (n + 3) / 4;
   for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (int64_t)gridDim.x * 256) {
@@ -96,14 +99,15 @@ extern "C" int evp_rows_scale_f32(const float *x, const float *u, float keep_pro
   return EVP_OK;
 }
 
-extern "C" int evp_dropout_fwd(const void *x, int dtype, void *out, void *mask, int64_t n, float p, uint64_t seed, uint64_t offset, void *stream) {
+extern "C" int evp_dropout_fwd(const void *x, int dtype, void *out, void *mask, int64_t n, float p, uint64_t seed, const void *seed_dev, uint64_t offset,
+                               void *stream) {
   EVP_CHECK_ARG(x && out && mask && n > 0 && p >= 0.f && p < 1.f, EVP_EINVAL, "evp_dropout_fwd: bad argument (0 <= p < 1)");
   EVP_CHECK_ARG(dtype == EVP_F32 || dtype == EVP_BF16, EVP_EINVAL, "evp_dropout_fwd: bad dtype %d", dtype);
   const unsigned g = grid_for((n + 3) / 4);
   if (dtype == EVP_F32)
-    hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float *)x, (float *)out, (uint8_t *)mask, n, p, seed, offset);
+    hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float *)x, (float *)out, (uint8_t *)mask, n, p, seed, (const uint64_t *)seed_dev, offset);
   else
-    hipLaunchKernelGGL(dropout_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x, (bf16_t *)out, (uint8_t *)mask, n, p, seed, offset);
+    hipLaunchKernelGGL(dropout_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x, (bf16_t *)out, (uint8_t *)mask, n, p, seed, (const uint64_t *)seed_dev, offset);
   EVP_CHECK_LAUNCH("evp_dropout_fwd");
   return EVP_OK;
 }

@@ -12,7 +12,7 @@ void evp_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 extern "C" const char *evp_last_error(void) { return g_err; }
-extern "C" int evp_abi_version(void) { return 1; }
+extern "C" int evp_abi_version(void) { return EVP_ABI_VERSION; }
 extern "C" const char *evp_target_arch(void) { return "gfx950"; }
 
 namespace {

@@ -49,6 +49,11 @@ class GraphedStep:
         hook before anything is launched and copied to the static device buffer; False = the captured graph cannot serve
         this step, which then runs eagerly with the same noise."""
         self.model, self.opt, self.forward, self.reducer = model, optimizer, forward, reducer
+        if reducer is not None:
+            # the reducer SUMs over ranks: the mean must be in force before anything is captured or stepped (ADVICE r3 -- the epoch
+            # loops hand their executor the scaler's reducer without ever calling the scaler)
+            from .parallel import ensure_mean_grad_scale
+            ensure_mean_grad_scale(optimizer, reducer, "GraphedStep")
         if step_prepare is not None and reducer is not None:
             # The hook decides per step, from THIS rank's noise, whether the captured launch shape fits; a rank that falls back
             # to an eager step while the others replay would leave the RCCL all-reduces unmatched (a hang at a random step).
@@ -69,6 +74,7 @@ class GraphedStep:
         self.eager_fallbacks = 0
         self.noise_feed = None         # optional iterator of (B, L) noise tensors used instead of a draw (tests: a given noise sequence)
         self.graph = self.graph0 = self.graph2 = self.graphB = self.plan = None
+        self._static_grads, self._ptr_tables = [], None
         self.parts = False
         self.loss = None
         self._tables_read = None       # event: the last replay's H2D nodes have read the pinned scalar tables
@@ -310,6 +316,16 @@ class GraphedStep:
         if self.noise is not None:
             B = inputs[0].shape[0]
             noise = torch.rand(B, *self.noise.shape[1:], device=self.noise.device, generator=self.gen)
+        if self.graph is None:
+            # nothing captured (capture failed or was refused): a plain eager step on the given inputs, data-parallel included --
+            # every rank meets the short batch at the same iteration, so the reducer's collectives match
+            out = self.forward(self.model, *inputs, noise)
+            out[0].backward()
+            if self.reducer is not None:
+                self.reducer.finish()
+            self.opt.step()
+            self.opt.zero_grad(set_to_none=True)
+            return out[0].detach()
         return self._eager_fallback(list(inputs), noise)
 
     def _eager_fallback(self, inputs=None, noise=None):

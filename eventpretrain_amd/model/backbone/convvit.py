@@ -91,7 +91,7 @@ class ConvViT(nn.Module):
         t3 = ops.LinearFn.apply(t3, self.patch_embed4.weight, self.patch_embed4.bias)
         t3 = ops.AddPosGatherFn.apply(t3, self.pos_embed, ids_keep)
         if self.training and self.drop_rate > 0:          # pos_drop (convvit.py:132,176)
-            t3 = ops.DropoutFn.apply(t3, self.drop_rate, int(torch.randint(0, 2 ** 62, (1,)).item()))
+            t3 = ops.DropoutFn.apply(t3, self.drop_rate, ops.draw_drop_seed(t3.device))
         return t1, t2, t3, (s1, s2)
 
     def forward(self, x, mask=False, noise=None):

@@ -281,7 +281,7 @@ class SwinTransformer(nn.Module):
         ids = plan.tok_ids.unsqueeze(0).expand(B, -1).contiguous()
         t = self.patch_embed(x, ids)
         if self.training and self.drop_rate > 0:          # pos_drop (swin.py:185,258)
-            t = ops.DropoutFn.apply(t, self.drop_rate, int(torch.randint(0, 2 ** 62, (1,)).item()))
+            t = ops.DropoutFn.apply(t, self.drop_rate, ops.draw_drop_seed(t.device))
         outs, attn = [], None
         last = len(self.swin_block) - 1
         for i, blk in enumerate(self.swin_block):

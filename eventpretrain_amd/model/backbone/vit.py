@@ -71,7 +71,7 @@ class ViT(nn.Module):
     def pos_drop(self, t):
         """nn.Dropout(p=drop_rate) on the embedded tokens (vit.py:114,137): training mode only."""
         if self.training and self.drop_rate > 0:
-            t = ops.DropoutFn.apply(t, self.drop_rate, int(torch.randint(0, 2 ** 62, (1,)).item()))
+            t = ops.DropoutFn.apply(t, self.drop_rate, ops.draw_drop_seed(t.device))
         return t
 
     def forward(self, x, mask=False, noise=None):

@@ -706,14 +706,17 @@ class BlockDrop:
     """Stochastic regularisers of ONE call of a residual block (reference vit_block.py:241,252-253 / conv_block.py:35,43-49 /
     swin_block.py:257,270-271; timm `drop_path`, nn.Dropout): `u1`, `u2` = float32 [x.shape[0]] uniform draws for the two
     DropPath applications (None = off), keep_prob = 1 - drop_path; `drop` = elementwise dropout rate of the branch outputs and the
-    MLP hidden (proj_drop / Mlp.drop), its masks drawn by evp_dropout_fwd from (seed, a per-use offset). A block called with
-    rd=None takes the fused fast path (residual add inside the GEMM epilogue)."""
+    MLP hidden (proj_drop / Mlp.drop), its masks drawn by evp_dropout_fwd from (seed, a per-use offset). `seed` is an int (tests:
+    a given stream) or a 1-element int64 DEVICE tensor (draw_drop_seed): the kernel reads it at run time, so a replayed HIP graph --
+    whose kernel arguments are frozen at capture -- draws new masks on every replay. A block called with rd=None takes the fused
+    fast path (residual add inside the GEMM epilogue)."""
 
     def __init__(self, u1=None, u2=None, keep_prob=1.0, drop=0.0, seed=0, masks=None):
         self.u = (u1, u2)
         self.keep_prob = float(keep_prob)
         self.drop = float(drop)
-        self.seed = int(seed)
+        self.seed_dev = seed if torch.is_tensor(seed) else None
+        self.seed = 0 if torch.is_tensor(seed) else int(seed)
         self.masks = masks            # optional explicit uint8 masks {"proj": .., "hidden": .., "fc2": ..} (tests: given-mask parity)
         self._n = 0
 
@@ -732,7 +735,7 @@ def dropout_fwd(x, rd, key):
         call("evp_dropout_apply", ptr(_chk(x)), dt(x), ptr(mask), ptr(out), n, 1.0 / (1.0 - rd.drop), stream_ptr())
         return out, mask
     mask = torch.empty(n, dtype=torch.uint8, device=x.device)
-    call("evp_dropout_fwd", ptr(_chk(x)), dt(x), ptr(out), ptr(mask), n, rd.drop, rd.seed, rd.next_offset(n), stream_ptr())
+    call("evp_dropout_fwd", ptr(_chk(x)), dt(x), ptr(out), ptr(mask), n, rd.drop, rd.seed, ptr(rd.seed_dev), rd.next_offset(n), stream_ptr())
     return out, mask
 
 
@@ -1780,7 +1783,7 @@ def draw_block_drop(module, n_samples, device):
     """BlockDrop for one training-mode call of a residual block module carrying `drop_path_rate` / `drop_rate` attributes, or None
     when both are off (the fused fast path). The draws come from torch's default generator of the device (as timm's `drop_path`
     and nn.Dropout do), so torch.manual_seed reproduces a run; the per-element masks use the Philox stream keyed by a seed
-    drawn from the host generator."""
+    drawn from the same device generator (draw_drop_seed)."""
     dp = float(getattr(module, "drop_path_rate", 0.0) or 0.0)
     dr = float(getattr(module, "drop_rate", 0.0) or 0.0)
     if not module.training or (dp <= 0.0 and dr <= 0.0):
@@ -1789,8 +1792,14 @@ def draw_block_drop(module, n_samples, device):
     if dp > 0.0:
         u = torch.rand(2, n_samples, device=device)
         u1, u2 = u[0], u[1]
-    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if dr > 0.0 else 0
+    seed = draw_drop_seed(device) if dr > 0.0 else 0
     return BlockDrop(u1, u2, 1.0 - dp, dr, seed)
+
+
+def draw_drop_seed(device):
+    """Key of one dropout stream, drawn ON the device from torch's generator (no host read-back; under HIP-graph capture torch's
+    generator advances per replay, so every replay of a captured step gets fresh keys -- ADVICE r3)."""
+    return torch.randint(0, 2 ** 62, (1,), device=device, dtype=torch.int64)
 
 
 class AddFn(torch.autograd.Function):

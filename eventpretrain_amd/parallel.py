@@ -15,6 +15,26 @@ import torch
 import torch.distributed as dist
 
 
+def ensure_mean_grad_scale(optimizer, reducer, who="data-parallel step"):
+    """The reducers SUM gradients over ranks; the MEAN that DistributedDataParallel applies (main_pretrain.py:319) rides on
+    FusedAdamW.grad_scale. Set it when the caller left the default 1.0, refuse anything else than 1 / world -- a silent
+    world-times-larger update otherwise. Returns the scale in force. Shared by NativeScalerWithGradNormCount and
+    engine.GraphedStep."""
+    gs = float(getattr(optimizer, "grad_scale", 1.0))
+    if reducer is None:
+        return gs
+    world = int(getattr(reducer, "world_size", 1))
+    if hasattr(optimizer, "grad_scale"):
+        if gs == 1.0 and world > 1:
+            optimizer.grad_scale = gs = 1.0 / world
+        elif abs(gs * world - 1.0) > 1e-6:
+            raise ValueError("%s: with a gradient reducer the optimizer's grad_scale must be 1 / world_size (= %g), got %g"
+                             % (who, 1.0 / world, gs))
+    elif world > 1:
+        raise ValueError("%s: a gradient reducer needs an optimizer with a grad_scale (FusedAdamW)" % who)
+    return gs
+
+
 class _Plan:
     def __init__(self, flats, others, bucket, views, group):
         self.flats, self.others, self.bucket, self.views, self.group = flats, others, bucket, views, group

@@ -212,19 +212,9 @@ class NativeScalerWithGradNormCount:
         if not update_grad:
             return None
         reducer = reducer if reducer is not None else self.reducer
-        gs = float(getattr(optimizer, "grad_scale", 1.0))
+        from ..parallel import ensure_mean_grad_scale
+        gs = ensure_mean_grad_scale(optimizer, reducer, "NativeScalerWithGradNormCount")
         if reducer is not None:
-            # the buffers will hold the SUM over ranks: the MEAN that DDP applies must ride on the optimizer's grad_scale. Set it
-            # when the caller left the default, refuse anything else than 1 / world (a silent world-times-larger update otherwise)
-            world = int(getattr(reducer, "world_size", 1))
-            if hasattr(optimizer, "grad_scale"):
-                if gs == 1.0 and world > 1:
-                    optimizer.grad_scale = gs = 1.0 / world
-                elif abs(gs * world - 1.0) > 1e-6:
-                    raise ValueError("NativeScalerWithGradNormCount: with a gradient reducer the optimizer's grad_scale must be 1 / world_size "
-                                     "(= %g), got %g" % (1.0 / world, gs))
-            elif world > 1:
-                raise ValueError("NativeScalerWithGradNormCount: a gradient reducer needs an optimizer with a grad_scale (FusedAdamW)")
             reducer.finish()
         norm = get_grad_norm_(parameters, optimizer=optimizer)
         norm = norm * gs                     # the norm of the gradient the optimizer applies (the mean over ranks; 1 without a reducer)

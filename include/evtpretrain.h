@@ -30,7 +30,9 @@ enum { EVP_F32 = 0, EVP_BF16 = 1 };
 enum { EVP_ACT_NONE = 0, EVP_ACT_GELU = 1, EVP_ACT_DGELU = 2, EVP_ACT_RELU = 3, EVP_ACT_DRELU = 4 };
 
 const char *evp_last_error(void);
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header; bumped on any signature change (2: evp_dropout_fwd takes a device-side seed; evp_gemm_desc lost its
+ * stream-K workspace fields in round 3). A host binding must compare evp_abi_version() with EVP_ABI_VERSION at load time. */
+#define EVP_ABI_VERSION 2
 int evp_abi_version(void);
 /* Name of the code object's target ("gfx950"). */
 const char *evp_target_arch(void);
@@ -453,11 +455,12 @@ int evp_token_mean_bwd(const float *g, int B, int N, int D, float *dx, void *str
  *   keep_prob >= 1: s_b = 1); out_lp (optional) receives s_b * x[m,:] in bf16. Forward: x + drop_path(branch); backward: the
  *   branch's incoming gradient s_b * g. float32, D % 4 == 0; out or out_lp may be NULL.
  * Dropout (nn.Dropout; vit_block.py:137-141,226-231, vit.py:114): evp_dropout_fwd draws keep ~ Bernoulli(1 - p) per element
- *   from Philox4x32-10 keyed by (seed, offset + element / 4), writes out = x * keep / (1 - p) and mask (uint8, 1 = kept);
+ *   from Philox4x32-10 keyed by (seed + *seed_dev, offset + element / 4) -- seed_dev (optional) is a uint64 scalar in DEVICE memory,
+ *   drawn per step on the device so that a replayed HIP graph, whose kernel arguments are frozen, draws fresh masks -- writes out = x * keep / (1 - p) and mask (uint8, 1 = kept);
  *   evp_dropout_apply: out = x * mask * scale (the backward, and the forward for a given mask). dtype = EVP_F32 | EVP_BF16. */
 int evp_rows_scale_f32(const float *x, const float *u, float keep_prob, const float *res, int64_t M, int D, int rows_per_sample,
                        float *out, void *out_lp, void *stream);
-int evp_dropout_fwd(const void *x, int dtype, void *out, void *mask, int64_t n, float p, uint64_t seed, uint64_t offset, void *stream);
+int evp_dropout_fwd(const void *x, int dtype, void *out, void *mask, int64_t n, float p, uint64_t seed, const void *seed_dev, uint64_t offset, void *stream);
 int evp_dropout_apply(const void *x, int dtype, const void *mask, void *out, int64_t n, float scale, void *stream);
 
 #ifdef __cplusplus
