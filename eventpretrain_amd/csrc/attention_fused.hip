@@ -122,32 +122,33 @@ template <int DH> __device__ __forceinline__ void head_of_block(int bid, int nbl
 // BIAS (windowed attention, model/sub_module/swin_block.py:135-158): logits = q.k*scale + addm[group][head][query][key], where
 // addm holds the gathered relative-position bias, or -100 for the pairs the reference masks (tokens of different windows, padding
 // slots); group = batch index % nG; addm is [nG][heads][NP][NP] f32 (evp_window_bias_build).
-template <int DH, int NT, int NW, bool BIAS = false>
-__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16_t *qkv, bf16_t *out, float *lse, bf16_t *probs, int N, int heads,
-                                                       float scale, int64_t ldp, unsigned long long *dbg, const float *addm,
-                                                       int nG) {
-  unsigned long long t0 = 0, t1 = 0;
-  if (dbg) t0 = __builtin_readcyclecounter();
-  constexpr int NP = 16 * NT, IMG = NP * DH * 2, KS = DH / 32, DT = DH / 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *Qs = smem, *Ks = smem + IMG, *Vs = smem + 2 * IMG;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  int b, h;
-  head_of_block<DH>(blockIdx.x, gridDim.x, heads, b, h);
-  const int bh = b * heads + h;
-  const int64_t C = (int64_t)heads * DH, tok = 3 * C;
-  const bf16_t *base = qkv + (int64_t)b * N * tok + (int64_t)h * DH;
-  {
-    HeadStage<DH, NP, 3, 64 * NW> st;
+// The kernel is built from three pieces so that a persistent workgroup can keep the NEXT head's loads in flight while it computes
+// the current one: fwd_stage_load (global -> registers), fwd_stage_store (registers -> LDS images), attn_fwd_compute.
+template <int DH, int NT, int NW> struct FwdStage {
+  static constexpr int NP = 16 * NT, IMG = NP * DH * 2;
+  HeadStage<DH, NP, 3, 64 * NW> st;
+  __device__ __forceinline__ void load(const bf16_t *qkv, int N, int heads, int b, int h, int tid) {
+    const int64_t C = (int64_t)heads * DH, tok = 3 * C;
+    const bf16_t *base = qkv + (int64_t)b * N * tok + (int64_t)h * DH;
     const bf16_t *const src[3] = {base, base + C, base + 2 * C};
     const int64_t toks[3] = {tok, tok, tok};
     st.load(src, toks, N, tid);
-    st.store(0, Qs, tid);
-    st.store(1, Ks, tid);
-    st.store(2, Vs, tid);
   }
-  __syncthreads();
-  if (dbg) t1 = __builtin_readcyclecounter();
+  __device__ __forceinline__ void store(char *smem, int tid) const {
+    st.store(0, smem, tid);
+    st.store(1, smem + IMG, tid);
+    st.store(2, smem + 2 * IMG, tid);
+  }
+};
+
+template <int DH, int NT, int NW, bool BIAS>
+__device__ __forceinline__ void attn_fwd_compute(char *smem, bf16_t *out, float *lse, bf16_t *probs, int N, int heads, float scale, int64_t ldp,
+                                                 const float *addm, int nG, const int b, const int h) {
+  constexpr int NP = 16 * NT, IMG = NP * DH * 2, KS = DH / 32, DT = DH / 16;
+  char *Qs = smem, *Ks = smem + IMG, *Vs = smem + 2 * IMG;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int bh = b * heads + h;
+  const int64_t C = (int64_t)heads * DH;
   const float c2 = scale * 1.44269504088896340736f;   // exp(x*scale) = exp2(x*c2)
 
   for (int strip = wave; strip * 16 < N; strip += NW) {
@@ -225,6 +226,25 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16_t *qkv, bf
       if (q < N) *reinterpret_cast<uint2 *>(out + ((int64_t)b * N + q) * C + h * DH + dt * 16 + 4 * g) = pack4(O);
     }
   }
+}
+
+template <int DH, int NT, int NW, bool BIAS = false>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16_t *qkv, bf16_t *out, float *lse, bf16_t *probs, int N, int heads,
+                                                       float scale, int64_t ldp, unsigned long long *dbg, const float *addm,
+                                                       int nG) {
+  unsigned long long t0 = 0, t1 = 0;
+  if (dbg) t0 = __builtin_readcyclecounter();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int b, h;
+  head_of_block<DH>(blockIdx.x, gridDim.x, heads, b, h);
+  {
+    FwdStage<DH, NT, NW> fs;
+    fs.load(qkv, N, heads, b, h, threadIdx.x);
+    fs.store(smem, threadIdx.x);
+  }
+  __syncthreads();
+  if (dbg) t1 = __builtin_readcyclecounter();
+  attn_fwd_compute<DH, NT, NW, BIAS>(smem, out, lse, probs, N, heads, scale, ldp, addm, nG, b, h);
   if (dbg && (threadIdx.x & 63) == 0) {
     const unsigned long long t2 = __builtin_readcyclecounter();
     if ((threadIdx.x >> 6) < 4) {
@@ -234,43 +254,78 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16_t *qkv, bf
   }
 }
 
+// Persistent form (round 4). The one-workgroup-per-head launch runs in lockstep: every resident workgroup stages its head at the
+// same time (a chip-wide HBM burst), then nobody touches memory until the write-out. Here the grid is a fixed number of workgroups
+// per CU and each walks its share of the (batch, head) items;
+//   SKEW: the workgroups of the second half of the grid (the second slot of every CU) start `skew` ticks of the 100 MHz counter
+//         late, so that from then on one workgroup of a CU stages while the other computes;
+//   PF:   the loads of item i + 1 are issued (into registers) before the strips of item i are computed.
+// Items are dealt round-robin (item = blockIdx.x + k * gridDim.x), so the head pairs of head_of_block() stay on one XCD.
+__device__ __forceinline__ void skew_wait(int ticks) {
+  if (ticks <= 0) return;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+// (waves-per-SIMD floor = the occupancy the one-head kernels reach: without it the item loop's hoisted addresses cost 20-40 registers
+// and a resident workgroup)
+template <int DH, int NT, int NW, bool PF>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PF ? 1 : (NW == 4 ? (DH == 64 && NT <= 8 ? 3 : 2) : 2))))
+void attn_fwd_persist_kernel(const bf16_t *qkv, bf16_t *out, float *lse, int N, int heads, float scale,
+                                                               int n_items, int skew) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (blockIdx.x >= (gridDim.x >> 1)) skew_wait(skew);
+  int b, h;
+  FwdStage<DH, NT, NW> fs;
+  int it = blockIdx.x;
+  if (PF && it < n_items) {
+    head_of_block<DH>(it, n_items, heads, b, h);
+    fs.load(qkv, N, heads, b, h, threadIdx.x);
+  }
+  for (; it < n_items; it += gridDim.x) {
+    head_of_block<DH>(it, n_items, heads, b, h);
+    if (!PF) fs.load(qkv, N, heads, b, h, threadIdx.x);
+    fs.store(smem, threadIdx.x);
+    __syncthreads();
+    if (PF && it + (int)gridDim.x < n_items) {
+      int b2, h2;
+      head_of_block<DH>(it + gridDim.x, n_items, heads, b2, h2);
+      fs.load(qkv, N, heads, b2, h2, threadIdx.x);
+    }
+    attn_fwd_compute<DH, NT, NW, false>(smem, out, lse, nullptr, N, heads, scale, 0, nullptr, 1, b, h);
+    __syncthreads();                       // every wave is done with the images before the next item overwrites them
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------- backward
 // BIAS: addm as in the forward, addmT its transpose per (group, head) ([key][query]: the key-on-lane pass reads 4 consecutive
 // queries); the d logits of this wave's query strip (one strip per wave: NW >= number of strips) are ADDED into dacc, which the
 // windowed wrapper keeps across the batch items it walks and flushes once.
-template <int DH, int NT, int NW, bool BIAS>
-__device__ __forceinline__ void attn_bwd_body(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse, bf16_t *dqkv, int N,
-                                              int heads, float scale, const float *addm, const float *addmT, int nG, const int b, const int h,
-                                              f32x4 (&dacc)[NT], unsigned long long *dbg = nullptr) {
-  unsigned long long t0 = 0, t1 = 0, t2 = 0;
-  if (dbg) t0 = __builtin_readcyclecounter();
-  #ifndef ATTN_CH
-#define ATTN_CH 4
-#endif
-  constexpr int NP = 16 * NT, IMG = NP * DH * 2, KS = DH / 32, DT = DH / 16, CH = ATTN_CH;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *Qs = smem, *Ks = smem + IMG, *Vs = smem + 2 * IMG, *Gs = smem + 3 * IMG;   // Gs = dO
-  float *Ls = reinterpret_cast<float *>(smem + 4 * IMG), *Ds = Ls + NP;          // log-sum-exp, delta = rowsum(dO * O)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
-  const int bh = b * heads + h;
-  const int64_t C = (int64_t)heads * DH, tok = 3 * C;
-  const bf16_t *base = qkv + (int64_t)b * N * tok + (int64_t)h * DH;
-  const bf16_t *go = dout + (int64_t)b * N * C + (int64_t)h * DH, *oo = out + (int64_t)b * N * C + (int64_t)h * DH;
-  {
-    // Q, K, V, dO and O in one batch of loads; O is only needed for delta[q] = sum_d dO[q,d] * O[q,d], formed from the
-    // staged registers (the DH/8 consecutive threads that share a row meet with shuffles)
-    using ST = HeadStage<DH, NP, 5, 64 * NW>;
-    constexpr int NTHR = 64 * NW;
-    ST st;
+template <int DH, int NT, int NW> struct BwdStage {
+  // Q, K, V, dO and O in one batch of loads; O is only needed for delta[q] = sum_d dO[q,d] * O[q,d], formed from the
+  // staged registers (the DH/8 consecutive threads that share a row meet with shuffles)
+  static constexpr int NP = 16 * NT, IMG = NP * DH * 2, NTHR = 64 * NW, NL = (NP + NTHR - 1) / NTHR;
+  using ST = HeadStage<DH, NP, 5, NTHR>;
+  ST st;
+  float lv[NL];
+  __device__ __forceinline__ void load(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse, int N, int heads, int b, int h,
+                                       int tid) {
+    const int bh = b * heads + h;
+    const int64_t C = (int64_t)heads * DH, tok = 3 * C;
+    const bf16_t *base = qkv + (int64_t)b * N * tok + (int64_t)h * DH;
+    const bf16_t *go = dout + (int64_t)b * N * C + (int64_t)h * DH, *oo = out + (int64_t)b * N * C + (int64_t)h * DH;
     const bf16_t *const src[5] = {base, base + C, base + 2 * C, go, oo};
     const int64_t toks[5] = {tok, tok, tok, C, C};
     st.load(src, toks, N, tid);
-    float lv[(NP + NTHR - 1) / NTHR];
 #pragma unroll
-    for (int i = 0; i < (NP + NTHR - 1) / NTHR; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int r = tid + i * NTHR;
       lv[i] = (r < N) ? lse[(int64_t)bh * N + r] : INFINITY;      // exp(-inf) = 0 on the padded queries
     }
+  }
+  __device__ __forceinline__ void store(char *smem, int tid) const {
+    char *Qs = smem, *Ks = smem + IMG, *Vs = smem + 2 * IMG, *Gs = smem + 3 * IMG;   // Gs = dO
+    float *Ls = reinterpret_cast<float *>(smem + 4 * IMG), *Ds = Ls + NP;          // log-sum-exp, delta = rowsum(dO * O)
     st.store(0, Qs, tid);
     st.store(1, Ks, tid);
     st.store(2, Vs, tid);
@@ -290,13 +345,25 @@ __device__ __forceinline__ void attn_bwd_body(const bf16_t *qkv, const bf16_t *o
       if (ch == 0 && (ST::TOTAL % NTHR == 0 || c < ST::TOTAL)) Ds[row] = d;
     }
 #pragma unroll
-    for (int i = 0; i < (NP + NTHR - 1) / NTHR; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int r = tid + i * NTHR;
       if (r < NP) Ls[r] = lv[i];
     }
   }
-  __syncthreads();
-  if (dbg) t1 = __builtin_readcyclecounter();
+};
+
+#ifndef ATTN_CH
+#define ATTN_CH 4
+#endif
+
+template <int DH, int NT, int NW, bool BIAS>
+__device__ __forceinline__ void attn_bwd_compute(char *smem, bf16_t *dqkv, int N, int heads, float scale, const float *addm, const float *addmT, int nG,
+                                                 const int b, const int h, f32x4 (&dacc)[NT], unsigned long long *t2p = nullptr) {
+  constexpr int NP = 16 * NT, IMG = NP * DH * 2, KS = DH / 32, DT = DH / 16, CH = ATTN_CH;
+  char *Qs = smem, *Ks = smem + IMG, *Vs = smem + 2 * IMG, *Gs = smem + 3 * IMG;   // Gs = dO
+  float *Ls = reinterpret_cast<float *>(smem + 4 * IMG), *Ds = Ls + NP;          // log-sum-exp, delta = rowsum(dO * O)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, li = lane & 15;
+  const int64_t C = (int64_t)heads * DH, tok = 3 * C;
   const float c2 = scale * 1.44269504088896340736f, l2e = 1.44269504088896340736f;
 
   // ---- pass 1, query on the lane: dQ ----
@@ -369,7 +436,7 @@ __device__ __forceinline__ void attn_bwd_body(const bf16_t *qkv, const bf16_t *o
     }
   }
 
-  if (dbg) t2 = __builtin_readcyclecounter();
+  if (t2p) *t2p = __builtin_readcyclecounter();
   // ---- pass 2, key on the lane: dK, dV ---- (strips dealt to the waves in the opposite order of pass 1: with 13 strips
   // the wave that took four in pass 1 takes three here)
   for (int strip = NW - 1 - wave; strip * 16 < N; strip += NW) {
@@ -431,6 +498,23 @@ __device__ __forceinline__ void attn_bwd_body(const bf16_t *qkv, const bf16_t *o
       }
     }
   }
+}
+
+template <int DH, int NT, int NW, bool BIAS>
+__device__ __forceinline__ void attn_bwd_body(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse, bf16_t *dqkv, int N,
+                                              int heads, float scale, const float *addm, const float *addmT, int nG, const int b, const int h,
+                                              f32x4 (&dacc)[NT], unsigned long long *dbg = nullptr) {
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  if (dbg) t0 = __builtin_readcyclecounter();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  {
+    BwdStage<DH, NT, NW> bs;
+    bs.load(qkv, out, dout, lse, N, heads, b, h, threadIdx.x);
+    bs.store(smem, threadIdx.x);
+  }
+  __syncthreads();
+  if (dbg) t1 = __builtin_readcyclecounter();
+  attn_bwd_compute<DH, NT, NW, BIAS>(smem, dqkv, N, heads, scale, addm, addmT, nG, b, h, dacc, dbg ? &t2 : nullptr);
   if (dbg && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 8) {      // measurement aid: per wave {staging, pass 1, pass 2} cycles
     const unsigned long long t3 = __builtin_readcyclecounter();
     unsigned long long *o = dbg + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 3;
@@ -445,6 +529,36 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16_t *qkv, co
   head_of_block<DH>(blockIdx.x, gridDim.x, heads, b, h);
   f32x4 unused[NT];
   attn_bwd_body<DH, NT, NW, false>(qkv, out, dout, lse, dqkv, N, heads, scale, nullptr, nullptr, 1, b, h, unused, dbg);
+}
+
+// Persistent form of the backward (see attn_fwd_persist_kernel).
+template <int DH, int NT, int NW, bool PF>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PF ? 1 : (NW == 8 ? 4 : NW == 4 ? 2 : 4))))
+void attn_bwd_persist_kernel(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse,
+                                                               bf16_t *dqkv, int N, int heads, float scale, int n_items, int skew) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (blockIdx.x >= (gridDim.x >> 1)) skew_wait(skew);
+  f32x4 unused[NT];
+  int b, h;
+  BwdStage<DH, NT, NW> bs;
+  int it = blockIdx.x;
+  if (PF && it < n_items) {
+    head_of_block<DH>(it, n_items, heads, b, h);
+    bs.load(qkv, out, dout, lse, N, heads, b, h, threadIdx.x);
+  }
+  for (; it < n_items; it += gridDim.x) {
+    head_of_block<DH>(it, n_items, heads, b, h);
+    if (!PF) bs.load(qkv, out, dout, lse, N, heads, b, h, threadIdx.x);
+    bs.store(smem, threadIdx.x);
+    __syncthreads();
+    if (PF && it + (int)gridDim.x < n_items) {
+      int b2, h2;
+      head_of_block<DH>(it + gridDim.x, n_items, heads, b2, h2);
+      bs.load(qkv, out, dout, lse, N, heads, b2, h2, threadIdx.x);
+    }
+    attn_bwd_compute<DH, NT, NW, false>(smem, dqkv, N, heads, scale, nullptr, nullptr, 1, b, h, unused);
+    __syncthreads();
+  }
 }
 
 // Windowed form: workgroup = (group, head, batch chunk). It walks `per` batch items of its (group, head), keeping the d logits of
@@ -499,33 +613,71 @@ static inline int attn_bwd_waves() {
   return g_attn_bwd_waves;
 }
 
+// Launch form (evp_attention_set_variant; A/B aid and the round-4 default once measured):
+//   mode 0 = one workgroup per (batch, head); 1 = persistent; 2 = persistent + next item's loads in flight under the strips
+//   grid = persistent workgroups in the launch (a multiple of 16, capped at the item count); skew = start delay of the second
+//   half of the grid in 10-ns ticks
+static int g_attn_mode[2] = {0, 0}, g_attn_grid[2] = {512, 512}, g_attn_skew[2] = {0, 0};
+
+template <int DH, int NT, int NW>
+void launch_fwd_nw(const bf16_t *qkv, bf16_t *out, float *lse, bf16_t *probs, int B, int N, int heads, float scale, int64_t ldp, hipStream_t s) {
+  constexpr int smem = 3 * 16 * NT * DH * 2;
+  const int mode = probs ? 0 : g_attn_mode[0];
+  const int items = B * heads;
+  int grid = g_attn_grid[0];
+  if (grid > items) grid = items;
+  grid &= ~15;
+  if (mode == 0 || grid < 16) {
+    auto k = attn_fwd_kernel<DH, NT, NW>;
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(k, dim3(items), dim3(64 * NW), smem, s, qkv, out, lse, probs, N, heads, scale, ldp, g_attn_dbg, (const float *)nullptr, 1);
+  } else if (mode == 1) {
+    auto k = attn_fwd_persist_kernel<DH, NT, NW, false>;
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), smem, s, qkv, out, lse, N, heads, scale, items, g_attn_skew[0]);
+  } else {
+    auto k = attn_fwd_persist_kernel<DH, NT, NW, true>;
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), smem, s, qkv, out, lse, N, heads, scale, items, g_attn_skew[0]);
+  }
+}
 template <int DH, int NT>
 int launch_fwd(const bf16_t *qkv, bf16_t *out, float *lse, bf16_t *probs, int B, int N, int heads, float scale, int64_t ldp, hipStream_t s) {
-  constexpr int smem = 3 * 16 * NT * DH * 2;
-  if (attn_fwd_waves() == 8) {
-    auto k = attn_fwd_kernel<DH, NT, 8>;
-    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(k, dim3(B * heads), dim3(512), smem, s, qkv, out, lse, probs, N, heads, scale, ldp, g_attn_dbg, (const float *)nullptr, 1);
-  } else {
-    auto k = attn_fwd_kernel<DH, NT, 4>;
-    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(k, dim3(B * heads), dim3(256), smem, s, qkv, out, lse, probs, N, heads, scale, ldp, g_attn_dbg, (const float *)nullptr, 1);
-  }
+  if (attn_fwd_waves() == 8) launch_fwd_nw<DH, NT, 8>(qkv, out, lse, probs, B, N, heads, scale, ldp, s);
+  else launch_fwd_nw<DH, NT, 4>(qkv, out, lse, probs, B, N, heads, scale, ldp, s);
   EVP_CHECK_LAUNCH("evp_attention_fused_fwd");
   return EVP_OK;
+}
+template <int DH, int NT, int NW>
+void launch_bwd_nw(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse, bf16_t *dqkv, int B, int N, int heads, float scale,
+                   hipStream_t s) {
+  constexpr int smem = 4 * 16 * NT * DH * 2 + 2 * 16 * NT * 4;
+  const int mode = g_attn_mode[1];
+  const int items = B * heads;
+  int grid = g_attn_grid[1];
+  if (grid > items) grid = items;
+  grid &= ~15;
+  if (mode == 0 || grid < 16) {
+    auto k = attn_bwd_kernel<DH, NT, NW>;
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(k, dim3(items), dim3(64 * NW), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale, g_attn_dbg);
+  } else if (mode == 1) {
+    auto k = attn_bwd_persist_kernel<DH, NT, NW, false>;
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale, items, g_attn_skew[1]);
+  } else {
+    auto k = attn_bwd_persist_kernel<DH, NT, NW, true>;
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale, items, g_attn_skew[1]);
+  }
 }
 template <int DH, int NT>
 int launch_bwd(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse, bf16_t *dqkv, int B, int N, int heads, float scale,
                hipStream_t s) {
-  constexpr int smem = 4 * 16 * NT * DH * 2 + 2 * 16 * NT * 4;
-  auto go = [&](auto kfn, int nthr) {
-    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(kfn, dim3(B * heads), dim3(nthr), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale, g_attn_dbg);
-  };
   const int nw = attn_bwd_waves();
-  if (nw == 16) go(attn_bwd_kernel<DH, NT, 16>, 1024);
-  else if (nw == 8) go(attn_bwd_kernel<DH, NT, 8>, 512);
-  else go(attn_bwd_kernel<DH, NT, 4>, 256);
+  if (nw == 16) launch_bwd_nw<DH, NT, 16>(qkv, out, dout, lse, dqkv, B, N, heads, scale, s);
+  else if (nw == 8) launch_bwd_nw<DH, NT, 8>(qkv, out, dout, lse, dqkv, B, N, heads, scale, s);
+  else launch_bwd_nw<DH, NT, 4>(qkv, out, dout, lse, dqkv, B, N, heads, scale, s);
   EVP_CHECK_LAUNCH("evp_attention_fused_bwd");
   return EVP_OK;
 }
@@ -647,6 +799,15 @@ int launch_win_bwd(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, con
 
 extern "C" int evp_attention_set_debug_buffer(void *buf) {   // measurement aid: uint64 [B*heads*4*2] {staging, compute} cycles per wave
   g_attn_dbg = reinterpret_cast<unsigned long long *>(buf);
+  return EVP_OK;
+}
+
+extern "C" int evp_attention_set_variant(int which, int mode, int grid, int skew_ticks) {
+  EVP_CHECK_ARG((which == 0 || which == 1) && mode >= 0 && mode <= 2 && grid >= 16 && grid <= 65536 && skew_ticks >= 0 && skew_ticks <= 100000,
+                EVP_EINVAL, "evp_attention_set_variant: which in {0 fwd, 1 bwd}, mode in 0..2, grid in 16..65536, skew_ticks in 0..100000");
+  g_attn_mode[which] = mode;
+  g_attn_grid[which] = grid;
+  g_attn_skew[which] = skew_ticks;
   return EVP_OK;
 }
 
