@@ -80,6 +80,7 @@ def build(args, device):
             if "norm_layer" not in k:
                 v.requires_grad = False
     world = dist.get_world_size() if dist.is_initialized() else 1
+    a.distributed = world > 1        # queue policy "all_gather": the contrastive keys of every rank enter every queue
     a.lr = a.blr * args.batch * world / 256
     groups = lrd.param_groups_lrd(a, model, a.weight_decay, layer_decay=1)
     opt = FusedAdamW(groups, lr=a.lr, betas=(0.9, 0.95), grad_scale=1.0 / world)
@@ -481,15 +482,12 @@ def main():
     step_prepare = None
     if phase == "rec":
         fwd, noise_shape = (lambda m, x, y, noise: m(x, y, is_rec=True, noise=noise)), (args.batch, cells)
-        if is_swin and not multi:
+        if is_swin:
             # Swin: the window plan is host work per pattern. The noise is drawn on the HOST (seeded per rank), the backbone's
             # fixed-shape plan tables are refreshed by one H2D copy before each replay (SwinTransformer.enable_static_plan), so
-            # ONE captured graph serves every pattern; a pattern that overflows the fixed group count runs that step eagerly.
+            # ONE captured graph serves every pattern; a pattern that overflows the fixed group count runs that step eagerly --
+            # with N > 1 on every rank at once (engine.GraphedStep._vote), in the data-parallel eager form.
             step_prepare = model.backbone.enable_static_plan(device)
-        elif is_swin:
-            # N > 1: every rank draws its own pattern, so a per-rank eager fall-back could leave the all-reduces unmatched
-            # (engine.GraphedStep refuses the hook together with a reducer): the data-parallel Swin step runs eagerly
-            use_graph = False
     else:
         fwd, noise_shape = (lambda m, x, y, noise: m(x, y)), None
     executor = GraphedStep(model, opt, fwd, [vox, tgt], noise_shape=noise_shape, generator=gen, reducer=reducer, use_graph=use_graph,

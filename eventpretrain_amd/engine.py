@@ -38,6 +38,82 @@ class BackwardCut:
         self.src = self.leaf = None
 
 
+class ForwardCollectives:
+    """The collectives INSIDE a model's forward (the contrastive stage's key all-gather, pr_hub_model.py:170-188,248-259; the
+    reference-faithful per-forward buffer broadcast), taken out of the captured HIP graphs. The step executor hands this object to
+    the model for the capture (`model.set_collective_hook`); the forward then calls, in place of the collective:
+
+      gather(t)             the all-gather's RESULT feeds the rest of the forward (in-batch InfoNCE): the capture is SPLIT here --
+                            the running graph ends, the next one begins -- and the call returns the static gathered buffer; at
+                            replay the executor runs all_gather_into_tensor(out, t) between the two graphs;
+      gather(t, then=fn)    the result only feeds `fn(gathered)`, which nothing else in this step depends on (the MoCo queue's
+                            enqueue): nothing is split; at replay the all-gather is issued asynchronously right after the forward
+                            graph, crosses xGMI under the backward graph, and `fn` runs after it;
+      pre_forward(fn)       `fn()` (a broadcast of module buffers) runs eagerly before the first graph of every step.
+    Eager steps (warm-up, fall-back) run with the hook removed, i.e. with the model's own collectives."""
+
+    def __init__(self, seq):
+        self.seq = seq            # the _GraphSeq being captured
+        self.pre, self.post = [], []
+
+    def pre_forward(self, fn):
+        self.pre.append(fn)
+
+    def gather(self, t, then=None):
+        import torch.distributed as dist
+        world = dist.get_world_size()
+        t = t.contiguous()
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        if then is not None:
+            self.post.append((t, out, then))
+            return None
+        self.seq.split(lambda: dist.all_gather_into_tensor(out, t))
+        return out
+
+
+class _GraphSeq:
+    """A captured step as a SEQUENCE of HIP graphs sharing one memory pool, with eager work (a collective) between two of them:
+    split(fn) ends the graph being captured, runs fn() once now (every rank meets the collective during capture as it will at
+    replay) and begins the next graph; replay() = graph, fn, graph, ..."""
+
+    def __init__(self, stream):
+        self.stream, self.graphs, self.between, self.cur, self.pool = stream, [], [], None, None
+
+    def begin(self):
+        g = torch.cuda.CUDAGraph()
+        kw = {} if self.pool is None else {"pool": self.pool}
+        g.capture_begin(capture_error_mode="thread_local", **kw)      # thread_local: RCCL's watchdog thread polls its events meanwhile
+        self.cur = g
+
+    def end(self):
+        self.cur.capture_end()
+        self.graphs.append(self.cur)
+        self.between.append(None)
+        if self.pool is None:
+            self.pool = self.cur.pool()
+        self.cur = None
+
+    def abort(self):
+        if self.cur is not None:
+            try:
+                self.cur.capture_end()
+            except Exception:
+                pass
+            self.cur = None
+
+    def split(self, fn):
+        self.end()
+        fn()
+        self.between[-1] = fn
+        self.begin()
+
+    def replay(self):
+        for g, fn in zip(self.graphs, self.between):
+            g.replay()
+            if fn is not None:
+                fn()
+
+
 class GraphedStep:
     def __init__(self, model, optimizer, forward, static_inputs, noise_shape=None, generator=None, reducer=None,
                  use_graph=True, warmup=2, wgrad_chunks=4, step_prepare=None, host_generator=None):
@@ -54,12 +130,14 @@ class GraphedStep:
             # loops hand their executor the scaler's reducer without ever calling the scaler)
             from .parallel import ensure_mean_grad_scale
             ensure_mean_grad_scale(optimizer, reducer, "GraphedStep")
-        if step_prepare is not None and reducer is not None:
-            # The hook decides per step, from THIS rank's noise, whether the captured launch shape fits; a rank that falls back
-            # to an eager step while the others replay would leave the RCCL all-reduces unmatched (a hang at a random step).
-            # Until the decision is made collectively and the eager fall-back has a data-parallel form, refuse the combination.
-            raise ValueError("GraphedStep: step_prepare (per-step launch geometry, the Swin window plan) cannot be combined with a "
-                             "gradient reducer; step the data-parallel Swin model without the hook (eager window plan per step)")
+        # step_prepare + reducer (the data-parallel Swin step): the hook decides per step, from THIS rank's noise, whether the captured
+        # launch shape fits. A rank that fell back to an eager step while the others replay would leave the all-reduces unmatched, so
+        # the decision is made COLLECTIVELY (_vote: a host-side MIN over ranks of one int per step, on a gloo group -- no device sync)
+        # and the fall-back has a data-parallel form (_eager_fallback): either every rank replays or every rank steps eagerly.
+        self._vote_group = None
+        if step_prepare is not None and reducer is not None and reducer.world_size > 1:
+            import torch.distributed as dist
+            self._vote_group = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
         self.inputs = [t for t in static_inputs]
         dev = self.inputs[0].device
         self.gen = generator if generator is not None else torch.Generator(device=dev)
@@ -73,7 +151,7 @@ class GraphedStep:
             self._noise_events, self._noise_turn, self._noise_cpu = [None] * 3, 0, None
         self.eager_fallbacks = 0
         self.noise_feed = None         # optional iterator of (B, L) noise tensors used instead of a draw (tests: a given noise sequence)
-        self.graph = self.graph0 = self.graph2 = self.graphB = self.plan = None
+        self.graph = self.graph0 = self.graph2 = self.graphB = self.plan = self.fc = None
         self._static_grads, self._ptr_tables = [], None
         self.parts = False
         self.loss = None
@@ -82,11 +160,11 @@ class GraphedStep:
         self.note = "eager"
         self.multi = reducer is not None
         self.wgrad_chunks = int(wgrad_chunks)
-        if use_graph and self.multi and self._forward_has_collective():
-            # collectives stay outside the captured graphs (module docstring): a forward that all-gathers the contrastive keys
-            # or re-broadcasts buffers from rank 0 is therefore not captured
+        if use_graph and self._forward_has_collective() and not hasattr(model, "set_collective_hook"):
+            # collectives stay outside the captured graphs (module docstring); a model that cannot hand them over (ForwardCollectives)
+            # is not captured
             use_graph = False
-            self.note = "eager (the forward holds a collective -- contrastive key all-gather / buffer broadcast -- which is kept out of HIP graphs)"
+            self.note = "eager (the forward holds a collective and the model has no set_collective_hook)"
         if use_graph:
             self._capture(max(2, warmup))
 
@@ -189,26 +267,39 @@ class GraphedStep:
                     else:
                         raise RuntimeError("step_prepare refused 64 noise draws in a row: nothing to capture")
                 side.synchronize()
-            g1 = torch.cuda.CUDAGraph()
-            # thread_local: RCCL's watchdog thread polls its events while this thread captures
+            seq = _GraphSeq(side)
+            fc = ForwardCollectives(seq) if (self._forward_has_collective() and hasattr(self.model, "set_collective_hook")) else None
             ops.hold_deferred_grads(self.multi)      # N ranks: the grouped weight-gradient launches stay out of the graph
-            # N ranks, masked modeling: the backward is cut at the encoder / decoder boundary (BackwardCut) and captured as two
-            # graphs, so that the decoder's weight gradients -- complete after the first -- are computed and all-reduced on side
-            # streams while the second (the encoder's backward, ~3 ms) replays: the window that hides the collective grows from the
-            # step's last ~2 ms to ~5 ms (unmeasured on more than one GPU)
+            # N ranks: the backward is cut (BackwardCut) -- masked modeling at the encoder / decoder boundary, the contrastive stage at
+            # the loss -- and captured as two graphs, so that what is complete after the first -- the decoder's weight gradients, the
+            # contrastive keys -- crosses xGMI on side streams while the second (the encoder's backward, ~3 ms) replays: the window
+            # that hides the collective grows from the step's last ~2 ms to ~5 ms (unmeasured on more than one GPU)
             cut = BackwardCut() if (self.multi and hasattr(self.model, "set_backward_cut")) else None
             early_steps = ()
+            import gc
             try:
                 if cut is not None:
                     self.model.set_backward_cut(cut)
-                with torch.cuda.graph(g1, stream=side, capture_error_mode="thread_local"):
-                    out = self.forward(self.model, *self.inputs, self.noise)
-                    out[0].backward()
-                    if not self.multi:
-                        self.opt.refresh(scalars=False)
-                        self.opt.launch()
-                    self.loss = out[0].detach()
-                    del out
+                if fc is not None:
+                    self.model.set_collective_hook(fc)
+                torch.cuda.synchronize()
+                gc.collect()
+                torch.cuda.empty_cache()
+                with torch.cuda.stream(side):
+                    seq.begin()
+                    try:
+                        out = self.forward(self.model, *self.inputs, self.noise)     # (a splitting gather ends / begins graphs in here)
+                        out[0].backward()
+                        if not self.multi:
+                            self.opt.refresh(scalars=False)
+                            self.opt.launch()
+                        self.loss = out[0].detach()
+                        del out
+                        seq.end()
+                    except BaseException:
+                        seq.abort()
+                        raise
+                g1 = seq.graphs[0]
                 if cut is not None and cut.src is not None:        # the forward used the cut: second half of the backward
                     with torch.cuda.stream(side):
                         early_steps = ops.build_deferred_plan(1)   # the decoder side's queued weight / bias gradients
@@ -220,6 +311,9 @@ class GraphedStep:
                 ops.hold_deferred_grads(False)
                 if cut is not None:
                     self.model.set_backward_cut(None)
+                if fc is not None:
+                    self.model.set_collective_hook(None)
+            self.fc = fc
             if not self.multi:
                 # the per-step scalar tables (lr, weight decay, bias corrections) travel in a graph of their own, replayed in
                 # FRONT of the step: the host may then prepare step N+1 as soon as step N has started (see step())
@@ -227,11 +321,7 @@ class GraphedStep:
                 with torch.cuda.graph(g0, stream=side, capture_error_mode="thread_local"):
                     self.opt.upload_scalars()
                 self.graph0 = g0
-            self.graph, self.note = g1, "hip-graph"
-            # what an eager fall-back step must put back: the captured gradient tensors and the optimizer's pointer tables
-            self._static_grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]
-            T = self.opt._tabs
-            self._ptr_tables = (T, T["n_grads"].copy(), T["n_lp"].copy()) if T is not None else None
+            self.graph, self.note = seq, "hip-graph"
             if self.multi:
                 # chunked weight-gradient launches interleaved with their all-reduces (parallel.OverlappedPlan)
                 with torch.cuda.stream(side):
@@ -254,8 +344,16 @@ class GraphedStep:
                              "%d weight-gradient chunks on two streams, each all-reduced (RCCL) while the next "
                              "computes, AdamW per reduced buffer" % self.wgrad_chunks) if self.parts else \
                             ("hip-graph (fwd+bwd) + %d weight-gradient chunks overlapped with RCCL all-reduce + hip-graph (AdamW)" % self.wgrad_chunks)
+                if fc is not None and (fc.post or fc.pre or len(seq.graphs) > 1):
+                    self.note += " [forward collectives outside the graphs: %d splitting key all-gather(s), %d overlapped with the backward, " \
+                                 "%d buffer broadcast(s)]" % (len(seq.graphs) - 1, len(fc.post), len(fc.pre))
+            # what an eager fall-back step must put back: the gradient tensors the captured graphs (and the reducer's plan) write and
+            # the optimizer reads, and the optimizer's pointer tables
+            self._static_grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]
+            T = self.opt._tabs
+            self._ptr_tables = (T, T["n_grads"].copy(), T["n_lp"].copy()) if T is not None else None
         except Exception as e:               # keep training; say what happened
-            self.graph = self.graph0 = self.graph2 = self.graphB = self.plan = None
+            self.graph = self.graph0 = self.graph2 = self.graphB = self.plan = self.fc = None
             self.note = "eager (graph capture failed: %r)" % (e,)
             self.opt.zero_grad(set_to_none=True)
             ops.flush_deferred_grads()
@@ -281,7 +379,7 @@ class GraphedStep:
                 dst.copy_(src, non_blocking=True)
         if self.graph is None:
             return self.eager_step()
-        if not self._draw_noise():
+        if not self._vote(self._draw_noise()):
             return self._eager_fallback()
         # The captured H2D nodes read the optimizer's pinned scalar tables when the REPLAY runs, not when it is queued: a host
         # that is a step ahead would hand step N the learning rate / bias corrections of step N+1. Wait until the replay that
@@ -296,18 +394,44 @@ class GraphedStep:
         if self.plan is not None and self.parts:
             self.graph2.replay()             # this step's lr / bias-correction tables -> device, ahead of everything that updates
             self._mark_tables_read()
-        self.graph.replay()
+        fc = self.fc
+        if fc is not None:
+            for fn in fc.pre:
+                fn()                         # (reference-faithful mode: rank 0's buffers -> every rank, before the forward)
+        self.graph.replay()                  # forward (+ backward); a splitting key all-gather runs between its graphs
+        post = []
+        if fc is not None and fc.post:
+            import torch.distributed as dist
+            # keys of this step -> every rank, asynchronously on RCCL's stream (ordered after the forward graph): under the backward
+            post = [(dist.all_gather_into_tensor(out, t, async_op=True), out, then) for t, out, then in fc.post]
         if self.plan is not None:
             if self.graphB is not None:
                 self.plan.run_early()        # decoder weight gradients + their all-reduce (+ update) on side streams ...
                 self.graphB.replay()         # ... under the encoder's backward
+            for w, out, then in post:
+                w.wait()                     # stream wait
+                then(out)                    # the enqueue of the gathered keys (one small launch)
             if self.parts:
                 self.plan.run()              # weight gradients, all-reduces and the update, part by part
             else:
                 self.plan.run()
                 self.graph2.replay()
                 self._mark_tables_read()
+        else:
+            for w, out, then in post:
+                w.wait()
+                then(out)
         return self.loss
+
+    def _vote(self, ok):
+        """All ranks replay, or all ranks fall back: MIN over ranks of this rank's verdict (host-side, gloo: no device sync; the
+        previous replay is still running on the GPU while the ranks agree on this one)."""
+        if self._vote_group is None:
+            return ok
+        import torch.distributed as dist
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self._vote_group)
+        return bool(t.item())
 
     def eager_step_with(self, *inputs):
         """One optimizer step on inputs whose shapes the captured graph cannot serve (the short last batch of an epoch), leaving
@@ -332,8 +456,6 @@ class GraphedStep:
         """One step outside the captured graph (the step's launch geometry does not fit it), leaving the graph usable: the
         eager backward must not accumulate into the captured gradient tensors, and the optimizer's eager refresh() rewrites
         the pinned pointer tables the graph's H2D nodes re-read -- both are put back."""
-        if self.multi:
-            raise RuntimeError("eager fall-back inside a data-parallel graphed step is not supported")
         self.eager_fallbacks += 1
         torch.cuda.current_stream().synchronize()
         self.opt.zero_grad(set_to_none=True)
@@ -342,6 +464,10 @@ class GraphedStep:
         else:
             out = self.forward(self.model, *inputs, noise)
         out[0].backward()
+        if self.reducer is not None:
+            # data-parallel form: every rank is here (the verdict was collective, or every rank met the same short batch), so the
+            # reducer's all-reduces match; the mean rides on the optimizer's grad_scale as in the captured step
+            self.reducer.finish()
         self.opt.step()
         self.opt.zero_grad(set_to_none=True)
         torch.cuda.current_stream().synchronize()

@@ -102,10 +102,19 @@ class PrHubModel(nn.Module):
         executor uses this to start the all-reduce of the decoder's gradients under the encoder's backward."""
         self._backward_cut = cut
 
+    _collective_hook = None
+
+    def set_collective_hook(self, hook):
+        """engine.ForwardCollectives (or None). While set, the forward hands its collectives to the hook instead of issuing them:
+        the key all-gather of the in-batch InfoNCE splits the captured step ([forward to keys] -> all_gather_into_tensor into a
+        static buffer -> [loss + backward]), the gathered enqueue of the MoCo queue and the reference-faithful buffer broadcast
+        run outside the graphs -- so the data-parallel contrastive stage replays captured graphs like the other stages."""
+        self._collective_hook = hook
+
     def forward_has_collective(self):
         """True when forward() talks to other ranks: the key all-gather of the queue / of the in-batch InfoNCE (pr_hub_model.py:
-        248-259) or the reference-faithful buffer broadcast. The step executor keeps collectives outside captured HIP graphs,
-        so it does not capture such a forward (engine.GraphedStep)."""
+        248-259) or the reference-faithful buffer broadcast. The step executor keeps collectives outside captured HIP graphs:
+        it captures such a forward through set_collective_hook (engine.ForwardCollectives)."""
         if self.args.pr_phase not in _CON_PHASES or not _dist_ready():
             return False
         pol = self.queue_policy()
@@ -127,6 +136,14 @@ class PrHubModel(nn.Module):
         and a one-thread kernel advances it, so the step has no host read-back (and can be captured in a HIP graph).
         Under the "all_gather" policy `keys` are first gathered from every rank (rank order), so B is world x local B."""
         if self.queue_policy() == "all_gather":
+            import torch.distributed as dist
+            if self.queue_length % (keys.shape[0] * dist.get_world_size()):
+                raise AssertionError("queue_length must be a multiple of the (gathered) batch size")
+            if self._collective_hook is not None:
+                # captured data-parallel step: the all-gather and the enqueue leave the graph; the executor issues the gather right
+                # after the forward graph (it crosses xGMI under the backward) and launches the enqueue behind it
+                self._collective_hook.gather(keys, then=lambda gathered: ops.enqueue_keys_dev(self.queue, gathered, self.queue_ptr))
+                return
             keys = concat_all_gather(keys)
         B = keys.shape[0]
         if self.queue_length % B:
@@ -139,7 +156,9 @@ class PrHubModel(nn.Module):
         return loss
 
     def contrastive_loss(self, emb_h, clip_emb):
-        return ops.info_nce_inbatch(emb_h, clip_emb, self.T, distributed=bool(self.args.distributed))
+        hook = self._collective_hook
+        return ops.info_nce_inbatch(emb_h, clip_emb, self.T, distributed=bool(self.args.distributed),
+                                    gather=None if hook is None else hook.gather)
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, events_voxel_grid, supp_data, is_rec=False, noise=None):
@@ -162,7 +181,10 @@ class PrHubModel(nn.Module):
             return reconstruct_loss, emb_l1, emb_l2, emb_lh, reconstruct_pred, mask, ids_restore
 
         if self.queue_policy() == "rank0_broadcast":
-            self._sync_buffers_from_rank0()
+            if self._collective_hook is not None:
+                self._collective_hook.pre_forward(self._sync_buffers_from_rank0)
+            else:
+                self._sync_buffers_from_rank0()
         if swin_:
             _, _, _, _, emb_h, attn = self.backbone(events_voxel_grid)
         else:
@@ -183,6 +205,10 @@ class PrHubModel(nn.Module):
             contrastive_loss = self.contrastive_loss_queue(emb_h_proj, clip_emb_proj)
         else:
             contrastive_loss = self.contrastive_loss(emb_h_proj, clip_emb_proj)
+        if self._backward_cut is not None:
+            # data-parallel step executor: [forward] and [backward] as two captured graphs, so that the key all-gather issued
+            # between them runs under the backward
+            contrastive_loss = self._backward_cut(contrastive_loss)
         return contrastive_loss, emb_h_org, emb_h_proj, clip_emb_org, clip_emb_proj, attn
 
 

@@ -1291,14 +1291,17 @@ def info_nce_queue(emb_h, clip_emb, queue, T_):
     return InfoNCEQueueFn.apply(q, k, queue, T_), k.detach()
 
 
-def info_nce_inbatch(emb_h, clip_emb, T_, distributed=False):
+def info_nce_inbatch(emb_h, clip_emb, T_, distributed=False, gather=None):
+    """`gather` (engine.ForwardCollectives.gather): takes the all-gather's place under a captured data-parallel step."""
     q = L2NormFn.apply(emb_h)
     k = L2NormFn.apply(clip_emb)
     rank = 0
     if distributed:
         import torch.distributed as dist
         from .model.pretrain.pr_hub_model import concat_all_gather
-        k_all, rank = concat_all_gather(k), dist.get_rank()       # RCCL all-gather over xGMI; no gradient (reference)
+        rank = dist.get_rank()
+        # RCCL all-gather over xGMI; no gradient (reference pr_hub_model.py:176-182,248-259)
+        k_all = concat_all_gather(k) if gather is None else gather(k.detach())
         return InfoNCEInBatchFn.apply(q, k_all, T_, rank, False)
     return InfoNCEInBatchFn.apply(q, k, T_, rank, True)
 

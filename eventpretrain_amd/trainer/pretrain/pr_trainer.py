@@ -14,7 +14,8 @@ def auto_step_executor(args, model, optimizer, loss_scaler, batch_tensors, loss_
     runs host-bound at 2.5-3x the device time. Returns None where the captured form cannot stand in for the
     eager loop: gradient accumulation (accum_iter > 1), backward off, visualisation inside the loop, an optimizer that is not
     FusedAdamW, a CPU device, a forward replaced on the instance, or `args.graph_step = False` (the opt-out). A data-parallel run
-    takes the executor's multi-GPU form with the scaler's reducer."""
+    takes the executor's multi-GPU form with the scaler's reducer -- the contrastive stage with its key all-gather between two
+    captured graphs, the Swin backbone with a collective per-step verdict on its window plan."""
     from ...engine import GraphedStep
     from ...optim import FusedAdamW
     if not getattr(args, "graph_step", True) or args.accum_iter != 1 or not args.backward:
@@ -37,10 +38,9 @@ def auto_step_executor(args, model, optimizer, loss_scaler, batch_tensors, loss_
         fwd = lambda m, x_, y_, noise: m(x_, y_, is_rec=True, noise=noise)
         if getattr(args, "masking_strategy", "random") == "random":
             noise_shape = (x.shape[0], model.backbone.num_patches)
-            if getattr(model, "backbone_type", "") == "swin" and reducer is None:
+            if getattr(model, "backbone_type", "") == "swin":
+                # (data-parallel too: the ranks agree per step whether every pattern fits the captured shape, engine.GraphedStep._vote)
                 step_prepare = model.backbone.enable_static_plan(x.device)
-            elif getattr(model, "backbone_type", "") == "swin":
-                return None            # data-parallel Swin: per-rank window plans, stepped eagerly (engine.GraphedStep)
     else:
         fwd = lambda m, x_, y_, noise: m(x_, y_)
     seed = int(torch.empty((), dtype=torch.int64).random_().item())      # follows torch.manual_seed like the eager draw would
@@ -56,6 +56,82 @@ def ops_dtype():
     return ops.get_compute_dtype()
 
 
+class _DevicePrefetcher:
+    """Batch i + 1's host -> device copies on a side stream while step i runs (the loop used to issue them in front of the replay on
+    the step's own stream: 64 MB of voxel grids per ViT-Base batch = 1.3 ms of a 10.7 ms step even from pinned memory). Wraps any
+    loader of dict batches; tensors already on the device pass through. The consumer's stream waits on the copy's event."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _move(self, batch):
+        if not isinstance(batch, dict):          # (the reference's loaders yield dicts; anything else passes through untouched)
+            return batch, None
+        moved, ev = {}, None
+        with torch.cuda.stream(self.stream):
+            for k, v in batch.items():
+                if torch.is_tensor(v) and v.device != self.device:
+                    moved[k] = v.to(self.device, non_blocking=True)
+                else:
+                    moved[k] = v
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return moved, ev
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._move(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur, ev = nxt
+            try:
+                nxt = self._move(next(it))      # queued behind the previous copy, ahead of the step the consumer is about to run
+            except StopIteration:
+                nxt = None
+            if ev is not None:
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                for v in cur.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(torch.cuda.current_stream(self.device))
+            yield cur
+
+
+class _DeferredLosses:
+    """Per-step losses kept ON THE DEVICE. The reference reads the loss back every step (`loss.item()`,
+    pr_trainer.py:46,64) and all-reduces it for the log (`utils/misc.py:406-414`): with a replayed step that is three host syncs
+    per iteration and the host can never queue step N+1 while step N runs. Here every step's loss is copied into a device array
+    (one tiny copy behind the replay); the meters receive the values -- one update per step, in order, so `global_avg`, the
+    smoothed window and the returned dict are what per-step updates give -- when something is about to be printed or logged and
+    at the end of the epoch. `args.sync_every_step = True` restores the reference's per-step read-back."""
+
+    def __init__(self, n_iter, device):
+        self.buf = torch.zeros(max(int(n_iter), 1), dtype=torch.float32, device=device)
+        self.done = 0          # steps already handed to the meters
+        self.n = 0
+
+    def push(self, loss):
+        if self.n >= self.buf.numel():        # a loader that yields more batches than len() promised
+            self.buf = torch.cat([self.buf, torch.zeros_like(self.buf)])
+        self.buf[self.n].copy_(loss.detach().reshape(()), non_blocking=True)
+        self.n += 1
+
+    def flush(self, logger, name):
+        """-> the newest loss value (a host float) or None when nothing was pending; ONE device read-back."""
+        if self.done == self.n:
+            return None
+        vals = self.buf[self.done:self.n].tolist()
+        self.done = self.n
+        for v in vals:
+            logger.update(**{name: v})
+        return vals[-1]
+
+
 def _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, loss_name, forward, vis_hook, step_executor=None, auto=True):
     model.train(True)
     logger = misc.MetricLogger(delimiter="  ")
@@ -67,6 +143,10 @@ def _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, l
     n_iter = len(data_loader)
     last = None
     auto = auto and step_executor is None
+    on_gpu = str(args.device).startswith("cuda")
+    deferred = None            # _DeferredLosses once a step executor runs the steps and per-step syncs are not asked for
+    if on_gpu and getattr(args, "prefetch_to_device", True) and not getattr(args, "sync_every_step", False):
+        data_loader = _DevicePrefetcher(data_loader, args.device)
     for it, batch in enumerate(logger.log_every(args, data_loader, args.print_freq, header)):
         if it % args.accum_iter == 0:
             adjust_learning_rate(optimizer, it / n_iter + epoch, args)
@@ -76,6 +156,8 @@ def _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, l
             # the fast path is the default path: the loop captures its own step executor on the first batch (auto_step_executor)
             step_executor = auto_step_executor(args, model, optimizer, loss_scaler, (events_voxel_grid, supp), loss_name, vis_hook)
             auto = step_executor is not None
+        lr = optimizer.param_groups[0]["lr"]
+        log_now = (it + 1) % args.log_freq == 0
         if step_executor is not None:
             # HIP-graph replay of forward + backward + optimizer step (eventpretrain_amd/engine.py); the lr set above
             # reaches the graph through the optimizer's staged scalars
@@ -85,8 +167,24 @@ def _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, l
                 loss = step_executor.step(events_voxel_grid, supp)
             else:                          # the short last batch of an epoch: one eager step that leaves the graph usable
                 loss = step_executor.eager_step_with(events_voxel_grid, supp)
-            logger.update(**{loss_name: loss.item()})
             step_now = True
+            if on_gpu and not getattr(args, "sync_every_step", False):
+                if deferred is None:
+                    deferred = _DeferredLosses(n_iter, events_voxel_grid.device)
+                deferred.push(loss)
+                logger.update(lr=lr)
+                # the host reads the device only when a value is needed: a progress line is due, a log point is due (the reduction of
+                # the logged value is collective: every rank is here at the same iterations), or the epoch ends
+                if log_now or (it + 1) % args.print_freq == 0 or it + 1 == n_iter:
+                    newest = deferred.flush(logger, loss_name)
+                    if log_now:
+                        reduced = misc.all_reduce_mean(newest)
+                        if log_writer is not None:
+                            x = int((it / n_iter + epoch) * 1000)        # "epoch_1000x" axis
+                            log_writer.add_scalar(loss_name, reduced, x)
+                            log_writer.add_scalar("lr", lr, x)
+                continue
+            logger.update(**{loss_name: loss.item()})
         else:
             outputs = forward(events_voxel_grid, supp)
             loss = outputs[0]
@@ -100,15 +198,16 @@ def _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, l
                 loss_scaler(loss, optimizer, parameters=model.parameters(), update_grad=step_now)
                 if step_now:
                     optimizer.zero_grad()
-        if str(args.device).startswith("cuda"):
+        if on_gpu:
             torch.cuda.synchronize()
-        lr = optimizer.param_groups[0]["lr"]
         logger.update(lr=lr)
         reduced = misc.all_reduce_mean(loss.item())
-        if log_writer is not None and (it + 1) % args.log_freq == 0 and step_now:
+        if log_writer is not None and log_now and step_now:
             x = int((it / n_iter + epoch) * 1000)        # "epoch_1000x" axis
             log_writer.add_scalar(loss_name, reduced, x)
             log_writer.add_scalar("lr", lr, x)
+    if deferred is not None:
+        deferred.flush(logger, loss_name)
     if vis_hook is not None and args.visualize and (epoch + 1) % args.vis_train_freq == 0 and last is not None:
         vis_hook(args, *last, epoch)
     logger.synchronize_between_processes()

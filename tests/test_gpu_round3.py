@@ -307,32 +307,46 @@ def test_default_epoch_loop_is_the_graphed_fast_path_and_follows_the_reference_t
         tol = 5e-4 if name.endswith("attn.qkv.bias") else 2e-5
         assert checksums(params[name])[2] == pytest.approx(ws, rel=2e-4, abs=tol), name
 
-    # (b) timing on a model large enough for the launch overhead to matter: ViT-Small, B = 16, bf16
+    # (b) timing at the headline size: ViT-Base, B = 64, bf16, batches in pinned host memory (what a DataLoader with pin_memory hands
+    # over). The loop prefetches batch i + 1 on a side stream and never reads the device back between log points,
+    # so a step of the default loop must cost what GraphedStep.step() on device-resident inputs costs, within 10 %.
     ops.set_compute_dtype(torch.bfloat16)
-    a2 = make_args(model_size="small", pr_phase="rec", device="cuda")
-    a2.batch_size, a2.epochs, a2.warmup_epochs, a2.accum_iter, a2.lr, a2.min_lr = 16, 4, 1, 1, 1e-4, 1e-6
-    a2.print_freq = 1000
+    a2 = make_args(model_size="base", pr_phase="rec", device="cuda")
+    a2.batch_size, a2.epochs, a2.warmup_epochs, a2.accum_iter, a2.lr, a2.min_lr = 64, 4, 1, 1, 1e-4, 1e-6
+    a2.print_freq, a2.log_freq = 1000, 1000
     torch.manual_seed(0)
-    m2 = hub.pretrain_hub_model_small_patch16(a2, emb_frames_dim=512, queue_length=8, T=0.07).cuda().train()
+    m2 = hub.pretrain_hub_model_base_patch16(a2, emb_frames_dim=512, queue_length=8, T=0.07).cuda().train()
     opt2 = FusedAdamW(lrd.param_groups_lrd(a2, m2, a2.weight_decay, layer_decay=1), lr=a2.lr, betas=(0.9, 0.95))
-    xs, ys = torch.randn(16, 5, 224, 224) * 0.5, torch.randn(16, 1, 224, 224)
-    loader = [dict(events_voxel_grid=xs, sub_frame=ys, image_name=["i"] * 16)] * 12
+    xs, ys = (torch.randn(64, 5, 224, 224) * 0.5).pin_memory(), torch.randn(64, 1, 224, 224).pin_memory()
+    loader = [dict(events_voxel_grid=xs, sub_frame=ys, image_name=["i"] * 64)] * 24
     pr_trainer.pr_rec_one_epoch(a2, m2, loader[:2], opt2, 0, scaler)       # builds and caches the executor
     ex2 = m2._evp_auto_executor[1]
     assert ex2.note == "hip-graph"
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pr_trainer.pr_rec_one_epoch(a2, m2, loader, opt2, 1, scaler)
+    stats2 = pr_trainer.pr_rec_one_epoch(a2, m2, loader, opt2, 1, scaler)
     torch.cuda.synchronize()
     t_loop = (time.perf_counter() - t0) / len(loader)
+    assert math.isfinite(stats2["reconstruct_loss"])
     xd, yd = xs.cuda(), ys.cuda()
+    for _ in range(3):
+        ex2.step(xd, yd)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(len(loader)):
-        ex2.step(xd, yd).item()
+        ex2.step(xd, yd)
     torch.cuda.synchronize()
     t_direct = (time.perf_counter() - t0) / len(loader)
+    # the reference-faithful opt-in: read the loss back, synchronize and all-reduce it every step
+    a2.sync_every_step = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pr_trainer.pr_rec_one_epoch(a2, m2, loader[:12], opt2, 2, scaler)
+    torch.cuda.synchronize()
+    t_sync = (time.perf_counter() - t0) / 12
+    a2.sync_every_step = False
     a2.graph_step = False
-    m3 = hub.pretrain_hub_model_small_patch16(a2, emb_frames_dim=512, queue_length=8, T=0.07).cuda().train()
+    m3 = hub.pretrain_hub_model_base_patch16(a2, emb_frames_dim=512, queue_length=8, T=0.07).cuda().train()
     opt3 = FusedAdamW(lrd.param_groups_lrd(a2, m3, a2.weight_decay, layer_decay=1), lr=a2.lr, betas=(0.9, 0.95))
     pr_trainer.pr_rec_one_epoch(a2, m3, loader[:2], opt3, 0, scaler)
     torch.cuda.synchronize()
@@ -341,9 +355,9 @@ def test_default_epoch_loop_is_the_graphed_fast_path_and_follows_the_reference_t
     torch.cuda.synchronize()
     t_eager = (time.perf_counter() - t0) / 6
     assert not hasattr(m3, "_evp_auto_executor")
-    print(f"[default loop] per step: default {t_loop * 1e3:.2f} ms, GraphedStep.step {t_direct * 1e3:.2f} ms, graph_step=False {t_eager * 1e3:.2f} ms")
-    # the loop adds the H2D copy of the batch (16 x 5 x 224 x 224 f32 from pageable memory) and its bookkeeping to the replay
-    assert t_loop <= 1.10 * t_direct + 2.5e-3, (t_loop, t_direct)
+    print(f"[default loop, ViT-Base B=64] per step: default {t_loop * 1e3:.2f} ms, GraphedStep.step on resident inputs {t_direct * 1e3:.2f} ms, "
+          f"sync_every_step {t_sync * 1e3:.2f} ms, graph_step=False {t_eager * 1e3:.2f} ms")
+    assert t_loop <= 1.10 * t_direct, (t_loop, t_direct)
     assert t_loop < 0.8 * t_eager, (t_loop, t_eager)
 
 
