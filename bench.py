@@ -737,27 +737,39 @@ def main():
             off2 = np.arange(0, (args.batch + 1) * 150_000, 150_000, dtype=np.int64)
             frames2 = torch.randn(args.batch, 1, 480, 640, device=device)
             pipe = GpuInputPipeline(pa, seed=1)
+            # host half (decisions, checks, packing into pinned slots) on the pipeline's worker thread, one batch ahead of the device
+            # half (one upload + seven launches): the timed loop below is what an epoch loop does per batch
             th = time.perf_counter()
-            drawn = [pipe.draw(off2[1:] - off2[:-1], step=s_, frame_size=(480, 640)) for s_ in range(4)]
+            for s_ in range(4):
+                pipe.prepare(off2, step=100 + s_, frame_size=(480, 640))
             host_ms = (time.perf_counter() - th) / 4 * 1e3
-            for w_, d_, p_, f_ in drawn[:2]:
-                pipe.run(evs2, off2, w_, d_, p_, frames=frames2, frame_params=f_)
-            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fut = pipe.prepare_async(off2, step=0, frame_size=(480, 640))
+            for s_ in range(1, 4):
+                pb_ = fut.result()
+                fut = pipe.prepare_async(off2, step=s_, frame_size=(480, 640))
+                pipe.run_prepared(evs2, pb_, frames=frames2)
             torch.cuda.synchronize()
+            n_rep = 16
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            tw = time.perf_counter()
             c0.record()
-            for r_ in range(8):
-                w_, d_, p_, f_ = drawn[r_ % 4]
-                pipe.run(evs2, off2, w_, d_, p_, frames=frames2, frame_params=f_)
+            for s_ in range(4, 4 + n_rep):
+                pb_ = fut.result()
+                fut = pipe.prepare_async(off2, step=s_, frame_size=(480, 640))
+                pipe.run_prepared(evs2, pb_, frames=frames2)
             c1.record()
             torch.cuda.synchronize()
-            csec = c0.elapsed_time(c1) * 1e-3 / 8
+            wall = (time.perf_counter() - tw) / n_rep
+            fut.result()
+            csec = c0.elapsed_time(c1) * 1e-3 / n_rep
             cbytes = pipe.algorithmic_bytes(np.full(args.batch, 100_000)) + args.batch * (480 * 640 + S * S) * 4.0
-            result["loader_chain"] = {"value": args.batch / csec, "unit": "clips/s", "us_per_batch": csec * 1e6, "bound": "hbm",
-                                      "achieved": cbytes / csec / 1e9, "peak": HBM_PEAK_GBS, "frac": cbytes / csec / 1e9 / HBM_PEAK_GBS,
-                                      "algorithmic_bytes_per_batch": cbytes, "host_decision_ms_per_batch": host_ms,
+            result["loader_chain"] = {"value": args.batch / csec, "unit": "clips/s", "us_per_batch": csec * 1e6, "wall_us_per_batch": wall * 1e6,
+                                      "bound": "hbm", "achieved": cbytes / csec / 1e9, "peak": HBM_PEAK_GBS, "frac": cbytes / csec / 1e9 / HBM_PEAK_GBS,
+                                      "algorithmic_bytes_per_batch": cbytes, "host_prepare_ms_per_batch": host_ms,
                                       "includes": "get_random_index (100k of 150k events) -> events_augment -> events_reshape -> "
-                                                  "events_to_voxel_grid -> evg_augment + frame_augment, 640x480 sensor clips resident in HBM, "
-                                                  "7 kernel launches per batch incl. the host's table uploads"}
+                                                  "events_to_voxel_grid -> evg_augment + frame_augment, 640x480 sensor clips resident in HBM; "
+                                                  "per batch one table upload + 7 kernel launches, the host half (counter-stream decisions, "
+                                                  "checks, packing) on a worker thread one batch ahead (host_prepare_ms_per_batch, off the critical path)"}
             result["end_to_end"] = {"value": args.batch * world / (ms * 1e-3 + csec), "unit": "samples/s",
                                     "includes": "the loader chain of the batch on the GPU (%.0f us) + optimiser step, serial, per GPU" % (csec * 1e6)}
         except Exception as e:      # a reported figure; never lose the bench line over it

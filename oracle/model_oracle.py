@@ -162,19 +162,35 @@ def vit_dense(sd, x, *, patch, heads, pre="backbone."):
 
 
 # ----------------------------------------------------------------------------- model/backbone/convvit.py, conv_block.py
-def conv_block(sd, pre, x, keep=None):
+def conv_block(sd, pre, x, keep=None, drops=None):
     """conv_block.py:41-51 on NCHW maps: LN over channels (eps 1e-5), 1x1 conv, keep-mask multiply, depthwise 5x5
-    (padding 2), 1x1 conv, residual; LN, 1x1 -> GELU -> 1x1, residual."""
+    (padding 2), 1x1 conv, residual; LN, 1x1 -> GELU -> 1x1, residual.
+    `drops` (training mode; conv_block.py:19-21,35,43-49): dict(u1, u2, keep_prob) = the per-sample draws of the two DropPath
+    applications, optionally p + 0/1 masks "hidden" / "fc2" [B, H*W, C'] (channels-last element order) of CMlp's two dropouts; the
+    conv branch has no dropout of its own."""
     def ln(t, n):
         return layer_norm(t.permute(0, 2, 3, 1), sd[pre + n + ".weight"], sd[pre + n + ".bias"], 1e-5).permute(0, 3, 1, 2)
+
+    def mask_map(t, key):            # channels-last [B, HW, C'] mask -> NCHW factor
+        B_, C_, H_, W_ = t.shape
+        return drops[key].view(B_, H_, W_, C_).permute(0, 3, 1, 2) / (1.0 - drops["p"])
     C = x.shape[1]
+    s1 = s2 = 1.0
+    if drops is not None and drops.get("u1") is not None:
+        s1 = drop_path_scale(drops["u1"], drops["keep_prob"]).view(-1, 1, 1, 1)
+        s2 = drop_path_scale(drops["u2"], drops["keep_prob"]).view(-1, 1, 1, 1)
     h = F.conv2d(ln(x, "norm1"), sd[pre + "conv1.weight"], sd[pre + "conv1.bias"])
     if keep is not None:
         h = keep * h
     h = F.conv2d(h, sd[pre + "attn.weight"], sd[pre + "attn.bias"], padding=2, groups=C)
-    x = x + F.conv2d(h, sd[pre + "conv2.weight"], sd[pre + "conv2.bias"])
+    x = x + s1 * F.conv2d(h, sd[pre + "conv2.weight"], sd[pre + "conv2.bias"])
     h = F.gelu(F.conv2d(ln(x, "norm2"), sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"]))
-    return x + F.conv2d(h, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    if drops is not None and drops.get("p"):
+        h = h * mask_map(h, "hidden")
+    m = F.conv2d(h, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    if drops is not None and drops.get("p"):
+        m = m * mask_map(m, "fc2")
+    return x + s2 * m
 
 
 def _patch_embed_map(sd, pre, x, p):
@@ -312,17 +328,32 @@ def window_attention(sd, pre, x, mask, rel, heads):
     return F.linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"]), p
 
 
-def swin_block(sd, pre, x, plan, heads, eps=1e-6):
-    """swin_block.py:260-273 wrapped in GroupingModule.group/merge (swin_block.py:454-466)."""
+def swin_block(sd, pre, x, plan, heads, eps=1e-6, drops=None):
+    """swin_block.py:260-273 wrapped in GroupingModule.group/merge (swin_block.py:454-466).
+    `drops` (training mode; swin_block.py:157,257,270-271, Mlp.drop): as in vit_block -- the DropPath draws are per row of the GROUPED
+    tensor (one per batch item x group: the reference applies drop_path to the (B * n_groups, gs, C) tensor), masks "proj" / "hidden"
+    / "fc2" in the grouped element order."""
     B, n, C = x.shape
     if plan["mode"] == "grouping":
         x = x[:, plan["gather"]].reshape(-1, plan["gs"], C)
     a, p = window_attention(sd, pre + "attn.", layer_norm(x, sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], eps),
                             plan["mask"], plan["rel"], heads)
-    x = x + a
+    s1 = s2 = 1.0
+    if drops is not None:
+        if drops.get("u1") is not None:
+            s1 = drop_path_scale(drops["u1"], drops["keep_prob"]).view(-1, 1, 1)
+            s2 = drop_path_scale(drops["u2"], drops["keep_prob"]).view(-1, 1, 1)
+        if drops.get("p"):
+            a = a * drops["proj"].view_as(a) / (1.0 - drops["p"])
+    x = x + s1 * a
     h = layer_norm(x, sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], eps)
     h = F.gelu(F.linear(h, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"]))
-    x = x + F.linear(h, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    if drops is not None and drops.get("p"):
+        h = h * drops["hidden"].view_as(h) / (1.0 - drops["p"])
+    m = F.linear(h, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    if drops is not None and drops.get("p"):
+        m = m * drops["fc2"].view_as(m) / (1.0 - drops["p"])
+    x = x + s2 * m
     if plan["mode"] == "grouping":
         x = x.reshape(B, -1, C)[:, plan["scatter"]]
     return x, p

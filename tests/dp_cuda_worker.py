@@ -90,7 +90,10 @@ def scenario_graph_vs_eager(kind, dtype, steps, rank, world):
         torch.cuda.synchronize()
         sums = {k: float(checksums(p)[2]) for k, p in m.named_parameters()}
         bufs = {k: float(checksums(b.float())[2]) for k, b in m.named_buffers()}
-        mine = torch.tensor([sums[k] for k in sorted(sums)] + [bufs[k] for k in sorted(bufs) if "queue" in k], dtype=torch.float64)
+        # identical across ranks: the weights always; the queue and its pointer too unless the policy is the reference's rank-0
+        # broadcast (there the ranks' queues differ between a step's enqueue and the next forward's broadcast)
+        same_q = kind != "con_bcast"
+        mine = torch.tensor([sums[k] for k in sorted(sums)] + [bufs[k] for k in sorted(bufs) if "queue" in k and same_q], dtype=torch.float64)
         both = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(both, mine)
         res[mode] = dict(losses=losses, wsums=sums, bufs=bufs, scale={k: float(p.detach().abs().sum()) for k, p in m.named_parameters()},

@@ -153,3 +153,125 @@ def test_graph_replay_draws_fresh_dropout_masks():
     g2.replay()
     torch.cuda.synchronize()
     assert torch.isfinite(a).all() and not torch.equal(a, yb)
+
+
+def test_prepared_loader_chain_equals_the_inline_chain():
+    """GpuInputPipeline.prepare (host half: decisions, checks, packing into ONE pinned slot; also on the worker
+    thread) + run_prepared (one upload, seven launches) give what run() gives for the same decisions -- ragged clips, one shorter
+    than the window, one under the 100-row augmentation threshold, frames with their own crop rows."""
+    import numpy as np
+    from eventpretrain_amd.dataset.pretrain.gpu_input_pipeline import GpuInputPipeline
+    from eventpretrain_amd.testing import make_args, synthetic_events
+    a = make_args(crop_min=0.8, input_size=224, fix_events_num=15000, img_sensor_w=640, img_sensor_h=480, device="cuda")
+    sizes = [40_000, 9_000, 60, 25_000, 15_001]
+    clips = [synthetic_events(900 + i, n, width=640, height=480) for i, n in enumerate(sizes)]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    ev = torch.from_numpy(np.concatenate(clips, 0)).cuda()
+    frames = torch.randn(len(sizes), 1, 480, 640, device="cuda")
+    pipe = GpuInputPipeline(a, seed=3)
+    for step in (0, 1, 2, 3, 4, 5):                # more batches than pinned slots: the ring is reused
+        w, d, p, f = pipe.draw(off[1:] - off[:-1], step=step, frame_size=(480, 640))
+        v0, t0 = pipe.run(ev, off, w, d, p, frames=frames, frame_params=f)
+        pb = pipe.prepare_async(off, step=step, frame_size=(480, 640)).result() if step % 2 else pipe.prepare(off, step=step, frame_size=(480, 640))
+        assert np.array_equal(pb.windows, w) and np.array_equal(pb.params, p) and np.array_equal(pb.fparams, f)
+        v1, t1 = pipe.run_prepared(ev, pb, frames=frames)
+        torch.cuda.synchronize()
+        # (K1 bins with LDS float adds whose order is not fixed: f32 rounding, not bit for bit)
+        assert torch.allclose(v0, v1, atol=1e-5, rtol=0) and torch.equal(t0, t1)
+        assert float(v1.abs().sum()) > 0 and torch.isfinite(v1).all()
+    v2, _ = pipe.run_prepared(ev, pipe.prepare(off, step=6), frames=None)
+    assert tuple(v2.shape) == (len(sizes), 5, 224, 224)
+    with pytest.raises(Exception):
+        pipe.prepare(np.array([0, 10, 5], dtype=np.int64), step=0)      # a clip with a negative length
+
+
+# ------------------------------------------------------------------------------------------- f3: DropPath / dropout on the other blocks
+def _given_drops(B, rows, widths, p_drop, g):
+    u1 = torch.tensor([0.05, 0.9, 0.5, 0.2, 0.31, 0.95][:B])        # keep_prob 0.7: floor(0.7 + u) -> 0, 1, 1, 0, 1, 1
+    u2 = torch.tensor([0.95, 0.1, 0.31, 0.6, 0.29, 0.7][:B])        #                              -> 1, 0, 1, 1, 0, 1
+    masks = None
+    if p_drop:
+        masks = {k: (torch.rand(rows * w, generator=g) >= p_drop).to(torch.uint8) for k, w in widths.items()}
+    return u1, u2, masks
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.25])
+def test_conv_block_drop_path_and_dropout_match_oracle_for_given_draws(p_drop):
+    """ConvBlock's stochastic depth (conv_block.py:35,43-49) and CMlp's dropouts (:19-21) were covered by a
+    finite-loss smoke only. Explicit per-sample draws and element masks, keep map on: output and every gradient equal the oracle's."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.model.sub_module.conv_block import ConvBlock
+    from eventpretrain_amd.testing import det_fill_module_, det_normalish
+    from oracle import model_oracle as mo
+    ops.set_compute_dtype(torch.float32)
+    B, C, H, W = 4, 64, 14, 14
+    blk = ConvBlock(input_size=C, kernel_size=5, mlp_ratio=4., drop=p_drop, drop_path=0.3)
+    det_fill_module_(blk)
+    blk = blk.cuda().train()
+    g = torch.Generator().manual_seed(11)
+    x = det_normalish("cbd.x", (B, C, H, W))
+    keep = (det_normalish("cbd.keep", (B, 1, 7, 7)) > -0.3).float().repeat_interleave(2, 2).repeat_interleave(2, 3)
+    u1, u2, masks = _given_drops(B, B * H * W, {"hidden": 4 * C, "fc2": C}, p_drop, g)
+    rd = ops.BlockDrop(u1.cuda(), u2.cuda(), keep_prob=0.7, drop=p_drop, seed=1, masks=None if masks is None else {k: v.cuda() for k, v in masks.items()})
+    xt = x.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous().cuda().requires_grad_(True)
+    coarse = (1.0 - keep).reshape(B, H * W).contiguous().cuda()
+    y = blk.forward_tokens(xt, H, W, coarse, 1, block_drop=rd)
+    wgt = torch.randn(B, H * W, C, generator=g)
+    (y * wgt.cuda()).sum().backward()
+    sd = {"b." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    xo = x.clone().requires_grad_(True)
+    drops = dict(u1=u1, u2=u2, keep_prob=0.7)
+    if p_drop:
+        drops.update(p=p_drop, hidden=masks["hidden"].float(), fc2=masks["fc2"].float())
+    yo = mo.conv_block(sd, "b.", xo, keep, drops=drops)
+    (yo.permute(0, 2, 3, 1).reshape(B, H * W, C) * wgt).sum().backward()
+    assert torch.allclose(y.detach().cpu(), yo.detach().permute(0, 2, 3, 1).reshape(B, H * W, C), atol=3e-5, rtol=1e-4)
+    gx = xo.grad.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    assert torch.allclose(xt.grad.cpu(), gx, atol=3e-5 * gx.abs().max().item() + 1e-6, rtol=2e-3)
+    for k, v in blk.named_parameters():
+        ref = sd["b." + k].grad
+        assert torch.allclose(v.grad.cpu(), ref, atol=5e-5 * ref.abs().max().item() + 1e-6, rtol=3e-3), k
+    assert torch.equal(y[0].detach()[:, :], y[0].detach()) and not torch.allclose(y[1].detach(), xt[1].detach())
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.25])
+def test_swin_block_drop_path_and_dropout_match_oracle_for_given_draws(p_drop):
+    """The Swin block on grouped tokens (swin_block.py:260-273): DropPath per row of the GROUPED tensor (batch item x group), proj /
+    hidden / fc2 dropouts, relative-position bias with masked pairs -- output, every parameter gradient (incl. the bias table) and the
+    input gradient against the oracle for explicit draws and masks (f32 mode: the LDS window-attention kernels)."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.model.sub_module.swin_block import SwinTransformerBlock
+    from eventpretrain_amd.testing import det_fill_module_
+    from oracle import model_oracle as mo
+    ops.set_compute_dtype(torch.float32)
+    Bn, nG, N, D, heads = 3, 2, 24, 64, 2
+    Bg = Bn * nG
+    blk = SwinTransformerBlock(dim=D, input_resolution=(14, 14), num_heads=heads, window_size=7, shift_size=0, mlp_ratio=4., drop=p_drop, drop_path=0.3)
+    det_fill_module_(blk)
+    blk = blk.cuda().train()
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(Bg, N, D, generator=g)
+    rel = torch.randint(0, 169, (nG, N, N), generator=g)
+    blocked = torch.rand(nG, N, N, generator=g) < 0.3
+    blocked[:, torch.arange(N), torch.arange(N)] = False             # every token sees itself
+    rel_dev = torch.where(blocked, torch.full_like(rel, -1), rel).to(torch.int32).cuda()
+    u1, u2, masks = _given_drops(Bg, Bg * N, {"proj": D, "hidden": 4 * D, "fc2": D}, p_drop, g)
+    rd = ops.BlockDrop(u1.cuda(), u2.cuda(), keep_prob=0.7, drop=p_drop, seed=1, masks=None if masks is None else {k: v.cuda() for k, v in masks.items()})
+    xt = x.clone().cuda().requires_grad_(True)
+    y = blk(xt, rel_dev, block_drop=rd)
+    y = y[0] if isinstance(y, tuple) else y
+    wgt = torch.randn(Bg, N, D, generator=g)
+    (y * wgt.cuda()).sum().backward()
+    sd = {"b." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in blk.state_dict().items() if v.is_floating_point()}
+    xo = x.clone().requires_grad_(True)
+    plan = dict(mode="plain", mask=torch.where(blocked, torch.tensor(-100.0), torch.tensor(0.0)), rel=rel)
+    drops = dict(u1=u1, u2=u2, keep_prob=0.7)
+    if p_drop:
+        drops.update(p=p_drop, proj=masks["proj"].float(), hidden=masks["hidden"].float(), fc2=masks["fc2"].float())
+    yo, _ = mo.swin_block(sd, "b.", xo, plan, heads, eps=blk.norm1.eps, drops=drops)
+    (yo * wgt).sum().backward()
+    assert torch.allclose(y.detach().cpu(), yo.detach(), atol=3e-5, rtol=1e-4), (y.detach().cpu() - yo.detach()).abs().max().item()
+    assert torch.allclose(xt.grad.cpu(), xo.grad, atol=3e-5 * xo.grad.abs().max().item() + 1e-6, rtol=2e-3)
+    for k, v in blk.named_parameters():
+        ref = sd["b." + k].grad
+        assert torch.allclose(v.grad.cpu(), ref, atol=5e-5 * ref.abs().max().item() + 1e-6, rtol=3e-3), k
