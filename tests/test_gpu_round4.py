@@ -1,6 +1,7 @@
 """Round-4 additions on the GPU: the data-parallel default loop with its tensors on the device (two ranks on one card over gloo),
 fresh dropout masks under HIP-graph replay."""
 import json
+import math
 import os
 import socket
 import subprocess
@@ -275,3 +276,53 @@ def test_swin_block_drop_path_and_dropout_match_oracle_for_given_draws(p_drop):
     for k, v in blk.named_parameters():
         ref = sd["b." + k].grad
         assert torch.allclose(v.grad.cpu(), ref, atol=5e-5 * ref.abs().max().item() + 1e-6, rtol=3e-3), k
+
+
+def test_finetune_epoch_runs_captured_and_follows_the_eager_loop():
+    """ft_train_one_epoch builds its own step executor (auto_ft_step_executor). (a) Regularisers off, f32: the
+    captured epoch's losses and final weights equal the eager loop's (args.graph_step = False) from the same start. (b) The recipe's
+    drop_path 0.1 / drop 0.05 in bf16: captured, finite, and the SAME batch gives different losses on two replays with the weights
+    frozen (lr 0) -- the draws advance under replay."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.model.finetune_cls import ft_cls_hub_model as ft
+    from eventpretrain_amd.optim import FusedAdamW
+    from eventpretrain_amd.testing import det_fill_module_, det_normalish, make_args
+    from eventpretrain_amd.trainer.finetune_cls.ft_cls_trainer import ft_train_one_epoch
+    from eventpretrain_amd.utils import lr_decay as lrd
+    from eventpretrain_amd.utils.misc import NativeScalerWithGradNormCount
+    from helpers import checksums
+    ops.set_compute_dtype(torch.float32)
+    loader = [dict(events_voxel_grid=det_normalish(f"ft.x.{i}", (4, 5, 224, 224)) * 0.5, label=torch.tensor([i % 10, 3, 7, (2 * i) % 10]), image_name=["i"] * 4)
+              for i in range(4)]
+    res = {}
+    for mode in ("eager", "graph"):
+        a = make_args(phase="finetune_cls", model_size="small", backbone_type="vit", num_classes=10, mask_ratio=0.0, device="cuda",
+                      dataset_type="n-caltech101", clip_grad=None, smoothing=0.1, drop_path_rate=0.0, drop_rate=0.0)
+        a.epochs, a.warmup_epochs, a.lr, a.min_lr, a.graph_step = 4, 1, 1e-3, 1e-6, mode == "graph"
+        m = ft.finetune_cls_hub_model_small_patch16(a)
+        det_fill_module_(m)
+        m = m.cuda()
+        opt = FusedAdamW(lrd.param_groups_lrd(a, m, 0.05, layer_decay=0.75), lr=a.lr, betas=(0.9, 0.999))
+        st = [ft_train_one_epoch(a, m, loader, opt, ep, NativeScalerWithGradNormCount())["loss_cls"] for ep in range(2)]
+        if mode == "graph":
+            assert m._evp_auto_executor[1].note == "hip-graph"
+        else:
+            assert not hasattr(m, "_evp_auto_executor")
+        res[mode] = (st, {k: checksums(p)[2] for k, p in m.named_parameters()}, {k: p.detach().abs().sum().item() for k, p in m.named_parameters()})
+    assert res["graph"][0] == pytest.approx(res["eager"][0], rel=2e-5)
+    worst = max(abs(res["graph"][1][k] - v) / max(res["eager"][2][k], 1e-6) for k, v in res["eager"][1].items())
+    assert worst <= 5e-6, worst
+    # (b)
+    ops.set_compute_dtype(torch.bfloat16)
+    a = make_args(phase="finetune_cls", model_size="small", backbone_type="vit", num_classes=10, mask_ratio=0.0, device="cuda",
+                  dataset_type="n-caltech101", clip_grad=None, smoothing=0.1, drop_path_rate=0.1, drop_rate=0.05)
+    a.epochs, a.warmup_epochs, a.lr, a.min_lr = 4, 0, 0.0, 0.0
+    torch.manual_seed(0)
+    m = ft.finetune_cls_hub_model_small_patch16(a).cuda()
+    opt = FusedAdamW(lrd.param_groups_lrd(a, m, 0.0, layer_decay=0.75), lr=0.0, betas=(0.9, 0.999))
+    ft_train_one_epoch(a, m, loader[:1] * 2, opt, 0, NativeScalerWithGradNormCount())
+    ex = m._evp_auto_executor[1]
+    assert ex.note == "hip-graph"
+    x, y = loader[0]["events_voxel_grid"].cuda(), loader[0]["label"].cuda()
+    ls = [ex.step(x, y).item() for _ in range(4)]
+    assert all(math.isfinite(v) for v in ls) and len({round(v, 6) for v in ls}) > 1, ls
