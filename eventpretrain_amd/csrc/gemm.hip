@@ -853,321 +853,19 @@ int launch(const evp_gemm_desc *d, hipStream_t s) {
   return EVP_OK;
 }
 
-// ---- persistent 128x128x64 bf16 kernel, the epilogue of tile i drained under the K loop of tile i+1 (round 4) -----------------
-// Why again (the round-1 persistent variants measured +3..8 % and were removed): they predate the finding that hipcc guards every
-// LDS read it can see behind an LDS-DMA with `s_waitcnt vmcnt(0)` -- in them every K iteration waited for the epilogue stores it had
-// just issued, so nothing overlapped. Here EVERY LDS access is inline asm and the vector-memory counter is accounted by hand.
-//
-// Cost model this is aimed at: a launch costs K-loop time + epilogue bytes at ~5.5 TB/s, the two ADDING because
-// all resident workgroups finish a round together -- a compute phase, then a chip-wide write burst (GELU forward: 77-103 MB per
-// launch = 13-17 us of pure HBM time on top of 30 us of K loops). Here `grid` <= 512 workgroups (two per CU) walk the tiles; when a
-// tile's K loop ends its accumulators are PARKED in a second register set, and during the first eight K iterations of the next tile
-// they leave in eight pieces: iteration h parks half-group h (16 tile rows x 128 columns, f32) in one of two 8 KiB LDS buffers
-// (the two waves that own those rows: 4 x ds_write_b128), iteration h+1 -- after the barrier pair -- has every thread read 8 columns
-// of one row back (2 x ds_read_b128), apply bias / GELU / GELU' and issue ONE 16-byte store, right behind the top-of-iteration wait so
-// that it has a whole MFMA phase to retire before the next counted wait has to see it gone. The last tile of a workgroup drains in a
-// tail of nine barrier-separated steps. Same MFMA order and epilogue arithmetic as gemm_kernel: bit-identical results.
-//
-// vmcnt accounting. In issue order, between the LDS-DMA pieces of K tile j (8 per wave) and those of K tile j+1 lie at most: the
-// GELU' operand load of the next piece, the piece's store and (once per tile) two bias loads. The top-of-iteration wait is
-// `vmcnt(8)`: everything but the newest tile's 8 pieces has landed -- tile j's operands, and the few epilogue operations of the previous
-// iteration, which are one MFMA phase (~0.8 us) old by then.
-__device__ __forceinline__ u32x4 lds_read_b128_asm(const char *a) {
-  u32x4 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)(lds_void *)a) : "memory");
-  return v;
-}
-__device__ __forceinline__ void lds_write_b128_asm(char *a, f32x4 v) {
-  asm volatile("ds_write_b128 %0, %1" : : "v"((unsigned)(uintptr_t)(lds_void *)a), "v"(v) : "memory");
-}
-
-template <int EPI, bool TB, bool AUXST, bool WT>
-__global__ __launch_bounds__(256, 2) void gemm_p3_kernel(const GemmParams p, const int ntiles) {
-  constexpr int BM = 128, BN = 128, BK = 64, NT = 256, MI = 4, NI = 4;
-  constexpr bool TA = false;
-  constexpr int A_BYTES = Img<bf16_t, TA, BM, BK>::BYTES, B_BYTES = Img<bf16_t, TB, BN, BK>::BYTES, STAGE_BYTES = A_BYTES + B_BYTES;
-  using GA = GStage<TA, BM, NT, BK>;
-  using GB = GStage<TB, BN, NT, BK>;
-  static_assert(GA::PER_WAVE + GB::PER_WAVE == 8, "vmcnt(8) below assumes 8 LDS-DMA pieces per wave and K tile");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *const stg = smem + 2 * STAGE_BYTES;          // two 8 KiB staging buffers: [16 rows][32 chunks of 16 B], chunk ^ (row & 15)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 15, lg = lane >> 4;
-  stamp_begin(p.stamp, blockIdx.x, gridDim.x);
-  const bf16_t *A = reinterpret_cast<const bf16_t *>(p.A);
-  const bf16_t *B = reinterpret_cast<const bf16_t *>(p.B);
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(A), 0, 0x7FFFFFFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(B), 0, 0x7FFFFFFF, 0x00020000);
-  const int lda = (int)p.lda, ldb = (int)p.ldb;
-  const int nk = p.K / BK;
-  const int G = gridDim.x;
-  bf16_t *const Cb = reinterpret_cast<bf16_t *>(p.C);
-  bf16_t *const Ab = reinterpret_cast<bf16_t *>(p.aux);
-
-  // ---- the LDS-DMA stream: one pipeline over (tile, k) pairs
-  int ld_tile = blockIdx.x, ld_k = 0, ld_m0, ld_n0;
-  {
-    int tm, tn;
-    map_tile(ntiles, ld_tile, p.tiles_m, tm, tn);
-    ld_m0 = tm * BM; ld_n0 = tn * BN;
-  }
-  auto issue_next = [&](int stage) -> bool {          // false: nothing left to load
-    if (ld_tile >= ntiles) return false;
-    char *img = smem + stage * STAGE_BYTES;
-    GA::issue(rsA, lda, ld_m0, ld_k * BK, p.M, p.K, img, wave, lane);
-    GB::issue(rsB, ldb, ld_n0, ld_k * BK, p.N, p.K, img + A_BYTES, wave, lane);
-    if (++ld_k == nk) {
-      ld_k = 0;
-      ld_tile += G;
-      if (ld_tile < ntiles) {
-        int tm, tn;
-        map_tile(ntiles, ld_tile, p.tiles_m, tm, tn);
-        ld_m0 = tm * BM; ld_n0 = tn * BN;
-      }
-    }
-    return true;
-  };
-
-  f32x4 acc[MI][NI], parked[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) acc[i][j] = parked[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // ---- drain state
-  bool has_parked = false;                 // `parked` holds a finished tile whose pieces have not all been staged
-  int pm0 = 0, pn0 = 0;                    // that tile's origin
-  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;     // its bias for this thread's 8 columns
-  bool pendB = false;                      // a staged half-group waits to be read back and stored
-  int pb_buf = 0, pb_row0 = 0, pb_n0 = 0;  // staging buffer, first tile row (global m) and tile column origin of it
-  uint4 auxv = make_uint4(0, 0, 0, 0);     // GELU' operand of the staged piece (requested one iteration ahead)
-  const int brow = tid >> 4, bch8 = tid & 15;            // part B: this thread's row of the half-group and 8-column chunk
-
-  auto compute = [&](const char *ia, const char *ib) {
-    u32x4 af[2][MI], bf[2][NI];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < MI; ++i) af[ks][i] = frag_bf16_asm<TA, BM, BK>(ia, wm * 64 + i * 16, ks, lane);
-#pragma unroll
-      for (int j = 0; j < NI; ++j) bf[ks][j] = frag_bf16_asm<TB, BN, BK>(ib, wn * 64 + j * 16, ks, lane);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      constexpr int PER_KS = MI + (TB ? 2 : 1) * NI;
-      if (ks == 0) {
-        if constexpr (PER_KS == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-#pragma unroll
-      for (int i = 0; i < MI; ++i) tie(af[ks][i]);
-#pragma unroll
-      for (int j = 0; j < NI; ++j) tie(bf[ks][j]);
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[ks][j]), __builtin_bit_cast(bf16x8, af[ks][i]),
-                                                              acc[i][j], 0, 0, 0);
-    }
-  };
-
-  // part B, first half (top of an iteration, before the DMA issue): request the staged piece from LDS
-  u32x4 sb0 = u32x4{0, 0, 0, 0}, sb1 = sb0;
-  auto partB_read = [&]() {
-    if (pendB) {
-      const char *base = stg + pb_buf * 8192 + brow * 512;
-      sb0 = lds_read_b128_asm(base + (((2 * bch8) ^ brow) << 4));
-      sb1 = lds_read_b128_asm(base + (((2 * bch8 + 1) ^ brow) << 4));
-    }
-  };
-  // part B, second half (behind the wait + barrier): arithmetic and the one 16-byte store of this thread
-  auto partB_store = [&]() {
-    if (pendB) {
-      tie(sb0);
-      tie(sb1);
-      const float4 a0 = __builtin_bit_cast(float4, sb0), a1 = __builtin_bit_cast(float4, sb1);
-      float4 v0 = make_float4(a0.x * p.alpha + b0.x, a0.y * p.alpha + b0.y, a0.z * p.alpha + b0.z, a0.w * p.alpha + b0.w);
-      float4 v1 = make_float4(a1.x * p.alpha + b1.x, a1.y * p.alpha + b1.y, a1.z * p.alpha + b1.z, a1.w * p.alpha + b1.w);
-      const int64_t m = pb_row0 + brow;
-      const int n = pb_n0 + bch8 * 8;
-      if constexpr (EPI == 1) {
-        if constexpr (AUXST) {
-          if constexpr (WT) st8_bf16_wt(Ab, m * p.ldaux + n, v0, v1);
-          else { st4<bf16_t>(Ab + m * p.ldaux + n, v0); st4<bf16_t>(Ab + m * p.ldaux + n + 4, v1); }
-        }
-        if (p.act == EVP_ACT_GELU) { v0 = gelu4(v0, true); v1 = gelu4(v1, true); }
-        else {
-          v0 = make_float4(fmaxf(v0.x, 0.f), fmaxf(v0.y, 0.f), fmaxf(v0.z, 0.f), fmaxf(v0.w, 0.f));
-          v1 = make_float4(fmaxf(v1.x, 0.f), fmaxf(v1.y, 0.f), fmaxf(v1.z, 0.f), fmaxf(v1.w, 0.f));
-        }
-      } else if constexpr (EPI == 2) {
-        const float4 h0 = make_float4(__uint_as_float(auxv.x << 16), __uint_as_float(auxv.x & 0xFFFF0000u), __uint_as_float(auxv.y << 16),
-                                      __uint_as_float(auxv.y & 0xFFFF0000u));
-        const float4 h1 = make_float4(__uint_as_float(auxv.z << 16), __uint_as_float(auxv.z & 0xFFFF0000u), __uint_as_float(auxv.w << 16),
-                                      __uint_as_float(auxv.w & 0xFFFF0000u));
-        if (p.act == EVP_ACT_DGELU) { v0 = dgelu_mul4(v0, h0, true); v1 = dgelu_mul4(v1, h1, true); }
-        else {
-          v0 = make_float4(h0.x > 0.f ? v0.x : 0.f, h0.y > 0.f ? v0.y : 0.f, h0.z > 0.f ? v0.z : 0.f, h0.w > 0.f ? v0.w : 0.f);
-          v1 = make_float4(h1.x > 0.f ? v1.x : 0.f, h1.y > 0.f ? v1.y : 0.f, h1.z > 0.f ? v1.z : 0.f, h1.w > 0.f ? v1.w : 0.f);
-        }
-      }
-      if constexpr (WT) st8_bf16_wt(Cb, m * p.ldc + n, v0, v1);
-      else {
-        uint4 u;
-        u.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
-        u.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
-        u.z = (uint32_t)f32_to_bf16(v1.x) | ((uint32_t)f32_to_bf16(v1.y) << 16);
-        u.w = (uint32_t)f32_to_bf16(v1.z) | ((uint32_t)f32_to_bf16(v1.w) << 16);
-        *reinterpret_cast<uint4 *>(Cb + m * p.ldc + n) = u;
-      }
-      pendB = false;
-    }
-  };
-  // part A of drain step H (compile-time: indexes the parked registers): the two waves that own tile rows wmh*64 + 16 i .. +15 park
-  // them; every thread requests the GELU' operand of the piece it will store next iteration
-  auto partA = [&](auto hc) {
-    constexpr int H = decltype(hc)::value;
-    if constexpr (H >= 0) {
-      if (has_parked) {
-        constexpr int i = H >> 1, wmh = H & 1;
-        if constexpr (H == 0) {
-          // this tile's bias for the thread's 8 columns: only now -- the previous tile's last piece (stored just above, in this same
-          // iteration when K = 512) still needed the old one
-          if (p.bias) {
-            b0 = *reinterpret_cast<const float4 *>(p.bias + pn0 + bch8 * 8);
-            b1 = *reinterpret_cast<const float4 *>(p.bias + pn0 + bch8 * 8 + 4);
-          }
-        }
-        if (wm == wmh) {
-          char *base = stg + wmh * 8192 + li * 512;
-#pragma unroll
-          for (int jn = 0; jn < NI; ++jn) lds_write_b128_asm(base + (((wn * 16 + jn * 4 + lg) ^ li) << 4), parked[i][jn]);
-        }
-        pendB = true;
-        pb_buf = wmh;
-        pb_row0 = pm0 + wmh * 64 + i * 16;
-        pb_n0 = pn0;
-        if constexpr (EPI == 2) auxv = *reinterpret_cast<const uint4 *>(Ab + (int64_t)(pb_row0 + brow) * p.ldaux + pn0 + bch8 * 8);
-        if constexpr (H == 7) has_parked = false;
-      }
-    }
-  };
-
-  int tile = blockIdx.x;
-  if (tile < ntiles) {
-    issue_next(0);
-    int j = 0;                                           // K iterations done by this workgroup (stage of iteration j = j & 1)
-    auto iteration = [&](auto hc) {
-      partB_read();
-      const bool more = issue_next((j + 1) & 1);
-      if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      partB_store();
-      partA(hc);
-      const char *ia = smem + (j & 1) * STAGE_BYTES;
-      compute(ia, ia + A_BYTES);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      ++j;
-    };
-    for (; tile < ntiles; tile += G) {
-      int tm, tn;
-      map_tile(ntiles, tile, p.tiles_m, tm, tn);
-      iteration(std::integral_constant<int, 0>{});
-      iteration(std::integral_constant<int, 1>{});
-      iteration(std::integral_constant<int, 2>{});
-      iteration(std::integral_constant<int, 3>{});
-      iteration(std::integral_constant<int, 4>{});
-      iteration(std::integral_constant<int, 5>{});
-      iteration(std::integral_constant<int, 6>{});
-      iteration(std::integral_constant<int, 7>{});
-#pragma unroll 1
-      for (int kt = 8; kt < nk; ++kt) iteration(std::integral_constant<int, -1>{});
-      // park the finished tile (its pieces leave during the next tile's first iterations, or in the tail below)
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int jn = 0; jn < NI; ++jn) {
-          parked[i][jn] = acc[i][jn];
-          acc[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      has_parked = true;
-      pm0 = tm * BM;
-      pn0 = tn * BN;
-    }
-    // tail: the last tile's eight pieces, nine barrier-separated steps without a K loop
-    auto tail = [&](auto hc) {
-      partB_read();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      partB_store();
-      partA(hc);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    };
-    tail(std::integral_constant<int, 0>{});
-    tail(std::integral_constant<int, 1>{});
-    tail(std::integral_constant<int, 2>{});
-    tail(std::integral_constant<int, 3>{});
-    tail(std::integral_constant<int, 4>{});
-    tail(std::integral_constant<int, 5>{});
-    tail(std::integral_constant<int, 6>{});
-    tail(std::integral_constant<int, 7>{});
-    tail(std::integral_constant<int, -1>{});
-  }
-  stamp_end(p.stamp, blockIdx.x, gridDim.x);
-}
-
-// shapes the drained-epilogue persistent kernel takes: whole 128 x 128 tiles, K a multiple of 64 and >= 512 (eight drain iterations
-// per tile), more tiles than the 512 resident workgroups (otherwise nothing follows a tile), bf16 C without residual / accumulate
-static inline bool p3_ok(const evp_gemm_desc *d) {
-  const int nbz = (d->batch0 > 0 ? d->batch0 : 1) * (d->batch1 > 0 ? d->batch1 : 1);
-  const int64_t span = (int64_t)d->M * (d->ldc > d->ldaux ? d->ldc : d->ldaux) * 2;
-  return d->dtype == EVP_BF16 && d->c_dtype == EVP_BF16 && !d->transA && nbz == 1 && d->M % 128 == 0 && d->N % 128 == 0 && d->K % 64 == 0 &&
-         d->K >= 512 && !d->residual && !d->accumulate && d->splitk <= 1 && span < 0x7FFFFFFFLL && d->ldc % 8 == 0 &&
-         (!d->aux || d->ldaux % 8 == 0) && ((uintptr_t)d->C & 15) == 0 && ((uintptr_t)d->aux & 15) == 0 &&
-         (!d->bias || ((uintptr_t)d->bias & 15) == 0);
-}
-static int g_gemm_p3 = 0;          // evp_gemm_set_variant(30 off / 31 on, write-through stores / 32 on, plain stores): route eligible launches
-static int g_gemm_p3_grid = 512;   // evp_gemm_set_variant(3000 + grid)
-
-template <int EPI, bool TB> int launch_p3(const evp_gemm_desc *d, hipStream_t s, bool wt) {
-  GemmParams p;
-  p.M = d->M; p.N = d->N; p.K = d->K;
-  p.A = d->A; p.lda = d->lda; p.sA0 = 0; p.sA1 = 0;
-  p.B = d->B; p.ldb = d->ldb; p.sB0 = 0; p.sB1 = 0;
-  p.C = d->C; p.c_dtype = d->c_dtype; p.ldc = d->ldc; p.sC0 = 0; p.sC1 = 0;
-  p.batch1 = 1;
-  p.alpha = d->alpha; p.bias = d->bias; p.act = d->act; p.aux = d->aux; p.ldaux = d->ldaux;
-  p.residual = nullptr; p.ldres = 0; p.accumulate = 0; p.dbg = 0; p.colsum = nullptr; p.colsum_acc = 0; p.stamp = evp_gemm_next_stamp_slot();
-  p.tiles_m = d->M / 128;
-  p.splitk = 1; p.k_per_split = d->K; p.c_wt16 = 1;
-  const int ntiles = p.tiles_m * (d->N / 128);
-  constexpr int smem = 2 * (Img<bf16_t, false, 128, 64>::BYTES + Img<bf16_t, TB, 128, 64>::BYTES) + 2 * 8192;
-  int grid = g_gemm_p3_grid < ntiles ? g_gemm_p3_grid : ntiles;
-  grid &= ~7;                                           // a multiple of 8: tile % 8 stays the XCD of the workgroup
-  if (grid < 8) grid = ntiles;
-  auto go = [&](auto kfn) -> int {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { evp_set_error("evp_gemm: hipFuncSetAttribute(%d) failed: %s", smem, hipGetErrorString(e)); return EVP_ELAUNCH; }
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(256), smem, s, p, ntiles);
-    EVP_CHECK_LAUNCH("evp_gemm");
-    return EVP_OK;
-  };
-  const bool auxst = EPI == 1 && d->aux != nullptr;
-  if (wt) return auxst ? go(gemm_p3_kernel<EPI, TB, true, true>) : go(gemm_p3_kernel<EPI, TB, false, true>);
-  return auxst ? go(gemm_p3_kernel<EPI, TB, true, false>) : go(gemm_p3_kernel<EPI, TB, false, false>);
-}
-
 // (Two persistent variants of the 128x128 body lived here in round 1 -- one workgroup per CU slot looping over tiles, the second
 // with the C stores of tile i folded into the K loop of tile i+1. Measured: +3..8 % on the largest shapes, slower on the small
-// ones (DESIGN.md section 4 "Epilogues"); never the default, removed in round 2.)
+// ones; never the default, removed in round 2. That measurement predated the finding that hipcc guards every visible ds_read behind
+// an LDS-DMA with vmcnt(0), so round 4 re-built the idea with every LDS access in inline asm and the vector-memory counter accounted
+// by hand (`gemm_p3_kernel`, commit "gemm_p3_kernel: persistent 128x128 kernel with the epilogue drained ..."): 512 resident
+// workgroups, a finished tile's accumulators parked in a second register set and drained in eight 16-row pieces through two 8 KiB
+// LDS buffers during the next tile's first eight K iterations, one 16-byte store per thread and iteration issued right behind the
+// top-of-iteration wait. Bit-identical to this kernel on every epilogue it took -- and slower everywhere: re-launched, enc qkv
+// forward 37.0 against 32.8 us, enc fc1 + GELU 55.0 / 44.8, dec fc1 + GELU 58.4 / 48.9, GELU' data gradients 89-97 / 50-54 (the NN
+// layout spills: acc + parked + fragments need > 256 registers at two workgroups per CU), 4096^3 140 / 134; in the replayed ViT-Base
+// step 12.21 against 10.80 ms (profiles/r04_gemm_p3_probe.txt, r04_ab_gemm_p3.txt). Why it cannot win here even without the spills:
+// the step's launches hold 1.7-3 tiles per resident workgroup, so at most one or two epilogues per workgroup can hide under a
+// following K loop while the last one -- every workgroup has one -- pays a longer, serial tail. Removed again.)
 
 template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(const evp_gemm_desc *d, hipStream_t s) {
   int tile = d->tile;
@@ -1192,20 +890,8 @@ template <typename T, typename TC, int EPI, bool TA, bool TB> int pick_tile(cons
       if (tile == 1 && g_gemm_variant != 2 && nb == 1 && t128 > 256 && t96 <= 512) tile = 4;
     }
   }
-  if constexpr (sizeof(T) == 2 && !TA && std::is_same<TC, bf16_t>::value) {
-    // persistent kernel with the drained epilogue: asked for (tile 30 = write-through stores, 31 = plain), or routed by the A/B switch
-    // for launches of more than one round
-    const bool asked = tile == 30 || tile == 31;
-    const bool routed = d->tile == 0 && g_gemm_p3 && g_gemm_variant != 2 && (int64_t)(d->M / 128) * (d->N / 128) > 512;
-    if (asked || routed) {
-      if (p3_ok(d)) return launch_p3<EPI, TB>(d, s, asked ? tile == 30 : g_gemm_p3 == 1);
-      if (asked) { evp_set_error("evp_gemm: tile 30 / 31 needs bf16 C, M, N %% 128 == 0, K %% 64 == 0, K >= 512, no batch / residual / accumulate"); return EVP_ESHAPE; }
-    }
-  } else {
-    if (tile == 30 || tile == 31) { evp_set_error("evp_gemm: tile 30 / 31 is built for bf16 operands, bf16 C and A row-major"); return EVP_EUNSUPPORTED; }
-  }
-  if (tile == 6 || tile == 7 || tile == 8 || tile == 12) {
-    evp_set_error("evp_gemm: tile %d (256x256 ring / persistent / stream-K variants of rounds 1-2) was removed; see DESIGN.md section 4", tile);
+  if (tile == 6 || tile == 7 || tile == 8 || tile == 12 || tile == 30 || tile == 31) {
+    evp_set_error("evp_gemm: tile %d (256x256 ring / persistent / stream-K variants of rounds 1-4) was removed; see DESIGN.md section 4", tile);
     return EVP_EUNSUPPORTED;
   }
   if constexpr (sizeof(T) == 2) {
@@ -1298,8 +984,6 @@ extern "C" int evp_gemm_set_variant(int v) {
   if (v >= 100 && v <= 103) g_gemm_dbg = v - 100;
   if (v == 18 || v == 19) g_gemm_wt16 = v - 18;
   if (v == 1 || v == 2) g_gemm_variant = v;
-  if (v >= 30 && v <= 32) g_gemm_p3 = v - 30;                // 30 off (default), 31 = persistent drained-epilogue kernel, 32 = the same with plain stores
-  if (v >= 3008 && v <= 3000 + 4096) g_gemm_p3_grid = v - 3000;
   if (v >= 10 && v <= 13) g_gemm_g4_fwd = v == 11 ? 3 : v == 10 ? 0 : v - 11;     // 10 off (default), 11 on, 12 = 256x256 only, 13 = 128x256 only
   return old;
 }

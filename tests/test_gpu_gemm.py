@@ -402,49 +402,3 @@ def test_eight_column_write_through_epilogue_is_bit_identical_and_falls_back():
         h2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
         ops.gemm(a, b, h2, M=M, N=N, K=K, bias=bias, act=ACT_GELU, aux=aux_off)
         assert torch.equal(h2, new[1]) and torch.equal(aux_off, new[2])
-
-
-@pytest.mark.parametrize("tile", [30, 31])
-@pytest.mark.parametrize("grid", [512, 16, 8])
-def test_persistent_drained_epilogue_kernel_is_bit_identical(tile, grid):
-    """Round 4: gemm_p3_kernel (persistent workgroups, the epilogue of tile i drained under the K loop of tile i + 1; tile 30 =
-    write-through stores, 31 = plain) against the 128 x 128 kernel, bit for bit: every epilogue it takes (linear + bias, GELU with the
-    pre-activation stored, GELU' with its operand), both layouts, K = 512 (eight K tiles: the drain exactly fills a tile) and longer,
-    with 1, 3 and 6 tiles per workgroup (grid 512 / 16 / 8 on 48 tiles). Integers first: a fragment / row mix-up shows as a wrong integer."""
-    from eventpretrain_amd import ops
-    from eventpretrain_amd._lib import ACT_DGELU, ACT_GELU, call
-    gen = torch.Generator().manual_seed(30)
-    call("evp_gemm_set_variant", 3000 + grid)
-    try:
-        for (M, N, K) in [(1024, 768, 512), (768, 1024, 832)]:
-            for tb in (False, True):
-                a, b, al, bl = _mk(M, N, K, False, tb, torch.bfloat16, gen, ints=True)
-                out = torch.empty(M, N, dtype=torch.bfloat16).cuda()
-                ops.gemm(a.cuda(), b.cuda(), out, M=M, N=N, K=K, trans_b=tb, tile=tile)
-                assert torch.equal(out.float().cpu(), (al @ bl.t()).float().bfloat16().float()), (M, N, K, tb)
-                a, b, al, bl = _mk(M, N, K, False, tb, torch.bfloat16, gen)
-                a, b = a.cuda(), b.cuda()
-                bias = torch.randn(N, generator=gen).cuda()
-                ref, got = torch.empty(M, N, dtype=torch.bfloat16).cuda(), torch.full((M, N), float("nan"), dtype=torch.bfloat16).cuda()
-                ops.gemm(a, b, ref, M=M, N=N, K=K, trans_b=tb, bias=bias, alpha=0.5, tile=1)
-                ops.gemm(a, b, got, M=M, N=N, K=K, trans_b=tb, bias=bias, alpha=0.5, tile=tile)
-                assert torch.equal(ref, got), (M, N, K, tb, "linear")
-                if not tb:       # activation forward: NT only
-                    r_pre, g_pre = torch.empty_like(ref), torch.full_like(got, float("nan"))
-                    got.fill_(float("nan"))
-                    ops.gemm(a, b, ref, M=M, N=N, K=K, bias=bias, act=ACT_GELU, aux=r_pre, tile=1)
-                    ops.gemm(a, b, got, M=M, N=N, K=K, bias=bias, act=ACT_GELU, aux=g_pre, tile=tile)
-                    assert torch.equal(ref, got) and torch.equal(r_pre, g_pre), (M, N, K, "gelu")
-                else:            # activation backward: transB only
-                    h = torch.randn(M, N, generator=gen).bfloat16().cuda()
-                    got.fill_(float("nan"))
-                    ops.gemm(a, b, ref, M=M, N=N, K=K, trans_b=True, act=ACT_DGELU, aux=h, tile=1)
-                    ops.gemm(a, b, got, M=M, N=N, K=K, trans_b=True, act=ACT_DGELU, aux=h, tile=tile)
-                    assert torch.equal(ref, got), (M, N, K, "dgelu")
-        # what it does not take is refused when asked for explicitly
-        from eventpretrain_amd import EvpError
-        a = torch.zeros(100, 64, dtype=torch.bfloat16).cuda()
-        with pytest.raises(EvpError):
-            ops.gemm(a, a, torch.empty(100, 100, dtype=torch.bfloat16).cuda(), M=100, N=100, K=64, tile=tile)
-    finally:
-        call("evp_gemm_set_variant", 3512)

@@ -36,8 +36,6 @@ VARIANTS = {
     "split2s400": {"_split": 2, "_skew_us": 400},
     "noguard": {"_guard_tables": False},     # host free to run ahead (the scalar-table race the guard closes)
     # launch form of the fused attention kernels: (fwd mode, grid, skew ticks, bwd mode, grid, skew ticks), evp_attention_set_variant
-    "p3": {"_p3": 31},                        # multi-round bf16-C GEMMs on the persistent drained-epilogue kernel (write-through stores)
-    "p3plain": {"_p3": 32},                   # the same with plain stores
     "attnp": {"_attn": (1, 512, 0, 1, 512, 0)},
     "attnps": {"_attn": (1, 512, 300, 1, 512, 300)},
     "attnps2": {"_attn": (1, 512, 150, 1, 512, 150)},
@@ -96,7 +94,6 @@ def build(B, cfg):
     apply(cfg)
     call("evp_gemm_set_variant", cfg.get("_variant", 10))      # the routing is decided at launch time, i.e. baked in at capture
     call("evp_gemm_set_variant", cfg.get("_cwt", 19))
-    call("evp_gemm_set_variant", cfg.get("_p3", 30))
     at = cfg.get("_attn", (0, 512, 0, 0, 512, 0))
     call("evp_attention_set_variant", 0, *at[:3])
     call("evp_attention_set_variant", 1, *at[3:])
@@ -153,7 +150,6 @@ def build(B, cfg):
     apply({})
     call("evp_gemm_set_variant", 10)
     call("evp_gemm_set_variant", 19)
-    call("evp_gemm_set_variant", 30)
     call("evp_attention_set_variant", 0, 0, 512, 0)
     call("evp_attention_set_variant", 1, 0, 512, 0)
     return ex
