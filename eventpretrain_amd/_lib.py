@@ -58,7 +58,6 @@ SIGNATURES = {
     "evp_attention_fwd": [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _i64, _vp, _vp],
     "evp_attention_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i64, _vp, _vp, _vp, _vp],
     "evp_attention_fused_supported": [_i, _i, _i],
-    "evp_attention_set_variant": [_i, _i, _i, _i],
     "evp_attention_fused_fwd": [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i64, _vp],
     "evp_attention_fused_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp],
     "evp_softmax_rows": [_vp, _vp, _i, _i64, _i, _i64, _vp],

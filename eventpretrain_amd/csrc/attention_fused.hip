@@ -254,48 +254,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const bf16_t *qkv, bf
   }
 }
 
-// Persistent form (round 4). The one-workgroup-per-head launch runs in lockstep: every resident workgroup stages its head at the
-// same time (a chip-wide HBM burst), then nobody touches memory until the write-out. Here the grid is a fixed number of workgroups
-// per CU and each walks its share of the (batch, head) items;
-//   SKEW: the workgroups of the second half of the grid (the second slot of every CU) start `skew` ticks of the 100 MHz counter
-//         late, so that from then on one workgroup of a CU stages while the other computes;
-//   PF:   the loads of item i + 1 are issued (into registers) before the strips of item i are computed.
-// Items are dealt round-robin (item = blockIdx.x + k * gridDim.x), so the head pairs of head_of_block() stay on one XCD.
-__device__ __forceinline__ void skew_wait(int ticks) {
-  if (ticks <= 0) return;
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(8);
-}
-
-// (waves-per-SIMD floor = the occupancy the one-head kernels reach: without it the item loop's hoisted addresses cost 20-40 registers
-// and a resident workgroup)
-template <int DH, int NT, int NW, bool PF>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PF ? 1 : (NW == 4 ? (DH == 64 && NT <= 8 ? 3 : 2) : 2))))
-void attn_fwd_persist_kernel(const bf16_t *qkv, bf16_t *out, float *lse, int N, int heads, float scale,
-                                                               int n_items, int skew) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (blockIdx.x >= (gridDim.x >> 1)) skew_wait(skew);
-  int b, h;
-  FwdStage<DH, NT, NW> fs;
-  int it = blockIdx.x;
-  if (PF && it < n_items) {
-    head_of_block<DH>(it, n_items, heads, b, h);
-    fs.load(qkv, N, heads, b, h, threadIdx.x);
-  }
-  for (; it < n_items; it += gridDim.x) {
-    head_of_block<DH>(it, n_items, heads, b, h);
-    if (!PF) fs.load(qkv, N, heads, b, h, threadIdx.x);
-    fs.store(smem, threadIdx.x);
-    __syncthreads();
-    if (PF && it + (int)gridDim.x < n_items) {
-      int b2, h2;
-      head_of_block<DH>(it + gridDim.x, n_items, heads, b2, h2);
-      fs.load(qkv, N, heads, b2, h2, threadIdx.x);
-    }
-    attn_fwd_compute<DH, NT, NW, false>(smem, out, lse, nullptr, N, heads, scale, 0, nullptr, 1, b, h);
-    __syncthreads();                       // every wave is done with the images before the next item overwrites them
-  }
-}
+// (Round 4, measured and removed again: PERSISTENT forms of both kernels -- a fixed grid of 256-1024 workgroups walking the (batch,
+//  head) items, optionally with the second half of the grid starting 2-4 us late so that one workgroup of a CU stages while the other
+//  computes, optionally with the next item's loads in flight (registers) under the current item's strips; the kernels above are
+//  split into stage / compute pieces for that. Bit-identical results, and slower in every form: the step's launches hold 768 / 1024
+//  items for 512-768 resident workgroups, i.e. 1-2 items per workgroup -- there is no steady state for a phase offset to pay in, the
+//  item loop's hoisted addresses cost 20-40 registers (a resident workgroup of the backward, or spills at the old occupancy), and the
+//  prefetch registers halve the occupancy outright. Re-launched: encoder forward 11.0 -> 11.0-19 us, backward 26.5 -> 29-38;
+//  decoder forward 27.2 -> 24.8-37, backward 52.2 -> 52.6-71; in the replayed ViT-Base step 10.85-11.18 against 10.67 ms
+//  (profiles/r04_attn_variants.txt, r04_ab_attn.txt).)
 
 // ---------------------------------------------------------------------------------------------------- backward
 // BIAS: addm as in the forward, addmT its transpose per (group, head) ([key][query]: the key-on-lane pass reads 4 consecutive
@@ -531,36 +498,6 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16_t *qkv, co
   attn_bwd_body<DH, NT, NW, false>(qkv, out, dout, lse, dqkv, N, heads, scale, nullptr, nullptr, 1, b, h, unused, dbg);
 }
 
-// Persistent form of the backward (see attn_fwd_persist_kernel).
-template <int DH, int NT, int NW, bool PF>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(PF ? 1 : (NW == 8 ? 4 : NW == 4 ? 2 : 4))))
-void attn_bwd_persist_kernel(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse,
-                                                               bf16_t *dqkv, int N, int heads, float scale, int n_items, int skew) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (blockIdx.x >= (gridDim.x >> 1)) skew_wait(skew);
-  f32x4 unused[NT];
-  int b, h;
-  BwdStage<DH, NT, NW> bs;
-  int it = blockIdx.x;
-  if (PF && it < n_items) {
-    head_of_block<DH>(it, n_items, heads, b, h);
-    bs.load(qkv, out, dout, lse, N, heads, b, h, threadIdx.x);
-  }
-  for (; it < n_items; it += gridDim.x) {
-    head_of_block<DH>(it, n_items, heads, b, h);
-    if (!PF) bs.load(qkv, out, dout, lse, N, heads, b, h, threadIdx.x);
-    bs.store(smem, threadIdx.x);
-    __syncthreads();
-    if (PF && it + (int)gridDim.x < n_items) {
-      int b2, h2;
-      head_of_block<DH>(it + gridDim.x, n_items, heads, b2, h2);
-      bs.load(qkv, out, dout, lse, N, heads, b2, h2, threadIdx.x);
-    }
-    attn_bwd_compute<DH, NT, NW, false>(smem, dqkv, N, heads, scale, nullptr, nullptr, 1, b, h, unused);
-    __syncthreads();
-  }
-}
-
 // Windowed form: workgroup = (group, head, batch chunk). It walks `per` batch items of its (group, head), keeping the d logits of
 // its query strips in registers, and adds them into dA once at the end -- B / per adds per element instead of B (one plain store
 // when a single workgroup covers the whole batch). One workgroup per (batch, head) adding every tile straight into dA measured
@@ -613,71 +550,33 @@ static inline int attn_bwd_waves() {
   return g_attn_bwd_waves;
 }
 
-// Launch form (evp_attention_set_variant; A/B aid and the round-4 default once measured):
-//   mode 0 = one workgroup per (batch, head); 1 = persistent; 2 = persistent + next item's loads in flight under the strips
-//   grid = persistent workgroups in the launch (a multiple of 16, capped at the item count); skew = start delay of the second
-//   half of the grid in 10-ns ticks
-static int g_attn_mode[2] = {0, 0}, g_attn_grid[2] = {512, 512}, g_attn_skew[2] = {0, 0};
-
-template <int DH, int NT, int NW>
-void launch_fwd_nw(const bf16_t *qkv, bf16_t *out, float *lse, bf16_t *probs, int B, int N, int heads, float scale, int64_t ldp, hipStream_t s) {
-  constexpr int smem = 3 * 16 * NT * DH * 2;
-  const int mode = probs ? 0 : g_attn_mode[0];
-  const int items = B * heads;
-  int grid = g_attn_grid[0];
-  if (grid > items) grid = items;
-  grid &= ~15;
-  if (mode == 0 || grid < 16) {
-    auto k = attn_fwd_kernel<DH, NT, NW>;
-    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(k, dim3(items), dim3(64 * NW), smem, s, qkv, out, lse, probs, N, heads, scale, ldp, g_attn_dbg, (const float *)nullptr, 1);
-  } else if (mode == 1) {
-    auto k = attn_fwd_persist_kernel<DH, NT, NW, false>;
-    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), smem, s, qkv, out, lse, N, heads, scale, items, g_attn_skew[0]);
-  } else {
-    auto k = attn_fwd_persist_kernel<DH, NT, NW, true>;
-    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), smem, s, qkv, out, lse, N, heads, scale, items, g_attn_skew[0]);
-  }
-}
 template <int DH, int NT>
 int launch_fwd(const bf16_t *qkv, bf16_t *out, float *lse, bf16_t *probs, int B, int N, int heads, float scale, int64_t ldp, hipStream_t s) {
-  if (attn_fwd_waves() == 8) launch_fwd_nw<DH, NT, 8>(qkv, out, lse, probs, B, N, heads, scale, ldp, s);
-  else launch_fwd_nw<DH, NT, 4>(qkv, out, lse, probs, B, N, heads, scale, ldp, s);
+  constexpr int smem = 3 * 16 * NT * DH * 2;
+  if (attn_fwd_waves() == 8) {
+    auto k = attn_fwd_kernel<DH, NT, 8>;
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(k, dim3(B * heads), dim3(512), smem, s, qkv, out, lse, probs, N, heads, scale, ldp, g_attn_dbg, (const float *)nullptr, 1);
+  } else {
+    auto k = attn_fwd_kernel<DH, NT, 4>;
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(k, dim3(B * heads), dim3(256), smem, s, qkv, out, lse, probs, N, heads, scale, ldp, g_attn_dbg, (const float *)nullptr, 1);
+  }
   EVP_CHECK_LAUNCH("evp_attention_fused_fwd");
   return EVP_OK;
-}
-template <int DH, int NT, int NW>
-void launch_bwd_nw(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse, bf16_t *dqkv, int B, int N, int heads, float scale,
-                   hipStream_t s) {
-  constexpr int smem = 4 * 16 * NT * DH * 2 + 2 * 16 * NT * 4;
-  const int mode = g_attn_mode[1];
-  const int items = B * heads;
-  int grid = g_attn_grid[1];
-  if (grid > items) grid = items;
-  grid &= ~15;
-  if (mode == 0 || grid < 16) {
-    auto k = attn_bwd_kernel<DH, NT, NW>;
-    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(k, dim3(items), dim3(64 * NW), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale, g_attn_dbg);
-  } else if (mode == 1) {
-    auto k = attn_bwd_persist_kernel<DH, NT, NW, false>;
-    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale, items, g_attn_skew[1]);
-  } else {
-    auto k = attn_bwd_persist_kernel<DH, NT, NW, true>;
-    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * NW), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale, items, g_attn_skew[1]);
-  }
 }
 template <int DH, int NT>
 int launch_bwd(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, const float *lse, bf16_t *dqkv, int B, int N, int heads, float scale,
                hipStream_t s) {
+  constexpr int smem = 4 * 16 * NT * DH * 2 + 2 * 16 * NT * 4;
+  auto go = [&](auto kfn, int nthr) {
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(kfn, dim3(B * heads), dim3(nthr), smem, s, qkv, out, dout, lse, dqkv, N, heads, scale, g_attn_dbg);
+  };
   const int nw = attn_bwd_waves();
-  if (nw == 16) launch_bwd_nw<DH, NT, 16>(qkv, out, dout, lse, dqkv, B, N, heads, scale, s);
-  else if (nw == 8) launch_bwd_nw<DH, NT, 8>(qkv, out, dout, lse, dqkv, B, N, heads, scale, s);
-  else launch_bwd_nw<DH, NT, 4>(qkv, out, dout, lse, dqkv, B, N, heads, scale, s);
+  if (nw == 16) go(attn_bwd_kernel<DH, NT, 16>, 1024);
+  else if (nw == 8) go(attn_bwd_kernel<DH, NT, 8>, 512);
+  else go(attn_bwd_kernel<DH, NT, 4>, 256);
   EVP_CHECK_LAUNCH("evp_attention_fused_bwd");
   return EVP_OK;
 }
@@ -799,15 +698,6 @@ int launch_win_bwd(const bf16_t *qkv, const bf16_t *out, const bf16_t *dout, con
 
 extern "C" int evp_attention_set_debug_buffer(void *buf) {   // measurement aid: uint64 [B*heads*4*2] {staging, compute} cycles per wave
   g_attn_dbg = reinterpret_cast<unsigned long long *>(buf);
-  return EVP_OK;
-}
-
-extern "C" int evp_attention_set_variant(int which, int mode, int grid, int skew_ticks) {
-  EVP_CHECK_ARG((which == 0 || which == 1) && mode >= 0 && mode <= 2 && grid >= 16 && grid <= 65536 && skew_ticks >= 0 && skew_ticks <= 100000,
-                EVP_EINVAL, "evp_attention_set_variant: which in {0 fwd, 1 bwd}, mode in 0..2, grid in 16..65536, skew_ticks in 0..100000");
-  g_attn_mode[which] = mode;
-  g_attn_grid[which] = grid;
-  g_attn_skew[which] = skew_ticks;
   return EVP_OK;
 }
 

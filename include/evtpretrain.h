@@ -219,10 +219,6 @@ int evp_attention_bwd(const void *qkv, const void *probs, const void *dout, int 
  * (lse float32 [B,h,N]) instead of the N x N probabilities; probs (bf16 [B,h,N,ldp], may be NULL) is written only
  * when the caller needs the attention map (dense branch, vit.py:144). The backward recomputes the probabilities from
  * qkv and lse; out is the forward output (needed for rowsum(dout*out)). */
-/* Launch form of the fused ViT attention kernels (A/B aid): which 0 = forward, 1 = backward; mode 0 = one workgroup per (batch,
- * head), 1 = `grid` persistent workgroups walking the heads, the second half of the grid starting skew_ticks x 10 ns late,
- * 2 = the same with the next head's loads in flight under the current head's arithmetic. Results are identical. */
-int evp_attention_set_variant(int which, int mode, int grid, int skew_ticks);
 int evp_attention_fused_supported(int dtype, int N, int dh);
 /* Measurement aid: device buffer uint64 [B*heads*4*2] that evp_attention_fused_fwd fills per wave with {staging, compute}
  * cycles; NULL (default) switches it off. */

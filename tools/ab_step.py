@@ -35,16 +35,6 @@ VARIANTS = {
     "split2s200": {"_split": 2, "_skew_us": 200},   # a LayerNorm / attention kernel of the other instead of its own twin
     "split2s400": {"_split": 2, "_skew_us": 400},
     "noguard": {"_guard_tables": False},     # host free to run ahead (the scalar-table race the guard closes)
-    # launch form of the fused attention kernels: (fwd mode, grid, skew ticks, bwd mode, grid, skew ticks), evp_attention_set_variant
-    "attnp": {"_attn": (1, 512, 0, 1, 512, 0)},
-    "attnps": {"_attn": (1, 512, 300, 1, 512, 300)},
-    "attnps2": {"_attn": (1, 512, 150, 1, 512, 150)},
-    "attnp256": {"_attn": (1, 256, 0, 1, 256, 0)},
-    "attnpf": {"_attn": (2, 512, 0, 2, 512, 0)},
-    "attnpfs": {"_attn": (2, 512, 300, 2, 512, 300)},
-    "attnpf256": {"_attn": (2, 256, 0, 2, 256, 0)},
-    "attnfp": {"_attn": (1, 512, 0, 0, 512, 0)},       # forward only
-    "attnbp": {"_attn": (0, 512, 0, 1, 512, 0)},       # backward only
 }
 
 
@@ -94,9 +84,6 @@ def build(B, cfg):
     apply(cfg)
     call("evp_gemm_set_variant", cfg.get("_variant", 10))      # the routing is decided at launch time, i.e. baked in at capture
     call("evp_gemm_set_variant", cfg.get("_cwt", 19))
-    at = cfg.get("_attn", (0, 512, 0, 0, 512, 0))
-    call("evp_attention_set_variant", 0, *at[:3])
-    call("evp_attention_set_variant", 1, *at[3:])
     a = make_args(model_size="base", pr_phase="rec", device="cuda", batch_size=B)
     torch.manual_seed(1)
     m = hub.pretrain_hub_model_base_patch16(a, emb_frames_dim=512, queue_length=1024, T=0.07).cuda().train()
@@ -150,8 +137,6 @@ def build(B, cfg):
     apply({})
     call("evp_gemm_set_variant", 10)
     call("evp_gemm_set_variant", 19)
-    call("evp_attention_set_variant", 0, 0, 512, 0)
-    call("evp_attention_set_variant", 1, 0, 512, 0)
     return ex
 
 
