@@ -224,6 +224,40 @@ __device__ __forceinline__ void gemm_g4_tn_body(const GemmParams &p, const int t
           if (mbase + r >= p.M || ncol4 >= p.N) continue;
           float4 v = tile[r * 64 + (lane ^ (r & 63))];
           float *c = crow + (int64_t)r * p.ldc;
+          if (p.ad_p != nullptr) {
+            // the optimizer update of these four weights right here (csrc/optim.hip adamw_kernel, same operations in the same
+            // order: bit-identical to writing the gradient and updating in a second kernel), instead of a gradient store now and
+            // a 30-byte-per-parameter pass over cold memory after the launch: the update's HBM traffic rides under the other
+            // workgroups' MFMA phases. Launcher guarantees ldc % 4 == 0, N % 4 == 0, 16-byte aligned bases, no accumulate.
+            const int64_t o = (int64_t)(mbase + r) * p.ldc + ncol4;
+            float4 pp = *reinterpret_cast<const float4 *>(p.ad_p + o);
+            float4 mm = *reinterpret_cast<const float4 *>(p.ad_m + o);
+            float4 vv = *reinterpret_cast<const float4 *>(p.ad_v + o);
+            const float bc1 = p.ad_hyper[0], bc2_sqrt = p.ad_hyper[1], grad_scale = p.ad_hyper[2], lr_mult = p.ad_hyper[3];
+            const float lr = 1.0f * lr_mult * p.ad_lr[0], wd = p.ad_wd[0];
+            const float decay = 1.0f - lr * wd, step_size = lr / bc1;
+            float *P = &pp.x, *Mo = &mm.x, *Vo = &vv.x;
+            const float G[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float gr = G[e] * grad_scale;
+              P[e] *= decay;
+              Mo[e] = p.ad_b1 * Mo[e] + (1.0f - p.ad_b1) * gr;
+              Vo[e] = p.ad_b2 * Vo[e] + (1.0f - p.ad_b2) * gr * gr;
+              const float denom = sqrtf(Vo[e]) / bc2_sqrt + p.ad_eps;
+              P[e] -= step_size * (Mo[e] / denom);
+            }
+            *reinterpret_cast<float4 *>(p.ad_p + o) = pp;
+            *reinterpret_cast<float4 *>(p.ad_m + o) = mm;
+            *reinterpret_cast<float4 *>(p.ad_v + o) = vv;
+            if (p.ad_lp) {
+              uint2 u;
+              u.x = (uint32_t)f32_to_bf16(pp.x) | ((uint32_t)f32_to_bf16(pp.y) << 16);
+              u.y = (uint32_t)f32_to_bf16(pp.z) | ((uint32_t)f32_to_bf16(pp.w) << 16);
+              *reinterpret_cast<uint2 *>(p.ad_lp + o) = u;
+            }
+            continue;
+          }
           if (vec_ok && ncol4 + 3 < p.N) {
             if (p.accumulate) {
               const float4 o = *reinterpret_cast<const float4 *>(c);
