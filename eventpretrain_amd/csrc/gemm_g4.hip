@@ -158,16 +158,23 @@ int evp_g4_gemm_tn(const evp_gemm_desc *d, hipStream_t s) {
   return EVP_OK;
 }
 
+// the kernel's LDS attribute, set once per process by whichever grouped entry runs first (the plain one: eager warm-up steps never
+// fuse, so the fused entry's first call -- inside a stream capture, where the attribute call is not permitted -- finds it done)
+static bool g4_grouped_attr(const char *who) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_g4_grouped_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 32 * 512);
+    if (e != hipSuccess) { evp_set_error("%s: hipFuncSetAttribute failed: %s", who, hipGetErrorString(e)); return false; }
+    attr_done = true;
+  }
+  return true;
+}
+
 extern "C" int evp_gemm_grouped_tn_g4_bf16(const void *problems, const void *items, int n_items, void *stream) {
   EVP_CHECK_ARG(problems && items && n_items > 0, EVP_EINVAL, "evp_gemm_grouped_tn_g4_bf16: bad argument");
   auto k = gemm_g4_grouped_tn_kernel;
   constexpr int smem = 4 * 2 * 32 * 512;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_gemm_grouped_tn_g4_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    attr_done = true;
-  }
+  if (!g4_grouped_attr("evp_gemm_grouped_tn_g4_bf16")) return EVP_ELAUNCH;
   hipLaunchKernelGGL(k, dim3((unsigned)n_items), dim3(256), smem, (hipStream_t)stream,
                      reinterpret_cast<const GroupedProblem *>(problems), reinterpret_cast<const GroupedItem *>(items), evp_gemm_next_stamp_slot(),
                      (const GroupedAdam *)nullptr, (const float *)nullptr, 0.f, 0.f, 0.f);
@@ -181,8 +188,7 @@ extern "C" int evp_gemm_grouped_tn_g4_adamw_bf16(const void *problems, const voi
   EVP_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f, EVP_EINVAL, "evp_gemm_grouped_tn_g4_adamw_bf16: bad betas / eps");
   auto k = gemm_g4_grouped_tn_kernel;
   constexpr int smem = 4 * 2 * 32 * 512;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_gemm_grouped_tn_g4_adamw_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+  if (!g4_grouped_attr("evp_gemm_grouped_tn_g4_adamw_bf16")) return EVP_ELAUNCH;
   hipLaunchKernelGGL(k, dim3((unsigned)n_items), dim3(256), smem, (hipStream_t)stream,
                      reinterpret_cast<const GroupedProblem *>(problems), reinterpret_cast<const GroupedItem *>(items), evp_gemm_next_stamp_slot(),
                      reinterpret_cast<const GroupedAdam *>(adam), hyper, beta1, beta2, eps);

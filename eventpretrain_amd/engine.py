@@ -364,6 +364,10 @@ class GraphedStep:
             T = self.opt._tabs
             self._ptr_tables = (T, T["n_grads"].copy(), T["n_lp"].copy()) if T is not None else None
         except Exception as e:               # keep training; say what happened
+            import os
+            if os.environ.get("EVP_RAISE_CAPTURE"):
+                import traceback
+                traceback.print_exc()
             self.graph = self.graph0 = self.graph2 = self.graphB = self.plan = self.fc = None
             self.note = "eager (graph capture failed: %r)" % (e,)
             self.opt.zero_grad(set_to_none=True)

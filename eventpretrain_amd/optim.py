@@ -31,7 +31,6 @@ class FusedAdamW(torch.optim.Optimizer):
         self._sig = None
         self._fused = {}            # id(param) -> param: updated inside the weight-gradient launch (ops.set_fused_update), never by launch()
         self._unfused_part = None
-        self._keepalive = []        # chunk tables a captured graph may still read (never freed: a few KB each)
 
     # ------------------------------------------------------------------------------------------------ tables
     def _active(self):
@@ -76,6 +75,11 @@ class FusedAdamW(torch.optim.Optimizer):
             norm_out=torch.empty(1, dtype=torch.float32, device=dev),
         )
         T["n_chunks"] = int(T["chunk_t"].numel())
+        T["host_numel"] = numel
+        # chunk table of "everything the weight-gradient launch did not update" (launch(skip_fused=True)): filled inside a HIP-graph
+        # capture, where neither a pageable copy nor a fresh pinned allocation is permitted -- so both halves exist from here on
+        T["uf_t"], T["uf_o"] = torch.empty_like(T["chunk_t"]), torch.empty_like(T["chunk_o"])
+        T["h_uf_t"], T["h_uf_o"] = torch.empty(T["n_chunks"], dtype=torch.int32).pin_memory(), torch.empty(T["n_chunks"], dtype=torch.int64).pin_memory()
         # pinned staging for the per-step refresh
         T["h_grads"] = torch.zeros(n, dtype=torch.int64).pin_memory()
         T["h_lp"] = torch.zeros(n, dtype=torch.int64).pin_memory()
@@ -204,13 +208,25 @@ class FusedAdamW(torch.optim.Optimizer):
         the parameters the weight-gradient launch has NOT already updated (mark_fused)."""
         if skip_fused and self._fused:
             if self._unfused_part is None:
-                keep = [p for _, p in self._act if id(p) not in self._fused]
-                saved = getattr(self, "_parts", None)
-                self.build_parts([keep])
-                self._unfused_part, self._parts = self._parts[0], saved
-                self._keepalive.append(self._unfused_part)
+                # chunk table of what is left, from host copies through the pinned twins made by _build (this runs inside a HIP-graph
+                # capture: the uploads become copy nodes). One fused set per optimizer: a later capture with the same set rewrites
+                # the same values.
+                T = self._tabs
+                ts = [t for t, (_, p) in enumerate(self._act) if id(p) not in self._fused]
+                if ts:
+                    numel = T["host_numel"]
+                    ct = np.concatenate([np.full((int(numel[t]) + CHUNK - 1) // CHUNK, t, dtype=np.int32) for t in ts])
+                    co = np.concatenate([np.arange(0, int(numel[t]), CHUNK, dtype=np.int64) for t in ts])
+                    n = int(ct.shape[0])
+                    T["h_uf_t"].numpy()[:n] = ct
+                    T["h_uf_o"].numpy()[:n] = co
+                    T["uf_t"][:n].copy_(T["h_uf_t"][:n], non_blocking=True)
+                    T["uf_o"][:n].copy_(T["h_uf_o"][:n], non_blocking=True)
+                    self._unfused_part = (T["uf_t"], T["uf_o"], n)
+                else:
+                    self._unfused_part = ()
             part = self._unfused_part
-            if part is None:
+            if not part:
                 return
             T = self._tabs
             b1, b2 = self.param_groups[0]["betas"]

@@ -356,7 +356,7 @@ def test_adamw_fused_into_the_weight_gradient_launch_is_bit_identical():
             ex = GraphedStep(m, opt, lambda mm, xx, yy, noise: mm(xx, yy, is_rec=True, noise=noise), [x, y], noise_shape=(B, 196), warmup=2)
             assert ex.note == "hip-graph", ex.note
             ex.noise_feed = iter(noises)
-            losses = []
+            losses, trace = [], []
             for i in range(6):
                 for g in opt.param_groups:
                     g["lr"] = 1e-3 * (1.0 - 0.1 * i) * g.get("lr_scale", 1.0)
@@ -365,7 +365,9 @@ def test_adamw_fused_into_the_weight_gradient_launch_is_bit_identical():
                     losses.append(ex._eager_fallback([x[:8], y[:8]], nz[:8].cuda()).item())
                 else:
                     losses.append(ex.step().item())
-            torch.cuda.synchronize()
+                torch.cuda.synchronize()
+                trace.append({k: p.detach().double().sum().item() for k, p in m.named_parameters()})
+            res.setdefault("trace", {})[mode] = trace
             fused = sorted(k for k, p in m.named_parameters() if id(p) in opt._fused)
             res[mode] = (losses, {k: p.detach().clone() for k, p in m.named_parameters()},
                          {k: (opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for k, p in m.named_parameters() if p in opt.state},
@@ -374,6 +376,9 @@ def test_adamw_fused_into_the_weight_gradient_launch_is_bit_identical():
     finally:
         ops.set_wgrad_adamw_fusion(True)
     (l0, p0, s0, h0, f0, g0), (l1, p1, s1, h1, f1, g1) = res[False], res[True]
+    for i, (t0, t1) in enumerate(zip(res["trace"][False], res["trace"][True])):
+        bad = [k for k in t0 if t0[k] != t1[k]]
+        assert not bad, (i, bad[:6], len(bad))
     assert not f0 and len(f1) >= 60, (len(f0), len(f1))           # 4 weights x 20 blocks (+ patch / decoder embeds), none without the switch
     assert not g1                                                  # no gradient tensor for a fused weight
     assert l0 == l1, (l0, l1)
