@@ -215,10 +215,7 @@ class StampedStep:
     two kernels of the graph); the warm re-launch figure of GemmTimer is printed beside it as `frac_warm`."""
     STRIDE = 2 * 4096        # uint64 per slot (EVP_STAMP_WGS workgroups x {start, end}), csrc/gemm_common.h
     GROUPED = {"evp_gemm_grouped_tn_bf16": ("gemm_grouped_tn_kernel<128,128>", 128),
-               "evp_gemm_grouped_tn_g4_bf16": ("gemm_g4_grouped_tn_kernel (256x256, one wave per SIMD, 32x32x16)", 256),
-               "evp_gemm_grouped_tn_g4_adamw_bf16": ("gemm_g4_grouped_tn_kernel (256x256, one wave per SIMD, 32x32x16; AdamW update of its weights fused "
-                                                     "into the tile epilogue)", 256)}
-    ALIAS = {"evp_gemm_grouped_tn_g4_adamw_bf16": "evp_gemm_grouped_tn_g4_bf16"}      # the queue's routing rule names the plain entry
+               "evp_gemm_grouped_tn_g4_bf16": ("gemm_g4_grouped_tn_kernel (256x256, one wave per SIMD, 32x32x16)", 256)}
 
     def __init__(self, make_executor, device, n_slots=2048):
         from eventpretrain_amd import ops as _ops
@@ -244,7 +241,7 @@ class StampedStep:
             capturing = torch.cuda.is_current_stream_capturing()
             idx = call("evp_gemm_stamp_count")
             r = orig_call(name, *a_)
-            fl, tiles = pending_grouped.pop(self.ALIAS.get(name, name), (0.0, 0))
+            fl, tiles = pending_grouped.pop(name, (0.0, 0))
             if capturing and call("evp_gemm_stamp_count") == idx + 1:
                 self.launches.append((idx % n_slots, "%s (weight gradients of the step, %d tiles)" % (self.GROUPED[name][0], tiles), fl))
             return r

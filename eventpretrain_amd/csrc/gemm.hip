@@ -774,7 +774,6 @@ __global__ __launch_bounds__(256) void gemm_grouped_tn_kernel(const GroupedProbl
   stamp_begin(stamp, blockIdx.x, gridDim.x);
   const GroupedProblem g = probs[it.prob];
   GemmParams p;
-  p.ad_p = nullptr;
   p.M = g.M; p.N = g.N; p.K = g.K;
   p.A = g.A; p.lda = g.lda; p.sA0 = 0; p.sA1 = 0;
   p.B = g.B; p.ldb = g.ldb; p.sB0 = 0; p.sB1 = 0;
@@ -790,7 +789,6 @@ template <typename T, typename TC, int EPI, bool TA, bool TB, int BM, int BN, in
           int MINW = 1>
 int launch(const evp_gemm_desc *d, hipStream_t s) {
   GemmParams p;
-  p.ad_p = nullptr;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.A = d->A; p.lda = d->lda; p.sA0 = d->strideA0; p.sA1 = d->strideA1;
   p.B = d->B; p.ldb = d->ldb; p.sB0 = d->strideB0; p.sB1 = d->strideB1;

@@ -35,13 +35,6 @@ struct GemmParams {
   int colsum_acc;
   int c_wt16;                // bf16 C (and aux) below 2 GiB: the LDS-staged epilogue may use 16-byte write-through buffer stores
   unsigned long long *stamp; // measurement aid (evp_gemm_set_stamp_buffer): [2 * workgroup] start / end wall-clock stamps of this launch
-  // G4 TN body only -- the AdamW update of this weight applied in the tile's epilogue instead of writing the gradient (ad_p != NULL):
-  // parameter / moments in C's layout, optional bf16 shadow, this tensor's lr and weight decay (device scalars), the step's
-  // {bias correction 1, sqrt(bias correction 2), grad scale, lr multiplier} table (device), betas and eps by value
-  float *ad_p, *ad_m, *ad_v;
-  uint16_t *ad_lp;
-  const float *ad_lr, *ad_wd, *ad_hyper;
-  float ad_b1, ad_b2, ad_eps;
 };
 
 // ---- epilogue helpers ----------------------------------------------------------------------------------------
@@ -204,13 +197,6 @@ struct GroupedProblem {
   float *colsum;             // G4 kernel only: colsum[m] (+)= sum_k A[k][m]; NULL = none
 };
 struct GroupedItem { int prob, tile_m, tile_n, pad; };
-// optional twin of a GroupedProblem (evp_gemm_grouped_tn_g4_adamw_bf16): where the finished tile goes when the optimizer update is
-// fused into the weight-gradient launch; p == NULL: plain gradient store for that problem
-struct GroupedAdam {
-  float *p, *m, *v;
-  uint16_t *lp;
-  const float *lr, *wd;
-};
 
 // ---- in-kernel wall-clock stamps (measurement aid, off by default) -------------------------------------------------------
 // With a stamp buffer installed (evp_gemm_set_stamp_buffer) every GEMM launch gets the next slot of EVP_STAMP_WGS x 2 uint64 and each

@@ -6,14 +6,12 @@
 namespace {
 
 __global__ __launch_bounds__(256) void gemm_g4_grouped_tn_kernel(const GroupedProblem *__restrict__ probs, const GroupedItem *__restrict__ items,
-                                                                 unsigned long long *stamp, const GroupedAdam *__restrict__ adam,
-                                                                 const float *__restrict__ hyper, float b1, float b2, float eps) {
+                                                                 unsigned long long *stamp) {
   const GroupedItem it = items[blockIdx.x];
   if (it.prob < 0) return;                       // padding of the per-XCD item lists
   stamp_begin(stamp, blockIdx.x, gridDim.x);
   const GroupedProblem g = probs[it.prob];
   GemmParams p;
-  p.ad_p = nullptr;
   p.M = g.M; p.N = g.N; p.K = g.K;
   p.A = g.A; p.lda = g.lda; p.sA0 = 0; p.sA1 = 0;
   p.B = g.B; p.ldb = g.ldb; p.sB0 = 0; p.sB1 = 0;
@@ -22,11 +20,6 @@ __global__ __launch_bounds__(256) void gemm_g4_grouped_tn_kernel(const GroupedPr
   p.residual = nullptr; p.ldres = 0; p.accumulate = g.accumulate; p.tiles_m = 0; p.splitk = 1; p.dbg = 0; p.stamp = nullptr; p.c_wt16 = 0;
   p.k_per_split = g.K;
   p.colsum = g.colsum; p.colsum_acc = g.colsum_accumulate;
-  if (adam) {
-    const GroupedAdam ad = adam[it.prob];
-    p.ad_p = ad.p; p.ad_m = ad.m; p.ad_v = ad.v; p.ad_lp = ad.lp; p.ad_lr = ad.lr; p.ad_wd = ad.wd;
-    p.ad_hyper = hyper; p.ad_b1 = b1; p.ad_b2 = b2; p.ad_eps = eps;
-  }
   gemm_g4_tn_body(p, it.tile_m, it.tile_n);
   stamp_end(stamp, blockIdx.x, gridDim.x);
 }
@@ -63,7 +56,6 @@ void fill_params(GemmParams &p, const evp_gemm_desc *d) {
 
 template <bool AKC, bool BKC, int FI, int FJ, int NST, typename TC, int EPI> int launch_g4x(const evp_gemm_desc *d, hipStream_t s, int dbg) {
   GemmParams p;
-  p.ad_p = nullptr;
   fill_params(p, d);
   p.dbg = dbg;
   p.tiles_m = (d->M + 64 * FI - 1) / (64 * FI);
@@ -141,7 +133,6 @@ int evp_g4_gemm(const evp_gemm_desc *d, hipStream_t s, int shape, int dbg) {
 
 int evp_g4_gemm_tn(const evp_gemm_desc *d, hipStream_t s) {
   GemmParams p;
-  p.ad_p = nullptr;
   fill_params(p, d);
   p.alpha = 1.0f; p.bias = nullptr; p.act = EVP_ACT_NONE; p.aux = nullptr; p.residual = nullptr;
   p.tiles_m = (d->M + 255) / 256;
@@ -158,40 +149,18 @@ int evp_g4_gemm_tn(const evp_gemm_desc *d, hipStream_t s) {
   return EVP_OK;
 }
 
-// the kernel's LDS attribute, set once per process by whichever grouped entry runs first (the plain one: eager warm-up steps never
-// fuse, so the fused entry's first call -- inside a stream capture, where the attribute call is not permitted -- finds it done)
-static bool g4_grouped_attr(const char *who) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_g4_grouped_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 32 * 512);
-    if (e != hipSuccess) { evp_set_error("%s: hipFuncSetAttribute failed: %s", who, hipGetErrorString(e)); return false; }
-    attr_done = true;
-  }
-  return true;
-}
-
 extern "C" int evp_gemm_grouped_tn_g4_bf16(const void *problems, const void *items, int n_items, void *stream) {
   EVP_CHECK_ARG(problems && items && n_items > 0, EVP_EINVAL, "evp_gemm_grouped_tn_g4_bf16: bad argument");
   auto k = gemm_g4_grouped_tn_kernel;
   constexpr int smem = 4 * 2 * 32 * 512;
-  if (!g4_grouped_attr("evp_gemm_grouped_tn_g4_bf16")) return EVP_ELAUNCH;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_gemm_grouped_tn_g4_bf16: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
   hipLaunchKernelGGL(k, dim3((unsigned)n_items), dim3(256), smem, (hipStream_t)stream,
-                     reinterpret_cast<const GroupedProblem *>(problems), reinterpret_cast<const GroupedItem *>(items), evp_gemm_next_stamp_slot(),
-                     (const GroupedAdam *)nullptr, (const float *)nullptr, 0.f, 0.f, 0.f);
+                     reinterpret_cast<const GroupedProblem *>(problems), reinterpret_cast<const GroupedItem *>(items), evp_gemm_next_stamp_slot());
   EVP_CHECK_LAUNCH("evp_gemm_grouped_tn_g4_bf16");
-  return EVP_OK;
-}
-
-extern "C" int evp_gemm_grouped_tn_g4_adamw_bf16(const void *problems, const void *adam, const void *items, int n_items, const float *hyper,
-                                                 float beta1, float beta2, float eps, void *stream) {
-  EVP_CHECK_ARG(problems && adam && items && n_items > 0 && hyper, EVP_EINVAL, "evp_gemm_grouped_tn_g4_adamw_bf16: bad argument");
-  EVP_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f, EVP_EINVAL, "evp_gemm_grouped_tn_g4_adamw_bf16: bad betas / eps");
-  auto k = gemm_g4_grouped_tn_kernel;
-  constexpr int smem = 4 * 2 * 32 * 512;
-  if (!g4_grouped_attr("evp_gemm_grouped_tn_g4_adamw_bf16")) return EVP_ELAUNCH;
-  hipLaunchKernelGGL(k, dim3((unsigned)n_items), dim3(256), smem, (hipStream_t)stream,
-                     reinterpret_cast<const GroupedProblem *>(problems), reinterpret_cast<const GroupedItem *>(items), evp_gemm_next_stamp_slot(),
-                     reinterpret_cast<const GroupedAdam *>(adam), hyper, beta1, beta2, eps);
-  EVP_CHECK_LAUNCH("evp_gemm_grouped_tn_g4_adamw_bf16");
   return EVP_OK;
 }

@@ -216,62 +216,6 @@ __device__ __forceinline__ void gemm_g4_tn_body(const GemmParams &p, const int t
       __syncthreads();
       const int mbase = m0 + half * 128;
       float *crow = C + (int64_t)mbase * p.ldc + ncol4;
-      if (p.ad_p != nullptr) {
-        // The optimizer update of this half-tile's weights right here (csrc/optim.hip adamw_kernel, the same operations in the same
-        // order: bit-identical to writing the gradient and updating in a second kernel) instead of a gradient store now and a
-        // 30-byte-per-parameter pass over cold memory after the launch: the update's HBM traffic rides under the OTHER workgroups'
-        // MFMA phases. EIGHT rows per trip with every load of the trip requested before the first use -- this workgroup is alone
-        // on its CU and the accumulators are dead, so loads in flight are what sets its pace (one row at a time ran at ~10 GB/s
-        // per CU and cost more than the separate kernel). Launcher guarantees ldc % 4 == 0, N % 4 == 0, 16-byte aligned bases.
-        const float bc1 = p.ad_hyper[0], bc2_sqrt = p.ad_hyper[1], grad_scale = p.ad_hyper[2], lr_mult = p.ad_hyper[3];
-        const float lr = 1.0f * lr_mult * p.ad_lr[0], wd = p.ad_wd[0];
-        const float decay = 1.0f - lr * wd, step_size = lr / bc1;
-        constexpr int RT = 8;
-#pragma unroll 1
-        for (int r0 = wave; r0 < 128; r0 += 4 * RT) {
-          float4 pp[RT], mm[RT], vv[RT], gg[RT];
-          bool live[RT];
-#pragma unroll
-          for (int u = 0; u < RT; ++u) {
-            const int r = r0 + 4 * u;
-            live[u] = mbase + r < p.M && ncol4 < p.N;
-            if (live[u]) {
-              const int64_t o = (int64_t)(mbase + r) * p.ldc + ncol4;
-              pp[u] = *reinterpret_cast<const float4 *>(p.ad_p + o);
-              mm[u] = *reinterpret_cast<const float4 *>(p.ad_m + o);
-              vv[u] = *reinterpret_cast<const float4 *>(p.ad_v + o);
-              gg[u] = tile[r * 64 + (lane ^ (r & 63))];
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < RT; ++u) {
-            if (!live[u]) continue;
-            const int r = r0 + 4 * u;
-            const int64_t o = (int64_t)(mbase + r) * p.ldc + ncol4;
-            float *P = &pp[u].x, *Mo = &mm[u].x, *Vo = &vv[u].x;
-            const float G[4] = {gg[u].x, gg[u].y, gg[u].z, gg[u].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float gr = G[e] * grad_scale;
-              P[e] *= decay;
-              Mo[e] = p.ad_b1 * Mo[e] + (1.0f - p.ad_b1) * gr;
-              Vo[e] = p.ad_b2 * Vo[e] + (1.0f - p.ad_b2) * gr * gr;
-              const float denom = sqrtf(Vo[e]) / bc2_sqrt + p.ad_eps;
-              P[e] -= step_size * (Mo[e] / denom);
-            }
-            *reinterpret_cast<float4 *>(p.ad_p + o) = pp[u];
-            *reinterpret_cast<float4 *>(p.ad_m + o) = mm[u];
-            *reinterpret_cast<float4 *>(p.ad_v + o) = vv[u];
-            if (p.ad_lp) {
-              uint2 w2;
-              w2.x = (uint32_t)f32_to_bf16(pp[u].x) | ((uint32_t)f32_to_bf16(pp[u].y) << 16);
-              w2.y = (uint32_t)f32_to_bf16(pp[u].z) | ((uint32_t)f32_to_bf16(pp[u].w) << 16);
-              *reinterpret_cast<uint2 *>(p.ad_lp + o) = w2;
-            }
-          }
-        }
-        continue;
-      }
 #pragma unroll 1
       for (int r0 = wave; r0 < 128; r0 += 16) {                // 4 rows per trip and wave
 #pragma unroll

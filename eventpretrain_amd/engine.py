@@ -285,25 +285,14 @@ class GraphedStep:
                 torch.cuda.synchronize()
                 gc.collect()
                 torch.cuda.empty_cache()
-                # One rank: the AdamW update of the big weights rides on the weight-gradient launch at the end of the backward
-                # (ops.set_fused_update) -- their 30 bytes per parameter of cold HBM traffic move under that launch's MFMA phases
-                # instead of in a pass of their own. Valid here because this step's lr / bias-correction tables are uploaded by
-                # graph0 in FRONT of the step; data-parallel steps need the gradients for the all-reduce and keep them.
-                fuse = (not self.multi) and hasattr(self.opt, "fused_slot")
                 with torch.cuda.stream(side):
                     seq.begin()
                     try:
-                        if fuse:
-                            self.opt.clear_fused()
-                            ops.set_fused_update(self.opt)
-                        try:
-                            out = self.forward(self.model, *self.inputs, self.noise)     # (a splitting gather ends / begins graphs in here)
-                            out[0].backward()
-                        finally:
-                            ops.set_fused_update(None)
+                        out = self.forward(self.model, *self.inputs, self.noise)     # (a splitting gather ends / begins graphs in here)
+                        out[0].backward()
                         if not self.multi:
                             self.opt.refresh(scalars=False)
-                            self.opt.launch(skip_fused=True)
+                            self.opt.launch()
                         self.loss = out[0].detach()
                         del out
                         seq.end()

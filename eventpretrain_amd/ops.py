@@ -315,7 +315,6 @@ class _DeferredGrads:
         self.flat_buffers = []      # flat f32 buffers holding the gradients written by the last flush(es)
         self._flat_consumer = None  # weakref to the data-parallel reducer: without a live consumer the list must not grow
         self.join_streams = []      # side streams that ran part of the backward (split-batch step): flush() waits for them
-        self.fuse_opt = None        # FusedAdamW whose update of the big weights rides on the weight-gradient launch (set_fused_update)
 
     def track_flats(self):
         c = self._flat_consumer
@@ -402,9 +401,8 @@ class _DeferredGrads:
         return self._build(n_chunks=n_chunks, static=True)
 
     class _Step:
-        def __init__(self, entry, pt, it, n_items, flats, zero, keep, post=(), adam=None):
+        def __init__(self, entry, pt, it, n_items, flats, zero, keep, post=()):
             self.entry, self.pt, self.it, self.n_items = entry, pt, it, n_items
-            self.adam = adam            # (device table of per-problem AdamW operands, hyper pointer, beta1, beta2, eps): fused update
             self.flats = flats          # flat gradient buffers complete once this step has run
             self.zero = zero            # buffers that accumulate with atomics: cleared before every run
             self.keep = keep            # operand tensors referenced by the tables
@@ -414,12 +412,7 @@ class _DeferredGrads:
         def run(self):
             for z in self.zero:
                 z.zero_()
-            if self.adam is not None:
-                at, hyper, b1, b2, eps = self.adam
-                call("evp_gemm_grouped_tn_g4_adamw_bf16", self.pt.data_ptr(), at.data_ptr(), self.it.data_ptr(), self.n_items, hyper, b1, b2, eps,
-                     stream_ptr())
-            else:
-                call(self.entry, self.pt.data_ptr(), self.it.data_ptr(), self.n_items, stream_ptr())
+            call(self.entry, self.pt.data_ptr(), self.it.data_ptr(), self.n_items, stream_ptr())
             for ws, out, ns, numel, acc in self.post:
                 call("evp_sum_slices_f32", ws.data_ptr(), out.data_ptr(), ns, numel, acc, stream_ptr())
 
@@ -497,34 +490,11 @@ class _DeferredGrads:
                     for it in part:
                         if it[6] is not None and T_ == 256 and n_slices_(it) > 1:
                             b.append((it[6], it[1]))
-                    # Fused optimizer update (set_fused_update): a weight whose ONLY gradient contribution of the step is a 256x256-tile
-                    # problem of this launch is updated in the tile epilogue -- no gradient tensor, no second pass over its 30 bytes
-                    # per parameter. Decided per problem; everything else keeps the gradient store.
-                    fuse = {}
-                    opt_ = self.fuse_opt
-                    if opt_ is not None and T_ == 256 and not static and len(rounds) == 1:
-                        for it in part:
-                            prm = it[0]
-                            if prm.grad is None and n_slices_(it) == 1 and it[4] % 4 == 0 and count.get(id(prm), 0) == 1:
-                                slot = opt_.fused_slot(prm)
-                                if slot is not None:
-                                    fuse[id(prm)] = slot
-                    flat, fresh_ids = alloc_fresh([it[0] for it in part if id(it[0]) not in fuse] +
+                    flat, fresh_ids = alloc_fresh([it[0] for it in part] +
                                                   [it[6] for it in part if it[6] is not None and T_ == 256 and n_slices_(it) == 1],
                                                   dev, zeroed=False)
                     rows_, items, post = [], [], []
-                    adam_rows = {}
                     for (param, dy, x, n_out, k_in, rows, bias_param) in part:
-                        if id(param) in fuse:
-                            cs_ptr, cs_acc = 0, 0
-                            if bias_param is not None:
-                                bt, cs_acc = self._target(bias_param)
-                                if id(bias_param) in fresh_ids:
-                                    cs_acc = 0
-                                cs_ptr = bt.data_ptr()
-                            tm, tn = (n_out + T_ - 1) // T_, (k_in + T_ - 1) // T_
-                            rows_.append((dy.data_ptr(), x.data_ptr(), 0, n_out, k_in, rows, n_out, k_in, k_in, 0, cs_acc, cs_ptr, tm, tn, id(param)))
-                            continue
                         gt, acc = self._target(param)
                         if id(param) in fresh_ids:
                             acc = 0                  # first write into the freshly allocated flat slice
@@ -539,7 +509,7 @@ class _DeferredGrads:
                                 k0 = sidx * kper
                                 kk = min(kper, rows - k0)
                                 rows_.append((dy.data_ptr() + k0 * n_out * 2, x.data_ptr() + k0 * k_in * 2, ws.data_ptr() + sidx * numel * 4,
-                                              n_out, k_in, kk, n_out, k_in, k_in, 0, 0, 0, tm, tn, 0))
+                                              n_out, k_in, kk, n_out, k_in, k_in, 0, 0, 0, tm, tn))
                             post.append((ws, gt, ns, numel, acc))
                             continue
                         cs_ptr, cs_acc = 0, 0
@@ -548,15 +518,12 @@ class _DeferredGrads:
                             if id(bias_param) in fresh_ids:
                                 cs_acc = 0
                             cs_ptr = bt.data_ptr()
-                        rows_.append((dy.data_ptr(), x.data_ptr(), gt.data_ptr(), n_out, k_in, rows, n_out, k_in, k_in, acc, cs_acc, cs_ptr, tm, tn, 0))
+                        rows_.append((dy.data_ptr(), x.data_ptr(), gt.data_ptr(), n_out, k_in, rows, n_out, k_in, k_in, acc, cs_acc, cs_ptr, tm, tn))
                     rows_.sort(key=lambda r_: -r_[5])           # longest K first
                     probs = np.zeros(len(rows_), dtype=pdt)
-                    adt = np.zeros(len(rows_), dtype=np.dtype([("p", "<u8"), ("m", "<u8"), ("v", "<u8"), ("lp", "<u8"), ("lr", "<u8"), ("wd", "<u8")]))
                     weights = []
                     for i, r_ in enumerate(rows_):
                         probs[i] = r_[:12]
-                        if r_[14]:
-                            adt[i] = fuse[r_[14]]
                         tm, tn = r_[12], r_[13]
                         t = np.zeros((tn, tm, 4), dtype=np.int32)
                         t[..., 0] = i
@@ -571,12 +538,8 @@ class _DeferredGrads:
                         items = _deal_to_xcds(items, np.concatenate(weights))
                     pt = table(tag + "p", probs.view(np.uint8), dev)
                     it_ = table(tag + "i", items.view(np.uint8).reshape(-1), dev)
-                    adam = None
-                    if fuse:
-                        adam = (table(tag + "a", adt.view(np.uint8), dev),) + opt_.fused_launch_args()
-                        opt_.mark_fused([it[0] for it in part if id(it[0]) in fuse])
                     steps.append(self._Step(entry, pt, it_, int(items.shape[0]), [flat] if flat is not None else [], [],
-                                            [(it[1], it[2]) for it in part], post, adam=adam))
+                                            [(it[1], it[2]) for it in part], post))
                     steps[-1].round = r
         if b:
             dev = b[0][1].device
@@ -644,24 +607,6 @@ def _deal_to_xcds(items, work, n_xcd=8):
 
 _wgrad_xcd_order = os.environ.get("EVP_WGRAD_XCD", "1") != "0"
 _use_wgrad_g4 = os.environ.get("EVP_WGRAD_G4", "1") != "0"
-
-
-_use_wgrad_adamw = os.environ.get("EVP_WGRAD_ADAMW", "1") != "0"
-
-
-def set_wgrad_adamw_fusion(flag):
-    """A/B switch: may a step executor fuse the AdamW update of the big weights into the weight-gradient launch (default on)?"""
-    global _use_wgrad_adamw
-    _use_wgrad_adamw = bool(flag)
-
-
-def set_fused_update(optimizer):
-    """While set (a FusedAdamW, or None), the end-of-backward weight-gradient launch applies the optimizer update of every weight it
-    can take -- 256x256-tile problems, one contribution per step, no gradient tensor yet -- in its tile epilogue
-    (evp_gemm_grouped_tn_g4_adamw_bf16) and tells the optimizer (FusedAdamW.mark_fused), whose own launch then skips them. The
-    caller guarantees that the optimizer's per-step scalar tables are on the device BEFORE the backward (the single-rank step
-    executor: they travel in a graph of their own in front of the step); plain eager steps do not qualify and never set this."""
-    _deferred.fuse_opt = optimizer if (optimizer is not None and _use_wgrad_adamw) else None
 
 
 def set_wgrad_g4(flag):

@@ -29,15 +29,13 @@ class FusedAdamW(torch.optim.Optimizer):
         self._step = 0
         self._tabs = None
         self._sig = None
-        self._fused = {}            # id(param) -> param: updated inside the weight-gradient launch (ops.set_fused_update), never by launch()
-        self._unfused_part = None
 
     # ------------------------------------------------------------------------------------------------ tables
     def _active(self):
         out = []
         for gi, g in enumerate(self.param_groups):
             for p in g["params"]:
-                if p.grad is not None or id(p) in self._fused:       # (a fused parameter keeps its table slot: lr / wd / moments)
+                if p.grad is not None:
                     out.append((gi, p))
         return out
 
@@ -75,11 +73,6 @@ class FusedAdamW(torch.optim.Optimizer):
             norm_out=torch.empty(1, dtype=torch.float32, device=dev),
         )
         T["n_chunks"] = int(T["chunk_t"].numel())
-        T["host_numel"] = numel
-        # chunk table of "everything the weight-gradient launch did not update" (launch(skip_fused=True)): filled inside a HIP-graph
-        # capture, where neither a pageable copy nor a fresh pinned allocation is permitted -- so both halves exist from here on
-        T["uf_t"], T["uf_o"] = torch.empty_like(T["chunk_t"]), torch.empty_like(T["chunk_o"])
-        T["h_uf_t"], T["h_uf_o"] = torch.empty(T["n_chunks"], dtype=torch.int32).pin_memory(), torch.empty(T["n_chunks"], dtype=torch.int64).pin_memory()
         # pinned staging for the per-step refresh
         T["h_grads"] = torch.zeros(n, dtype=torch.int64).pin_memory()
         T["h_lp"] = torch.zeros(n, dtype=torch.int64).pin_memory()
@@ -108,15 +101,11 @@ class FusedAdamW(torch.optim.Optimizer):
         T = self._tabs
         self._act = act
         ng, nl = T["n_grads"], T["n_lp"]
-        self._index = {id(p): i for i, (_, p) in enumerate(act)}
         for i, (gi, p) in enumerate(act):
             g = p.grad
-            if g is None:                 # updated by the weight-gradient launch this step (mark_fused): no gradient tensor exists
-                ng[i] = 0
-            else:
-                if g.dtype != torch.float32 or not g.is_contiguous():
-                    raise _lib.EvpError("FusedAdamW: gradients must be contiguous float32")
-                ng[i] = g.data_ptr()
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                raise _lib.EvpError("FusedAdamW: gradients must be contiguous float32")
+            ng[i] = g.data_ptr()
             sh = getattr(p, "_evp_lp", None)
             nl[i] = sh.data_ptr() if (sh is not None and getattr(p, "_evp_lp_version", -1) == p._version) else 0
         if scalars:
@@ -175,66 +164,8 @@ class FusedAdamW(torch.optim.Optimizer):
                 st["exp_avg_sq"].zero_()
         self._step = 0
 
-    # ------------------------------------------------------------------------------------------------ update fused into the weight gradients
-    def fused_slot(self, p):
-        """-> (p, exp_avg, exp_avg_sq, bf16 shadow | 0, &lr[slot], &wd[slot]) device addresses for a parameter whose update the
-        weight-gradient launch may apply itself (ops._DeferredGrads), or None: the tables of the last refresh() must hold it (its
-        moments exist, its slot's lr / weight decay are what stage_scalars() uploads every step)."""
-        T, idx = self._tabs, getattr(self, "_index", None)
-        if T is None or idx is None or id(p) not in idx or p.dtype != torch.float32 or not p.is_contiguous():
-            return None
-        st = self.state.get(p, {})
-        if "exp_avg" not in st or self._act[idx[id(p)]][1] is not p:
-            return None
-        i = idx[id(p)]
-        sh = getattr(p, "_evp_lp", None)
-        lp = sh.data_ptr() if (sh is not None and getattr(p, "_evp_lp_version", -1) == p._version) else 0
-        return (p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), lp, T["lr"].data_ptr() + 4 * i, T["wd"].data_ptr() + 4 * i)
-
-    def fused_launch_args(self):
-        b1, b2 = self.param_groups[0]["betas"]
-        return (self._tabs["hyper"].data_ptr(), float(b1), float(b2), float(self.param_groups[0]["eps"]))
-
-    def mark_fused(self, params):
-        for p in params:
-            self._fused[id(p)] = p
-        self._unfused_part = None
-
-    def clear_fused(self):
-        self._fused, self._unfused_part = {}, None
-
-    def launch(self, skip_fused=False):
-        """Device side of a step (graph-capturable): one evp_adamw_multi over all chunks -- or, with `skip_fused`, over the chunks of
-        the parameters the weight-gradient launch has NOT already updated (mark_fused)."""
-        if skip_fused and self._fused:
-            if self._unfused_part is None:
-                # chunk table of what is left, from host copies through the pinned twins made by _build (this runs inside a HIP-graph
-                # capture: the uploads become copy nodes). One fused set per optimizer: a later capture with the same set rewrites
-                # the same values.
-                T = self._tabs
-                ts = [t for t, (_, p) in enumerate(self._act) if id(p) not in self._fused]
-                if ts:
-                    numel = T["host_numel"]
-                    ct = np.concatenate([np.full((int(numel[t]) + CHUNK - 1) // CHUNK, t, dtype=np.int32) for t in ts])
-                    co = np.concatenate([np.arange(0, int(numel[t]), CHUNK, dtype=np.int64) for t in ts])
-                    n = int(ct.shape[0])
-                    T["h_uf_t"].numpy()[:n] = ct
-                    T["h_uf_o"].numpy()[:n] = co
-                    T["uf_t"][:n].copy_(T["h_uf_t"][:n], non_blocking=True)
-                    T["uf_o"][:n].copy_(T["h_uf_o"][:n], non_blocking=True)
-                    self._unfused_part = (T["uf_t"], T["uf_o"], n)
-                else:
-                    self._unfused_part = ()
-            part = self._unfused_part
-            if not part:
-                return
-            T = self._tabs
-            b1, b2 = self.param_groups[0]["betas"]
-            call("evp_adamw_multi", T["params"].data_ptr(), T["grads"].data_ptr(), T["m"].data_ptr(), T["v"].data_ptr(),
-                 T["lp"].data_ptr(), T["numel"].data_ptr(), T["wd"].data_ptr(), T["lr"].data_ptr(), part[0].data_ptr(),
-                 part[1].data_ptr(), part[2], CHUNK, 1.0, float(b1), float(b2), float(self.param_groups[0]["eps"]),
-                 max(self._step, 1), self.grad_scale, T["hyper"].data_ptr(), stream_ptr())
-            return
+    def launch(self):
+        """Device side of a step (graph-capturable): one evp_adamw_multi over all chunks."""
         T = self._tabs
         b1, b2 = self.param_groups[0]["betas"]
         call("evp_adamw_multi", T["params"].data_ptr(), T["grads"].data_ptr(), T["m"].data_ptr(), T["v"].data_ptr(),

@@ -31,8 +31,8 @@ enum { EVP_ACT_NONE = 0, EVP_ACT_GELU = 1, EVP_ACT_DGELU = 2, EVP_ACT_RELU = 3, 
 
 const char *evp_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: evp_dropout_fwd takes a device-side seed; evp_gemm_desc lost its
- * stream-K workspace fields in round 3; 3: evp_gemm_grouped_tn_g4_adamw_bf16). A host binding must compare evp_abi_version() with EVP_ABI_VERSION at load time. */
-#define EVP_ABI_VERSION 3
+ * stream-K workspace fields in round 3). A host binding must compare evp_abi_version() with EVP_ABI_VERSION at load time. */
+#define EVP_ABI_VERSION 2
 int evp_abi_version(void);
 /* Name of the code object's target ("gfx950"). */
 const char *evp_target_arch(void);
@@ -154,17 +154,6 @@ int evp_gemm_grouped_tn_bf16(const void *problems, const void *items, int n_item
  * A non-NULL `colsum` (float32 [M_g]) also receives colsum[m] (+)= sum_k A_g[k][m] -- the bias gradient db = sum over
  * rows of dY of the same Linear -- computed from the A fragments already in registers (no second pass over dY). */
 int evp_gemm_grouped_tn_g4_bf16(const void *problems, const void *items, int n_items, void *stream);
-/* The same launch with the OPTIMIZER UPDATE of the weights fused into the tile epilogue (torch.optim.AdamW semantics, the update
- * main_pretrain.py:341-343 + utils/misc.py:274-300 apply after the backward): `adam` is a device array parallel to `problems` of
- *   struct { float *p, *m, *v; uint16_t *lp; const float *lr, *wd; }   (48 bytes each)
- * p / m / v: parameter, exp_avg, exp_avg_sq in C_g's layout (ldc = N_g, N_g % 4 == 0, 16-byte aligned), lp: optional bf16 shadow of
- * the parameter, lr / wd: DEVICE scalars of this tensor's learning rate and weight decay; p == NULL: that problem writes its
- * gradient into C_g as usual. `hyper`: device float[4] = {1 - beta1^t, sqrt(1 - beta2^t), gradient scale, lr multiplier} of the step
- * (device-resident so that a replayed HIP graph reads each step's values). A fused problem's C_g is not written (may be NULL) and
- * must not accumulate. Arithmetic and operation order are those of evp_adamw_multi: bit-identical weights. Why: the update is 30
- * bytes of cold HBM traffic per parameter with idle matrix cores, the weight-gradient launch is matrix-bound with idle HBM. */
-int evp_gemm_grouped_tn_g4_adamw_bf16(const void *problems, const void *adam, const void *items, int n_items, const float *hyper,
-                                      float beta1, float beta2, float eps, void *stream);
 /* out[i] (+)= sum_s ws[s*numel + i], float32, numel % 4 == 0: reduction of split-K partials when a long-K problem was
  * entered into the grouped launch as several K-slice problems writing to a workspace (ConvViT stage 1: K = B*56*56). */
 int evp_sum_slices_f32(const float *ws, float *out, int n_slices, int64_t numel, int accumulate, void *stream);

@@ -46,7 +46,6 @@ def _restore_global_switches(request):
         ops.set_fused_attention(True)
         ops.set_grad_side(True)
         ops.set_wgrad_g4(True)
-        ops.set_wgrad_adamw_fusion(True)
         ops.set_wgrad_xcd_order(True)
         ops.set_deferred_grads(True)
         from eventpretrain_amd._lib import call

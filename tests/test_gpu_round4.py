@@ -326,66 +326,3 @@ def test_finetune_epoch_runs_captured_and_follows_the_eager_loop():
     x, y = loader[0]["events_voxel_grid"].cuda(), loader[0]["label"].cuda()
     ls = [ex.step(x, y).item() for _ in range(4)]
     assert all(math.isfinite(v) for v in ls) and len({round(v, 6) for v in ls}) > 1, ls
-
-
-def test_adamw_fused_into_the_weight_gradient_launch_is_bit_identical():
-    """Round 4: under the single-rank step executor the AdamW update of the big weights is applied in the tile epilogue of the grouped
-    weight-gradient launch (evp_gemm_grouped_tn_g4_adamw_bf16) -- no gradient tensor, no second pass over 30 bytes per parameter.
-    Same operations in the same order as evp_adamw_multi: after six captured steps (changing lr, weight decay on the decayed group
-    only) every parameter, both moments and the bf16 shadows are BIT-identical to the executor with the fusion switched off, the
-    fused weights carry no .grad, and an eager fall-back step in between (which materialises gradients again) leaves the graph usable."""
-    from eventpretrain_amd import ops
-    from eventpretrain_amd.engine import GraphedStep
-    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
-    from eventpretrain_amd.optim import FusedAdamW
-    from eventpretrain_amd.testing import make_args
-    from eventpretrain_amd.utils import lr_decay as lrd
-    ops.set_compute_dtype(torch.bfloat16)
-    B = 16
-    x = torch.randn(B, 5, 224, 224, generator=torch.Generator().manual_seed(1)).cuda() * 0.5
-    y = torch.randn(B, 1, 224, 224, generator=torch.Generator().manual_seed(2)).cuda()
-    noises = [torch.rand(B, 196, generator=torch.Generator().manual_seed(10 + i)) for i in range(8)]
-    res = {}
-    try:
-        for mode in (False, True):
-            ops.set_wgrad_adamw_fusion(mode)
-            a = make_args(model_size="small", pr_phase="rec", device="cuda", batch_size=B)
-            torch.manual_seed(0)
-            m = hub.pretrain_hub_model_small_patch16(a, emb_frames_dim=512, queue_length=8, T=0.07).cuda().train()
-            opt = FusedAdamW(lrd.param_groups_lrd(a, m, 0.05, layer_decay=1), lr=1e-3, betas=(0.9, 0.95))
-            ex = GraphedStep(m, opt, lambda mm, xx, yy, noise: mm(xx, yy, is_rec=True, noise=noise), [x, y], noise_shape=(B, 196), warmup=2)
-            assert ex.note == "hip-graph", ex.note
-            ex.noise_feed = iter(noises)
-            losses, trace = [], []
-            for i in range(6):
-                for g in opt.param_groups:
-                    g["lr"] = 1e-3 * (1.0 - 0.1 * i) * g.get("lr_scale", 1.0)
-                if i == 3:                       # a short batch in the middle: one eager step, gradients for every weight again
-                    nz = next(ex.noise_feed)
-                    losses.append(ex._eager_fallback([x[:8], y[:8]], nz[:8].cuda()).item())
-                else:
-                    losses.append(ex.step().item())
-                torch.cuda.synchronize()
-                trace.append({k: p.detach().double().sum().item() for k, p in m.named_parameters()})
-            res.setdefault("trace", {})[mode] = trace
-            fused = sorted(k for k, p in m.named_parameters() if id(p) in opt._fused)
-            res[mode] = (losses, {k: p.detach().clone() for k, p in m.named_parameters()},
-                         {k: (opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for k, p in m.named_parameters() if p in opt.state},
-                         {k: p._evp_lp.clone() for k, p in m.named_parameters() if getattr(p, "_evp_lp", None) is not None}, fused,
-                         [k for k, p in m.named_parameters() if id(p) in opt._fused and p.grad is not None])
-    finally:
-        ops.set_wgrad_adamw_fusion(True)
-    (l0, p0, s0, h0, f0, g0), (l1, p1, s1, h1, f1, g1) = res[False], res[True]
-    for i, (t0, t1) in enumerate(zip(res["trace"][False], res["trace"][True])):
-        bad = [k for k in t0 if t0[k] != t1[k]]
-        assert not bad, (i, bad[:6], len(bad))
-    assert not f0 and len(f1) >= 60, (len(f0), len(f1))           # 4 weights x 20 blocks (+ patch / decoder embeds), none without the switch
-    assert not g1                                                  # no gradient tensor for a fused weight
-    assert l0 == l1, (l0, l1)
-    for k in p0:
-        assert torch.equal(p0[k], p1[k]), k
-    for k in s0:
-        assert torch.equal(s0[k][0], s1[k][0]) and torch.equal(s0[k][1], s1[k][1]), k
-    for k in h0:
-        assert torch.equal(h0[k], h1[k]), k
-    print(f"[fused AdamW] {len(f1)} weights updated inside the weight-gradient launch; losses {['%.5f' % v for v in l1]}")

@@ -34,13 +34,12 @@ VARIANTS = {
     "split2s100": {"_split": 2, "_skew_us": 100},   # the second half starts (forward and backward) that much later: a GEMM of one half meets
     "split2s200": {"_split": 2, "_skew_us": 200},   # a LayerNorm / attention kernel of the other instead of its own twin
     "split2s400": {"_split": 2, "_skew_us": 400},
-    "nofuse": {"set_wgrad_adamw_fusion": False},   # AdamW as its own launch after the weight gradients (the round-3 form)
     "noguard": {"_guard_tables": False},     # host free to run ahead (the scalar-table race the guard closes)
 }
 
 
 def apply(cfg):
-    defaults = {"set_grad_side": True, "set_wgrad_xcd_order": True, "set_deferred_grads": True, "set_wgrad_g4": True, "set_wgrad_adamw_fusion": True}
+    defaults = {"set_grad_side": True, "set_wgrad_xcd_order": True, "set_deferred_grads": True, "set_wgrad_g4": True}
     for k, v in {**defaults, **cfg}.items():
         if hasattr(ops, k):
             getattr(ops, k)(v)
