@@ -63,11 +63,53 @@ def draw_erase_add(n, rs=None):
     return erase_index.astype(np.int64), add_index.astype(np.int64), np.ascontiguousarray(noise, dtype=np.float64)
 
 
+# ---- counter-based streams shared by host and device (csrc/events.hip ev_philox / ev_rand_word) ----------------------------------
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def philox_words(seed, step, samples, purpose, n_words):
+    """uint32 [len(samples), n_words]: word w of sample s = Philox4x32-10 with counter (w // 4, purpose, s lo, s hi) and key
+    (seed lo ^ hi32(step * 0x9E3779B97F4A7C15), seed hi ^ lo32(step)), output lane w % 4 -- the stream csrc/events.hip draws from on the
+    device, restated with numpy array arithmetic (a few microseconds for a batch's worth of counts and crop boxes)."""
+    samples = np.asarray(samples, dtype=np.uint64).reshape(-1, 1)
+    nb = (int(n_words) + 3) // 4
+    seed, step = int(seed) & (2 ** 64 - 1), int(step) & (2 ** 64 - 1)
+    k0 = np.uint64((seed & 0xFFFFFFFF) ^ (((step * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)) >> 32))
+    k1 = np.uint64((seed >> 32) ^ (step & 0xFFFFFFFF))
+    c0 = np.broadcast_to(np.arange(nb, dtype=np.uint64)[None, :], (samples.shape[0], nb)).copy()
+    c1 = np.full_like(c0, np.uint64(purpose))
+    c2 = np.broadcast_to(samples & _M32, c0.shape).copy()
+    c3 = np.broadcast_to(samples >> np.uint64(32), c0.shape).copy()
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & _M32
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ k1) & _M32
+        c1, c3, c0, c2 = p1 & _M32, p0 & _M32, n0, n2
+        k0 = (k0 + np.uint64(0x9E3779B9)) & _M32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & _M32
+    return np.stack([c0, c1, c2, c3], axis=2).reshape(samples.shape[0], nb * 4)[:, :n_words].astype(np.uint32)
+
+
+def draw_erase_add_counts(seed, step, sizes, first_sample=0):
+    """(erase_num, add_num) int64 [B] for windows of `sizes` rows: uniform in [int(0.001 n), int(0.01 n)) as the reference draws them
+    (events_augment.py:31-33,38), 0 where int(0.01 n) == 0; from the shared counter stream (purpose 0, words 1 and 2; word 0 is the
+    window start). The rows themselves and the noise are drawn on the device (evp_events_draw_erase_add)."""
+    n = np.asarray([int(v) for v in sizes], dtype=np.int64)
+    w = philox_words(seed, step, first_sample + np.arange(n.shape[0]), 0, 4).astype(np.uint64)
+    lo, hi = (0.001 * n).astype(np.int64), (0.01 * n).astype(np.int64)
+    span = np.maximum(hi - lo, 0).astype(np.uint64)
+    e = lo + ((w[:, 1] * span) >> np.uint64(32)).astype(np.int64)
+    a_ = lo + ((w[:, 2] * span) >> np.uint64(32)).astype(np.int64)
+    live = hi > 0
+    return np.where(live, e, 0), np.where(live, a_, 0)
+
+
 def draw_erase_add_batch(seed, step, sizes, first_sample=0):
-    """Counter-based decisions for a batch: sample i of optimizer step `step` uses the Philox stream keyed by
+    """Counter-based decisions for a batch drawn on the HOST: sample i of optimizer step `step` uses the Philox stream keyed by
     (seed, step, first_sample + i), so a clip's augmentation does not depend on worker scheduling. Same distribution as
     the reference's (counts uniform in [int(0.001 n), int(0.01 n)), rows without replacement, N(0,1.5) / N(0,1.5) /
-    N(0,0.001) noise), but the noise is drawn for the added rows only (the reference draws 3 n normals and keeps <= 1 %)."""
+    N(0,0.001) noise), but the noise is drawn for the added rows only (the reference draws 3 n normals and keeps <= 1 %).
+    ~130 us of numpy calls per clip: the batched pipeline draws on the device instead (GpuInputPipeline decision_stream="device")."""
     out = []
     for i, n in enumerate(int(v) for v in sizes):
         if int(0.01 * n) <= 0:

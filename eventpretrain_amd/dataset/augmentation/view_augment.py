@@ -36,18 +36,32 @@ def draw_evg_params(rs, H, W, crop_min=0.8, ratio=(3 / 4, 4 / 3)):
     return x0, y0, w, h, hflip, tflip
 
 
-def draw_evg_params_batch(seed, step, B, H, W, crop_min=0.8, first_sample=0):
+def draw_evg_params_batch(seed, step, B, H, W, crop_min=0.8, first_sample=0, ratio=(3 / 4, 4 / 3)):
     """int32 [B,6] rows for samples first_sample .. first_sample+B-1 of optimizer step `step`: sample i uses the Philox
-    stream keyed by (seed, step, i). Same distribution as the reference's (same accept / reject rule)."""
+    stream keyed by (seed, step, i). Same distribution as the reference's (same accept / reject rule: up to ten tries of
+    (area, aspect, swap coin), the first box that fits is placed uniformly, else the whole view; then the two flip coins), vectorised
+    over the batch: every sample draws the uniforms of all ten tries, the first accepted one is used."""
+    from .events_augment import philox_words
+    U = philox_words(seed, step, first_sample + np.arange(B), 4, 10 * 5 + 2).astype(np.float64) * 2.3283064365386963e-10       # [0, 1)
+    T = U[:, :50].reshape(B, 10, 5)
+    area = W * H
+    target = (crop_min + T[..., 0] * (1.0 - crop_min)) * area
+    aspect = W / H * ratio[0] + T[..., 1] * (W / H * ratio[1] - W / H * ratio[0])
+    cw = np.rint(np.sqrt(target * aspect)).astype(np.int64)
+    ch = np.rint(np.sqrt(target / aspect)).astype(np.int64)
+    swap = (T[..., 2] * 10).astype(np.int64) < 5
+    cw, ch = np.where(swap, ch, cw), np.where(swap, cw, ch)
+    ok = (cw < W) & (ch < H)
+    first = np.argmax(ok, axis=1)
+    any_ok = ok.any(axis=1)
+    r = np.arange(B)
+    cw1, ch1 = cw[r, first], ch[r, first]
+    x0 = np.minimum((T[r, first, 3] * np.maximum(W - cw1, 1)).astype(np.int64), np.maximum(W - cw1 - 1, 0))
+    y0 = np.minimum((T[r, first, 4] * np.maximum(H - ch1, 1)).astype(np.int64), np.maximum(H - ch1 - 1, 0))
     out = np.zeros((B, 6), dtype=np.int32)
-    for i in range(B):
-        g = np.random.Generator(np.random.Philox(key=[int(seed) & (2 ** 64 - 1), ((int(step) << 24) ^ (first_sample + i)) & (2 ** 64 - 1)]))
-
-        class _RS:            # the four draw kinds of the reference, on a Generator
-            uniform = staticmethod(lambda a, b: g.uniform(a, b))
-            randint = staticmethod(lambda a, b: int(g.integers(a, b)))
-            random_sample = staticmethod(lambda: g.random())
-        out[i] = draw_evg_params(_RS, H, W, crop_min)
+    out[:, 0], out[:, 1] = np.where(any_ok, x0, 0), np.where(any_ok, y0, 0)
+    out[:, 2], out[:, 3] = np.where(any_ok, cw1, W), np.where(any_ok, ch1, H)
+    out[:, 4], out[:, 5] = U[:, 50] < 0.5, U[:, 51] < 0.5
     return out
 
 

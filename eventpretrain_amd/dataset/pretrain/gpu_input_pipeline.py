@@ -11,8 +11,10 @@ previous step) and every byte of event / voxel data stays on the device:
     rescale + voxel scatter    csrc/voxel.hip    evp_voxel_scatter_scaled_f32  (K1, 3 launches in the verified mode)
     crop / resize / flips      csrc/augment.hip  evp_view_augment_f32, evp_frame_augment_f32
 
-Decision streams: "counter" (default) = Philox keyed by (seed, step, sample): a sample's augmentation does not depend on worker
-scheduling; "legacy" = the reference's process-global numpy stream consumed by the reference's own functions in the order
+Decision streams: "device" (default, round 4) = Philox4x32-10 keyed by (seed, step, sample), the per-clip COUNTS, window starts and
+crop boxes computed on the host with array arithmetic (~1 ms per batch) and the erase / add ROWS and noise drawn by a kernel
+(evp_events_draw_erase_add) -- nothing per clip on the host, no decision tables to upload; "counter" = the same idea with numpy's own
+Philox generator, everything drawn on the host (~13 ms per 64-clip batch: more than a training step); "legacy" = the reference's process-global numpy stream consumed by the reference's own functions in the order
 tests/golden/loader_chain.npz was made with (oracle/gen_golden.py gen_chain): get_random_index -> events_augment on the running
 stream as pr_n_imagenet_dataset.py:82-89, then the seeded evg_augment / frame_augment pair of pr_ef_imagenet_dataset.py:187-206
 (`seed = np.random.randint(1000)` drawn at that point). It reproduces THAT composition under np.random.seed(s) -- neither dataset's
@@ -40,16 +42,17 @@ class PreparedBatch:
     bits) | five offset rows [n_clips + 1] (window begin, window end, erase / add / output offsets) | crop rows of the grids | crop rows
     of the frames (int32 [B,6] each, padded to 8 bytes), plus the few scalars the launches need. `busy` = event recorded after the
     upload that last read the pinned words (the slot is reused round-robin)."""
-    __slots__ = ("words", "n_words", "o", "n_clips", "n_add", "n_out", "max_add", "windows", "params", "fparams", "slot", "sizes")
+    __slots__ = ("words", "n_words", "o", "n_clips", "n_add", "n_out", "max_add", "windows", "params", "fparams", "slot", "sizes",
+                 "n_erase", "max_cnt", "step", "first_sample", "on_device")
 
 
 class GpuInputPipeline:
-    RING = 4
-
-    def __init__(self, args, seed=0, decision_stream="counter"):
-        """args: the reference's namespace (fix_events_num, img_sensor_h / _w, input_size, num_bins, crop_min)."""
-        if decision_stream not in ("counter", "legacy"):
-            raise ValueError("decision_stream must be 'counter' or 'legacy'")
+    def __init__(self, args, seed=0, decision_stream="device", ring=4):
+        """args: the reference's namespace (fix_events_num, img_sensor_h / _w, input_size, num_bins, crop_min). `ring`: pinned slots
+        for prepared batches (how many may exist at once before their run_prepared)."""
+        self.RING = int(ring)
+        if decision_stream not in ("device", "counter", "legacy"):
+            raise ValueError("decision_stream must be 'device', 'counter' or 'legacy'")
         self.args, self.seed, self.stream = args, int(seed), decision_stream
         self.sensor = (int(args.img_sensor_h), int(args.img_sensor_w))
         self.S = int(args.input_size)
@@ -90,7 +93,21 @@ class GpuInputPipeline:
                     fparams[i] = va.draw_evg_params(np.random, int(frame_size[0]), int(frame_size[1]), self.crop_min)
                     fparams[i, 5] = params[i, 5]
             return (windows, dec, params) if fparams is None else (windows, dec, params, fparams)
-        for i, n in enumerate(int(v) for v in sizes):
+        sz = np.asarray([int(v) for v in sizes], dtype=np.int64)
+        if self.stream == "device":
+            w0 = ea.philox_words(self.seed, step, first_sample + np.arange(B), 0, 1)[:, 0].astype(np.uint64)
+            s0 = ((w0 * np.maximum(sz - fix, 0).astype(np.uint64)) >> np.uint64(32)).astype(np.int64)
+            windows[:, 0] = np.where(sz > fix, s0, 0)
+            windows[:, 1] = np.where(sz > fix, s0 + fix, sz)
+            # the rows and the noise are drawn on the device: the "decisions" are the two counts per clip
+            dec = ea.draw_erase_add_counts(self.seed, step, windows[:, 1] - windows[:, 0], first_sample)
+            params = va.draw_evg_params_batch(self.seed, step, B, self.S, self.S, self.crop_min, first_sample)
+            if fparams is None:
+                return windows, dec, params
+            fparams = va.draw_evg_params_batch(self.seed, step, B, int(frame_size[0]), int(frame_size[1]), self.crop_min, first_sample)
+            fparams[:, 5] = params[:, 5]
+            return windows, dec, params, fparams
+        for i, n in enumerate(int(v) for v in sz):
             if n > fix:
                 g = np.random.Generator(np.random.Philox(key=[self.seed & (2 ** 64 - 1), (((int(step) << 24) ^ (first_sample + i)) + (1 << 60)) & (2 ** 64 - 1)]))
                 s0 = int(g.integers(0, n - fix))
@@ -112,6 +129,9 @@ class GpuInputPipeline:
         Returns (voxels float32 [B,bins,S,S], targets float32 [B,C,S,S] | None)."""
         _lib.require_device()
         H, W = self.sensor
+        if self.stream == "device" and isinstance(decisions, tuple) and len(decisions) == 2 and isinstance(decisions[0], np.ndarray):
+            raise ValueError("GpuInputPipeline.run takes per-clip decision lists; with decision_stream='device' use prepare() / run_prepared() "
+                             "(or batch()), or read the device's draws back with device_decisions()")
         ev, off = ea.events_augment_batch(events, clip_offsets, decisions, (H, W), windows=windows)
         vox = voxel_grid_batch(ev, off, self.bins, (self.S, self.S), assume_sorted=assume_sorted, scale=(self.S / W, self.S / H))
         # the grid's and the frames' parameter rows in ONE upload (each pageable copy is a stall of the host)
@@ -150,6 +170,14 @@ class GpuInputPipeline:
         tab = np.zeros((5, n_clips + 1), np.int64)
         tab[0, :n_clips], tab[1, :n_clips] = w_beg, w_end
         max_add = 0
+        on_device = self.stream == "device"
+        if on_device:
+            e_num, a_num = dec
+            tab[2, 1:], tab[3, 1:] = np.cumsum(e_num), np.cumsum(a_num)
+            tab[4, 1:] = np.cumsum((w_end - w_beg) - e_num + a_num)
+            max_add = int(max(a_num.max(), 0)) if n_clips else 0
+            max_cnt = int(max(max_add, e_num.max())) if n_clips else 0
+            dec = []
         for c, d in enumerate(dec):
             n = int(w_end[c] - w_beg[c])
             e = a = 0
@@ -165,13 +193,15 @@ class GpuInputPipeline:
             tab[2, c + 1], tab[3, c + 1], tab[4, c + 1] = tab[2, c] + e, tab[3, c] + a, tab[4, c] + n - e + a
         if max_add > ea.MAX_ADD_PER_CLIP:
             raise _lib.EvpError("GpuInputPipeline.prepare: at most %d added rows per clip (got %d)" % (ea.MAX_ADD_PER_CLIP, max_add))
+        if not on_device:
+            max_cnt = max_add
         rows = np.ascontiguousarray(params, dtype=np.int32).reshape(n_clips, 6)
         S = self.S
         if ((rows[:, 0] < 0) | (rows[:, 1] < 0) | (rows[:, 2] < 1) | (rows[:, 3] < 1) | (rows[:, 0] + rows[:, 2] > S) | (rows[:, 1] + rows[:, 3] > S)).any():
             raise ValueError("GpuInputPipeline.prepare: crop box outside the view")
         n_e, n_a = int(tab[2, -1]), int(tab[3, -1])
         pw = (n_clips * 6 + 1) // 2                      # int32 [B,6] in 8-byte words
-        o = [0, n_e, n_e + n_a, n_e + n_a + 3 * n_a, 0, 0, 0]
+        o = [0, n_e, n_e + n_a, n_e + n_a + 3 * n_a, 0, 0, 0] if not on_device else [0, 0, 0, 0, 0, 0, 0]     # (device stream: no decision tables)
         o[4] = o[3] + 5 * (n_clips + 1)
         o[5] = o[4] + pw
         o[6] = o[5] + (pw if fparams is not None else 0)
@@ -183,9 +213,9 @@ class GpuInputPipeline:
         if pin is None or pin.numel() < o[6]:
             pin = self._pins[slot] = torch.empty(max(o[6] * 2, 1 << 16), dtype=torch.int64).pin_memory()
         w = pin.numpy()
-        if n_e:
+        if n_e and not on_device:
             np.concatenate(er_l, out=w[o[0]:o[1]])
-        if n_a:
+        if n_a and not on_device:
             np.concatenate(ai_l, out=w[o[1]:o[2]])
             np.concatenate(nz_l, out=w[o[2]:o[3]].view(np.float64))
         w[o[3]:o[4]] = tab.reshape(-1)
@@ -198,6 +228,7 @@ class GpuInputPipeline:
             w[o[5]:o[6]].view(np.int32)[:n_clips * 6] = fr.reshape(-1)
         pb = PreparedBatch()
         pb.words, pb.n_words, pb.o, pb.n_clips, pb.n_add, pb.n_out, pb.max_add = pin, o[6], o, n_clips, n_a, int(tab[4, -1]), max_add
+        pb.n_erase, pb.max_cnt, pb.step, pb.first_sample, pb.on_device = n_e, max_cnt, int(step), int(first_sample), on_device
         pb.windows, pb.params, pb.fparams, pb.slot, pb.sizes = windows, params, fparams, slot, win[:, 1] - win[:, 0]
         return pb
 
@@ -223,8 +254,12 @@ class GpuInputPipeline:
         H, W = self.sensor
         ws = torch.empty(max(pb.n_add, 1), 4, dtype=torch.float64, device=dev)
         ev = torch.empty(pb.n_out, 4, dtype=torch.float64, device=dev)
-        call("evp_events_erase_add_win_f64", ptr(events), ptr(tabs[0]), ptr(tabs[1]), nc, ptr(d[o[0]:o[1]]), ptr(tabs[2]), ptr(d[o[1]:o[2]]),
-             ptr(d[o[2]:o[3]]), ptr(tabs[3]), pb.max_add, float(W), float(H), ptr(ws), ptr(tabs[4]), ptr(ev), stream_ptr())
+        if pb.on_device:
+            er_d, ai_d, nz_d = self._draw_on_device(pb, tabs, dev)
+        else:
+            er_d, ai_d, nz_d = d[o[0]:o[1]], d[o[1]:o[2]], d[o[2]:o[3]]
+        call("evp_events_erase_add_win_f64", ptr(events), ptr(tabs[0]), ptr(tabs[1]), nc, ptr(er_d), ptr(tabs[2]), ptr(ai_d),
+             ptr(nz_d), ptr(tabs[3]), pb.max_add, float(W), float(H), ptr(ws), ptr(tabs[4]), ptr(ev), stream_ptr())
         vox = voxel_grid_batch(ev, tabs[4], self.bins, (self.S, self.S), assume_sorted=assume_sorted, scale=(self.S / W, self.S / H))
         p_dev = d[o[4]:o[5]].view(torch.int32)[:nc * 6].view(nc, 6)
         out = va.evg_augment_batch(vox, p_dev, (self.S, self.S))
@@ -234,8 +269,36 @@ class GpuInputPipeline:
             tgt = va.frame_augment_batch(frames, fp, (self.S, self.S))
         return out, tgt
 
+    def _draw_on_device(self, pb, tabs, dev):
+        """The erase / add rows and the noise of a prepared batch, drawn by evp_events_draw_erase_add into fresh device arrays."""
+        er_d = torch.empty(max(pb.n_erase, 1), dtype=torch.int64, device=dev)
+        ai_d = torch.empty(max(pb.n_add, 1), dtype=torch.int64, device=dev)
+        nz_d = torch.empty(max(pb.n_add, 1) * 3, dtype=torch.float64, device=dev)
+        call("evp_events_draw_erase_add", ptr(tabs[0]), ptr(tabs[1]), pb.n_clips, ptr(tabs[2]), ptr(tabs[3]), self.seed & (2 ** 64 - 1),
+             pb.step & (2 ** 64 - 1), pb.first_sample, pb.max_cnt, ptr(er_d), ptr(ai_d), ptr(nz_d), stream_ptr())
+        return er_d, ai_d, nz_d
+
+    def device_decisions(self, pb, device):
+        """Read the device stream's draws of a prepared batch back as the per-clip lists run() / events_augment_batch take (tests, debugging:
+        one upload, one launch, one read-back)."""
+        d = torch.empty(pb.n_words, dtype=torch.int64, device=device)
+        d.copy_(pb.words[:pb.n_words])
+        tabs = d[pb.o[3]:pb.o[4]].view(5, pb.n_clips + 1)
+        er_d, ai_d, nz_d = self._draw_on_device(pb, tabs, d.device)
+        t = tabs.cpu().numpy()
+        er, ai, nz = er_d.cpu().numpy(), ai_d.cpu().numpy(), nz_d.cpu().numpy().reshape(-1, 3)
+        out = []
+        for c in range(pb.n_clips):
+            e, a = slice(t[2, c], t[2, c + 1]), slice(t[3, c], t[3, c + 1])
+            out.append(None if (e.stop == e.start and a.stop == a.start) else (er[e].copy(), ai[a].copy(), nz[a].copy()))
+        return out
+
     def batch(self, events, clip_offsets, step, frames=None, first_sample=0, sample_seeds=None):
         """The whole chain for one batch: decisions on the host, data on the device."""
+        if self.stream == "device":
+            offs = np.asarray(clip_offsets.cpu() if torch.is_tensor(clip_offsets) else clip_offsets, dtype=np.int64)
+            pb = self.prepare(offs, step, first_sample, sample_seeds, frame_size=None if frames is None else frames.shape[-2:])
+            return self.run_prepared(events, pb, frames=frames)
         offs = np.asarray(clip_offsets.cpu() if torch.is_tensor(clip_offsets) else clip_offsets, dtype=np.int64)
         if frames is None:
             windows, dec, params = self.draw(offs[1:] - offs[:-1], step, first_sample, sample_seeds)

@@ -92,6 +92,15 @@ int evp_events_erase_add_win_f64(const double *events, const int64_t *win_begin,
                                  const int64_t *erase_idx, const int64_t *erase_offsets, const int64_t *add_idx, const double *add_noise,
                                  const int64_t *add_offsets, int max_add_per_clip, double sensor_w, double sensor_h, double *add_rows_ws,
                                  const int64_t *out_offsets, double *out_events, void *stream);
+/* The DECISIONS of erase_and_add_events drawn on the device (events_augment.py:31-44: which rows to erase, which to copy, the three
+ * normal noise columns of the copies): clip c (rows [win_begin[c], win_end[c]) of some event array, n_c of them) gets
+ * erase_offsets[c+1] - erase_offsets[c] DISTINCT rows in erase_idx (ascending, clip-relative) and add_offsets[c+1] - add_offsets[c]
+ * distinct rows in add_idx (draw order) with add_noise [.,3] ~ N(0,1.5), N(0,1.5), N(0,0.001) -- uniform draws without replacement
+ * from Philox4x32-10 keyed by (seed, step, first_sample + c). The COUNTS (the offsets) are the caller's: two numbers per clip, uniform
+ * in [int(0.001 n), int(0.01 n)). max_per_clip = the largest count of any list (<= ~7200). Feeds evp_events_erase_add(_win)_f64. */
+int evp_events_draw_erase_add(const int64_t *win_begin, const int64_t *win_end, int n_clips, const int64_t *erase_offsets,
+                              const int64_t *add_offsets, uint64_t seed, uint64_t step, int64_t first_sample, int max_per_clip,
+                              int64_t *erase_idx, int64_t *add_idx, double *add_noise, void *stream);
 /* sorted_flags[c] = 1 if clip c's stamps are non-decreasing, else 0 (device int32 [n_clips]). */
 int evp_events_sorted_check(const double *events, const int64_t *clip_offsets, int n_clips, int is_txyp,
                             int32_t *sorted_flags, void *stream);

@@ -169,7 +169,7 @@ def test_prepared_loader_chain_equals_the_inline_chain():
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     ev = torch.from_numpy(np.concatenate(clips, 0)).cuda()
     frames = torch.randn(len(sizes), 1, 480, 640, device="cuda")
-    pipe = GpuInputPipeline(a, seed=3)
+    pipe = GpuInputPipeline(a, seed=3, decision_stream="counter")     # the host-drawn stream: draw() hands out the decision lists run() takes
     for step in (0, 1, 2, 3, 4, 5):                # more batches than pinned slots: the ring is reused
         w, d, p, f = pipe.draw(off[1:] - off[:-1], step=step, frame_size=(480, 640))
         v0, t0 = pipe.run(ev, off, w, d, p, frames=frames, frame_params=f)
@@ -326,3 +326,67 @@ def test_finetune_epoch_runs_captured_and_follows_the_eager_loop():
     x, y = loader[0]["events_voxel_grid"].cuda(), loader[0]["label"].cuda()
     ls = [ex.step(x, y).item() for _ in range(4)]
     assert all(math.isfinite(v) for v in ls) and len({round(v, 6) for v in ls}) > 1, ls
+
+
+def test_device_decision_stream_equals_its_host_emulation_and_feeds_the_same_chain():
+    """Round 4: with decision_stream="device" (the default) the host computes only counts, window starts and crop boxes (array
+    arithmetic on a Philox4x32-10 restated in numpy -- the known-answer vector of the generator is checked on the CPU side); WHICH rows
+    are erased / copied and the noise are drawn by evp_events_draw_erase_add. (a) The device's lists equal a numpy emulation of the same
+    algorithm bit for bit (first k distinct candidates floor(u n) in draw order; erased rows ascending), the noise to 1e-12; every
+    list is distinct and in range. (b) run_prepared on the device stream equals run() fed with the lists read back. (c) A sample's
+    draws depend on (seed, step, sample) only: the same clip inside another batch gets the same rows."""
+    import numpy as np
+    from eventpretrain_amd.dataset.augmentation import events_augment as ea
+    from eventpretrain_amd.dataset.pretrain.gpu_input_pipeline import GpuInputPipeline
+    from eventpretrain_amd.testing import make_args, synthetic_events
+    a = make_args(crop_min=0.8, input_size=224, fix_events_num=60000, img_sensor_w=640, img_sensor_h=480, device="cuda")
+    sizes = [100_000, 9_000, 60, 25_000, 60_001, 150]
+    clips = [synthetic_events(700 + i, n, width=640, height=480) for i, n in enumerate(sizes)]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    ev = torch.from_numpy(np.concatenate(clips, 0)).cuda()
+    frames = torch.randn(len(sizes), 1, 480, 640, device="cuda")
+    pipe = GpuInputPipeline(a, seed=11)
+    assert pipe.stream == "device"
+    seed, step = 11, 5
+    pb = pipe.prepare(off, step=step, frame_size=(480, 640))
+    dec = pipe.device_decisions(pb, ev.device)
+    win = pb.windows
+    e_num, a_num = ea.draw_erase_add_counts(seed, step, win[:, 1] - win[:, 0])
+    for c, d in enumerate(dec):
+        n = int(win[c, 1] - win[c, 0])
+        if int(0.01 * n) <= 0:
+            assert d is None and e_num[c] == 0 and a_num[c] == 0
+            continue
+        er, ai, nz = d
+        lo, hi = int(0.001 * n), int(0.01 * n)
+        assert lo <= er.size < max(hi, lo + 1) and lo <= ai.size < max(hi, lo + 1) and er.size == e_num[c] and ai.size == a_num[c]
+        assert np.all(np.diff(er) > 0) and er.min() >= 0 and er.max() < n
+        assert np.unique(ai).size == ai.size and ai.min() >= 0 and ai.max() < n
+        # numpy emulation of the kernel
+        want = max(int(e_num.max()), int(a_num.max()))
+        want = want + 64 + want // 8
+        np2 = 64
+        while np2 < want:
+            np2 <<= 1
+        for purpose, k, got, srt in ((1, er.size, er, True), (2, ai.size, ai, False)):
+            w = ea.philox_words(seed, step, [c], purpose, np2)[0].astype(np.uint64)
+            cand = ((w * np.uint64(n)) >> np.uint64(32)).astype(np.int64)
+            _, first = np.unique(cand, return_index=True)
+            sel = cand[np.sort(first)[:k]]                      # first k distinct values in draw order
+            assert np.array_equal(got, np.sort(sel) if srt else sel), (c, purpose)
+        w = ea.philox_words(seed, step, [c], 3, 4 * ai.size)[0].astype(np.float64).reshape(-1, 4)
+        u0, u1, u2, u3 = (w[:, 0] + 0.5) * 2.0 ** -32, w[:, 1] * 2.0 ** -32, (w[:, 2] + 0.5) * 2.0 ** -32, w[:, 3] * 2.0 ** -32
+        r0, r1 = np.sqrt(-2 * np.log(u0)), np.sqrt(-2 * np.log(u2))
+        ref = np.stack([1.5 * r0 * np.cos(2 * np.pi * u1), 1.5 * r0 * np.sin(2 * np.pi * u1), 0.001 * r1 * np.cos(2 * np.pi * u3)], 1)
+        assert np.allclose(nz, ref, rtol=1e-11, atol=1e-13), c
+    # (b) the same chain either way
+    v1, t1 = pipe.run_prepared(ev, pipe.prepare(off, step=step, frame_size=(480, 640)), frames=frames)
+    v0, t0 = pipe.run(ev, off, pb.windows, dec, pb.params, frames=frames, frame_params=pb.fparams)
+    torch.cuda.synchronize()
+    assert torch.allclose(v0, v1, atol=1e-5, rtol=0) and torch.equal(t0, t1)
+    v2, _ = pipe.batch(ev, off, step=step + 1, frames=frames)
+    assert not torch.allclose(v1, v2, atol=1e-3, rtol=0) and torch.isfinite(v2).all()
+    # (c) clip 3 alone, as sample 3 of the same step
+    pb3 = pipe.prepare(np.array([0, sizes[3]], dtype=np.int64), step=step, first_sample=3)
+    d3 = pipe.device_decisions(pb3, ev.device)[0]
+    assert np.array_equal(pb3.windows[0], pb.windows[3]) and all(np.array_equal(x, y) for x, y in zip(d3, dec[3]))

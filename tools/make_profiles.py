@@ -14,7 +14,7 @@ P = os.path.join(ROOT, "profiles")
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     t = json.load(open(os.path.join(G, "pmc_traffic_kernels.json")))
     v = json.load(open(os.path.join(G, "pmc_voxel_kernels.json")))
     sq = json.load(open(os.path.join(G, "pmc_sq_kernels.json")))
@@ -53,7 +53,7 @@ def main():
                     "tools/pmc_kernels.py on the GPU box. Per MI355X_MICROARCH.md 'HBM': on gfx950 FETCH_SIZE tallies the 128-B requests of "
                     "16-B-per-lane loads at 64 B, so reads are doubled (traffic_bytes = (2 x fetch + write) x 1024); WRITE_SIZE is exact. "
                     "Infinity-Cache hits are included in these fabric-side counters.",
-               commands=["tools/gpu_round3_profile.sh (rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py "
+               commands=["tools/gpu_round4_profile.sh (earlier rounds: gpu_round3_profile.sh; rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py "
                          "--no-cpu-baseline --no-kernel-timing --steps 3 --warmup 2; same for tools/voxel_pmc.py)"], kernels=k)
     json.dump(out, open(os.path.join(P, tag + "_pmc_traffic.json"), "w"), indent=1)
     json.dump(dict(note="rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT "
@@ -62,10 +62,10 @@ def main():
               open(os.path.join(P, tag + "_pmc_sq_kernels.json"), "w"), indent=1)
     shutil.copy(os.path.join(G, "pmc_sq_kernels.txt"), os.path.join(P, tag + "_pmc_sq_kernels.txt"))
     shutil.copy(os.path.join(G, "pmc_traffic_kernels.txt"), os.path.join(P, tag + "_pmc_traffic_kernels.txt"))
-    st = "r3" if tag >= "r03" else "r2"
+    st = "r4" if tag >= "r04" else "r3" if tag >= "r03" else "r2"
     shutil.copy(os.path.join(G, "prof_%s_stats" % st, "%s_kernel_stats.csv" % st), os.path.join(P, tag + "_bench_kernel_stats.csv"))
-    for extra, name in (("prof_r3_check.txt", "_roofline_check.txt"), (os.path.join("prof_r3_stats", "r3_memory_copy_stats.csv"), "_bench_memory_copy_stats.csv")):
-        if st == "r3" and os.path.exists(os.path.join(G, extra)):
+    for extra, name in (("prof_%s_check.txt" % st, "_roofline_check.txt"), (os.path.join("prof_%s_stats" % st, "%s_memory_copy_stats.csv" % st), "_bench_memory_copy_stats.csv")):
+        if st != "r2" and os.path.exists(os.path.join(G, extra)):
             shutil.copy(os.path.join(G, extra), os.path.join(P, tag + name))
     for n in ("gemm_g4_grouped_tn_kernel", "gemm_kernel<", "voxel_bin_kernel"):
         if n in k:
