@@ -36,7 +36,7 @@ SIGNATURES = {
     "evp_voxel_scatter_scaled_f32": [_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp],
     "evp_events_sorted_check": [_vp, _vp, _i, _i, _vp, _vp],
     "evp_events_erase_add_f64": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp],
-    "evp_events_draw_erase_add": [_vp, _vp, _i, _vp, _vp, C.c_uint64, C.c_uint64, _i64, _i, _vp, _vp, _vp, _vp],
+    "evp_events_draw_erase_add": [_vp, _vp, _i, _vp, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _i, _vp, _vp, _vp, _vp],
     "evp_events_erase_add_win_f64": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp],
     "evp_mask_from_noise": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "evp_density_noise": [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp],

@@ -285,7 +285,12 @@ __device__ void draw_distinct(uint64_t *keys, int *a, int *b, int *scratch, int 
 
 __global__ __launch_bounds__(1024) void draw_erase_add_kernel(const int64_t *win_begin, const int64_t *win_end, const int64_t *erase_offsets,
                                                               const int64_t *add_offsets, uint64_t seed, uint64_t step, int64_t first_sample,
-                                                              int np2, int64_t *erase_idx, int64_t *add_idx, double *add_noise) {
+                                                              const int64_t *step_first, int np2, int64_t *erase_idx, int64_t *add_idx,
+                                                              double *add_noise) {
+  if (step_first) {                       // (step, first sample) from device memory: a replayed HIP graph draws each batch's own stream
+    step = (uint64_t)step_first[0];
+    first_sample = step_first[1];
+  }
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   uint64_t *keys = reinterpret_cast<uint64_t *>(smem_raw);
   int *a = reinterpret_cast<int *>(keys + np2), *b = a + np2, *scratch = b + np2;      // scratch: 1024 + np2 ints
@@ -361,8 +366,8 @@ extern "C" int evp_events_erase_add_win_f64(const double *events, const int64_t 
 }
 
 extern "C" int evp_events_draw_erase_add(const int64_t *win_begin, const int64_t *win_end, int n_clips, const int64_t *erase_offsets,
-                                         const int64_t *add_offsets, uint64_t seed, uint64_t step, int64_t first_sample, int max_per_clip,
-                                         int64_t *erase_idx, int64_t *add_idx, double *add_noise, void *stream) {
+                                         const int64_t *add_offsets, uint64_t seed, uint64_t step, int64_t first_sample, const int64_t *step_first_dev,
+                                         int max_per_clip, int64_t *erase_idx, int64_t *add_idx, double *add_noise, void *stream) {
   EVP_CHECK_ARG(win_begin && win_end && erase_offsets && add_offsets && erase_idx && add_idx && add_noise, EVP_EINVAL, "evp_events_draw_erase_add: null pointer");
   EVP_CHECK_ARG(n_clips > 0 && max_per_clip >= 0, EVP_ESHAPE, "evp_events_draw_erase_add: bad shape");
   if (max_per_clip == 0) return EVP_OK;
@@ -376,7 +381,7 @@ extern "C" int evp_events_draw_erase_add(const int64_t *win_begin, const int64_t
     EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_events_draw_erase_add: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
   }
   hipLaunchKernelGGL(draw_erase_add_kernel, dim3(n_clips), dim3(1024), smem, (hipStream_t)stream, win_begin, win_end, erase_offsets, add_offsets, seed, step,
-                     first_sample, np2, erase_idx, add_idx, add_noise);
+                     first_sample, step_first_dev, np2, erase_idx, add_idx, add_noise);
   EVP_CHECK_LAUNCH("evp_events_draw_erase_add");
   return EVP_OK;
 }

@@ -90,12 +90,12 @@ def philox_words(seed, step, samples, purpose, n_words):
     return np.stack([c0, c1, c2, c3], axis=2).reshape(samples.shape[0], nb * 4)[:, :n_words].astype(np.uint32)
 
 
-def draw_erase_add_counts(seed, step, sizes, first_sample=0):
+def draw_erase_add_counts(seed, step, sizes, first_sample=0, words=None):
     """(erase_num, add_num) int64 [B] for windows of `sizes` rows: uniform in [int(0.001 n), int(0.01 n)) as the reference draws them
     (events_augment.py:31-33,38), 0 where int(0.01 n) == 0; from the shared counter stream (purpose 0, words 1 and 2; word 0 is the
     window start). The rows themselves and the noise are drawn on the device (evp_events_draw_erase_add)."""
-    n = np.asarray([int(v) for v in sizes], dtype=np.int64)
-    w = philox_words(seed, step, first_sample + np.arange(n.shape[0]), 0, 4).astype(np.uint64)
+    n = np.asarray(sizes, dtype=np.int64)
+    w = (philox_words(seed, step, first_sample + np.arange(n.shape[0]), 0, 4) if words is None else words).astype(np.uint64)
     lo, hi = (0.001 * n).astype(np.int64), (0.01 * n).astype(np.int64)
     span = np.maximum(hi - lo, 0).astype(np.uint64)
     e = lo + ((w[:, 1] * span) >> np.uint64(32)).astype(np.int64)

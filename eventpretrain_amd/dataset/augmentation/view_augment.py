@@ -36,13 +36,13 @@ def draw_evg_params(rs, H, W, crop_min=0.8, ratio=(3 / 4, 4 / 3)):
     return x0, y0, w, h, hflip, tflip
 
 
-def draw_evg_params_batch(seed, step, B, H, W, crop_min=0.8, first_sample=0, ratio=(3 / 4, 4 / 3)):
+def draw_evg_params_batch(seed, step, B, H, W, crop_min=0.8, first_sample=0, ratio=(3 / 4, 4 / 3), U=None):
     """int32 [B,6] rows for samples first_sample .. first_sample+B-1 of optimizer step `step`: sample i uses the Philox
     stream keyed by (seed, step, i). Same distribution as the reference's (same accept / reject rule: up to ten tries of
     (area, aspect, swap coin), the first box that fits is placed uniformly, else the whole view; then the two flip coins), vectorised
     over the batch: every sample draws the uniforms of all ten tries, the first accepted one is used."""
-    from .events_augment import philox_words
-    U = philox_words(seed, step, first_sample + np.arange(B), 4, 10 * 5 + 2).astype(np.float64) * 2.3283064365386963e-10       # [0, 1)
+    if U is None:
+        U = evg_uniforms(seed, step, B, first_sample)
     T = U[:, :50].reshape(B, 10, 5)
     area = W * H
     target = (crop_min + T[..., 0] * (1.0 - crop_min)) * area
@@ -63,6 +63,14 @@ def draw_evg_params_batch(seed, step, B, H, W, crop_min=0.8, first_sample=0, rat
     out[:, 2], out[:, 3] = np.where(any_ok, cw1, W), np.where(any_ok, ch1, H)
     out[:, 4], out[:, 5] = U[:, 50] < 0.5, U[:, 51] < 0.5
     return out
+
+
+def evg_uniforms(seed, step, B, first_sample=0):
+    """float64 [B, 52] in [0, 1): the uniforms behind one sample's crop box and flip coins (shared counter stream, purpose 4). The frame's
+    box is drawn from the SAME uniforms scaled to the frame's size (the reference re-seeds numpy with the sample's seed before
+    frame_augment), so a caller that needs both passes this array to draw_evg_params_batch twice."""
+    from .events_augment import philox_words
+    return philox_words(seed, step, first_sample + np.arange(B), 4, 10 * 5 + 2).astype(np.float64) * 2.3283064365386963e-10
 
 
 def evg_augment_batch(voxels, params, size, negate=None, out=None):

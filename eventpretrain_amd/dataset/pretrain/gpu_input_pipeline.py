@@ -95,16 +95,17 @@ class GpuInputPipeline:
             return (windows, dec, params) if fparams is None else (windows, dec, params, fparams)
         sz = np.asarray([int(v) for v in sizes], dtype=np.int64)
         if self.stream == "device":
-            w0 = ea.philox_words(self.seed, step, first_sample + np.arange(B), 0, 1)[:, 0].astype(np.uint64)
-            s0 = ((w0 * np.maximum(sz - fix, 0).astype(np.uint64)) >> np.uint64(32)).astype(np.int64)
+            words = ea.philox_words(self.seed, step, first_sample + np.arange(B), 0, 4)          # word 0: window start, 1 / 2: the two counts
+            s0 = ((words[:, 0].astype(np.uint64) * np.maximum(sz - fix, 0).astype(np.uint64)) >> np.uint64(32)).astype(np.int64)
             windows[:, 0] = np.where(sz > fix, s0, 0)
             windows[:, 1] = np.where(sz > fix, s0 + fix, sz)
             # the rows and the noise are drawn on the device: the "decisions" are the two counts per clip
-            dec = ea.draw_erase_add_counts(self.seed, step, windows[:, 1] - windows[:, 0], first_sample)
-            params = va.draw_evg_params_batch(self.seed, step, B, self.S, self.S, self.crop_min, first_sample)
+            dec = ea.draw_erase_add_counts(self.seed, step, windows[:, 1] - windows[:, 0], first_sample, words=words)
+            U = va.evg_uniforms(self.seed, step, B, first_sample)
+            params = va.draw_evg_params_batch(self.seed, step, B, self.S, self.S, self.crop_min, first_sample, U=U)
             if fparams is None:
                 return windows, dec, params
-            fparams = va.draw_evg_params_batch(self.seed, step, B, int(frame_size[0]), int(frame_size[1]), self.crop_min, first_sample)
+            fparams = va.draw_evg_params_batch(self.seed, step, B, int(frame_size[0]), int(frame_size[1]), self.crop_min, first_sample, U=U)
             fparams[:, 5] = params[:, 5]
             return windows, dec, params, fparams
         for i, n in enumerate(int(v) for v in sz):
@@ -275,7 +276,7 @@ class GpuInputPipeline:
         ai_d = torch.empty(max(pb.n_add, 1), dtype=torch.int64, device=dev)
         nz_d = torch.empty(max(pb.n_add, 1) * 3, dtype=torch.float64, device=dev)
         call("evp_events_draw_erase_add", ptr(tabs[0]), ptr(tabs[1]), pb.n_clips, ptr(tabs[2]), ptr(tabs[3]), self.seed & (2 ** 64 - 1),
-             pb.step & (2 ** 64 - 1), pb.first_sample, pb.max_cnt, ptr(er_d), ptr(ai_d), ptr(nz_d), stream_ptr())
+             pb.step & (2 ** 64 - 1), pb.first_sample, None, pb.max_cnt, ptr(er_d), ptr(ai_d), ptr(nz_d), stream_ptr())
         return er_d, ai_d, nz_d
 
     def device_decisions(self, pb, device):
@@ -292,6 +293,16 @@ class GpuInputPipeline:
             e, a = slice(t[2, c], t[2, c + 1]), slice(t[3, c], t[3, c + 1])
             out.append(None if (e.stop == e.start and a.stop == a.start) else (er[e].copy(), ai[a].copy(), nz[a].copy()))
         return out
+
+    def capture(self, events, n_clips, frames=None):
+        """The device half as ONE HIP graph (device decision stream): `events` is the buffer every batch's raw rows will sit in (fixed
+        address: the loader uploads into it), `frames` likewise. Launched from Python the eight kernels of a batch cost more host time
+        (~0.9 ms with the worker thread competing for the interpreter) than the GPU needs for them (~0.42 ms); replayed they cost one
+        call. Every buffer gets its upper bound (windows of at most fix_events_num rows, counts below int(0.01 fix_events_num)); what
+        varies per batch -- offsets, crop rows, (step, first sample) -- travels through one pinned table the graph's upload node
+        re-reads. Returns a CapturedChain; its run(prepared) hands out the two STATIC output tensors (consume or clone them before the
+        next run)."""
+        return CapturedChain(self, events, int(n_clips), frames)
 
     def batch(self, events, clip_offsets, step, frames=None, first_sample=0, sample_seeds=None):
         """The whole chain for one batch: decisions on the host, data on the device."""
@@ -313,3 +324,83 @@ class GpuInputPipeline:
         n = float(np.sum(sizes))
         grid = self.bins * self.S * self.S * 4.0 * len(sizes)
         return n * 32 + n * 32 + n * 32 + grid + grid + grid
+
+
+class CapturedChain:
+    """GpuInputPipeline.capture: the chain's device half captured once, replayed per batch."""
+
+    def __init__(self, pipe, events, n_clips, frames):
+        if pipe.stream != "device":
+            raise ValueError("CapturedChain needs decision_stream='device' (host-drawn decision lists change size per batch)")
+        _lib.require_device()
+        self.pipe, self.events, self.frames, self.nc = pipe, events, frames, n_clips
+        dev = events.device
+        fix = int(pipe.args.fix_events_num)
+        self.kmax = max(int(0.01 * fix), 1)
+        pw = (n_clips * 6 + 1) // 2
+        # table layout of a device-stream PreparedBatch: five offset rows | crop rows | frame crop rows; two more words: step, first sample
+        self.n_tab = 5 * (n_clips + 1) + pw + (pw if frames is not None else 0)
+        self.h_tab = torch.zeros(self.n_tab + 2, dtype=torch.int64).pin_memory()      # what the graph's upload node reads
+        self.d_tab = torch.zeros(self.n_tab + 2, dtype=torch.int64, device=dev)
+        self.er = torch.zeros(n_clips * self.kmax, dtype=torch.int64, device=dev)
+        self.ai = torch.zeros(n_clips * self.kmax, dtype=torch.int64, device=dev)
+        self.nz = torch.zeros(n_clips * self.kmax * 3, dtype=torch.float64, device=dev)
+        self.ws = torch.zeros(n_clips * self.kmax, 4, dtype=torch.float64, device=dev)
+        self.ev = torch.zeros(n_clips * (fix + self.kmax), 4, dtype=torch.float64, device=dev)
+        self._busy = None
+        # warm-up (allocator, kernel attributes) on a side stream, then capture
+        import numpy as _np
+        sizes = _np.full(n_clips, min(fix, int(events.shape[0]) // max(n_clips, 1)), dtype=_np.int64)
+        off = _np.concatenate([[0], _np.cumsum(sizes)]).astype(_np.int64)
+        pb = pipe.prepare(off, step=0, frame_size=None if frames is None else frames.shape[-2:])
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._stage(pb)
+            self._launches()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self.out, self.tgt = self._launches()
+
+    def _stage(self, pb):
+        if pb.n_clips != self.nc or not pb.on_device or pb.n_words != self.n_tab:
+            raise ValueError("CapturedChain.run: the prepared batch does not have the captured shape (clips, frames, decision stream)")
+        if pb.max_cnt > self.kmax or int(pb.sizes.max()) > int(self.pipe.args.fix_events_num):
+            raise ValueError("CapturedChain.run: a window or a count exceeds the captured upper bounds")
+        h = self.h_tab.numpy()
+        h[:self.n_tab] = pb.words.numpy()[:self.n_tab]
+        h[self.n_tab], h[self.n_tab + 1] = pb.step, pb.first_sample
+
+    def _launches(self):
+        pipe, nc, dev = self.pipe, self.nc, self.events.device
+        self.d_tab.copy_(self.h_tab, non_blocking=True)
+        d = self.d_tab
+        tabs = d[:5 * (nc + 1)].view(5, nc + 1)
+        pw = (nc * 6 + 1) // 2
+        o4 = 5 * (nc + 1)
+        H, W = pipe.sensor
+        call("evp_events_draw_erase_add", ptr(tabs[0]), ptr(tabs[1]), nc, ptr(tabs[2]), ptr(tabs[3]), pipe.seed & (2 ** 64 - 1), 0, 0,
+             ptr(d[self.n_tab:]), self.kmax, ptr(self.er), ptr(self.ai), ptr(self.nz), stream_ptr())
+        call("evp_events_erase_add_win_f64", ptr(self.events), ptr(tabs[0]), ptr(tabs[1]), nc, ptr(self.er), ptr(tabs[2]), ptr(self.ai),
+             ptr(self.nz), ptr(tabs[3]), self.kmax, float(W), float(H), ptr(self.ws), ptr(tabs[4]), ptr(self.ev), stream_ptr())
+        vox = voxel_grid_batch(self.ev, tabs[4], pipe.bins, (pipe.S, pipe.S), assume_sorted=True, scale=(pipe.S / W, pipe.S / H))
+        p_dev = d[o4:o4 + pw].view(torch.int32)[:nc * 6].view(nc, 6)
+        out = va.evg_augment_batch(vox, p_dev, (pipe.S, pipe.S))
+        tgt = None
+        if self.frames is not None:
+            fp = d[o4 + pw:o4 + 2 * pw].view(torch.int32)[:nc * 6].view(nc, 6)
+            tgt = va.frame_augment_batch(self.frames, fp, (pipe.S, pipe.S))
+        return out, tgt
+
+    def run(self, pb):
+        """One batch: the prepared tables into the pinned slot, one replay. -> (voxels, targets): static tensors."""
+        if self._busy is not None:
+            self._busy.synchronize()                  # the previous replay is done: its upload node has read the pinned table and its
+        self._stage(pb)                               # outputs have been consumed by whatever the caller queued behind it
+        self.graph.replay()
+        ev = self._busy or torch.cuda.Event()
+        ev.record()
+        self._busy = ev
+        return self.out, self.tgt

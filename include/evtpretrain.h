@@ -97,10 +97,12 @@ int evp_events_erase_add_win_f64(const double *events, const int64_t *win_begin,
  * erase_offsets[c+1] - erase_offsets[c] DISTINCT rows in erase_idx (ascending, clip-relative) and add_offsets[c+1] - add_offsets[c]
  * distinct rows in add_idx (draw order) with add_noise [.,3] ~ N(0,1.5), N(0,1.5), N(0,0.001) -- uniform draws without replacement
  * from Philox4x32-10 keyed by (seed, step, first_sample + c). The COUNTS (the offsets) are the caller's: two numbers per clip, uniform
- * in [int(0.001 n), int(0.01 n)). max_per_clip = the largest count of any list (<= ~7200). Feeds evp_events_erase_add(_win)_f64. */
+ * in [int(0.001 n), int(0.01 n)). max_per_clip = the largest count of any list (<= ~7200; an upper bound will do). step_first_dev
+ * (optional, device int64[2]) overrides (step, first_sample) at run time, so that one captured HIP graph serves every batch. Feeds
+ * evp_events_erase_add(_win)_f64. */
 int evp_events_draw_erase_add(const int64_t *win_begin, const int64_t *win_end, int n_clips, const int64_t *erase_offsets,
-                              const int64_t *add_offsets, uint64_t seed, uint64_t step, int64_t first_sample, int max_per_clip,
-                              int64_t *erase_idx, int64_t *add_idx, double *add_noise, void *stream);
+                              const int64_t *add_offsets, uint64_t seed, uint64_t step, int64_t first_sample, const int64_t *step_first_dev,
+                              int max_per_clip, int64_t *erase_idx, int64_t *add_idx, double *add_noise, void *stream);
 /* sorted_flags[c] = 1 if clip c's stamps are non-decreasing, else 0 (device int32 [n_clips]). */
 int evp_events_sorted_check(const double *events, const int64_t *clip_offsets, int n_clips, int is_txyp,
                             int32_t *sorted_flags, void *stream);

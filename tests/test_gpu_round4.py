@@ -354,14 +354,14 @@ def test_device_decision_stream_equals_its_host_emulation_and_feeds_the_same_cha
     e_num, a_num = ea.draw_erase_add_counts(seed, step, win[:, 1] - win[:, 0])
     for c, d in enumerate(dec):
         n = int(win[c, 1] - win[c, 0])
-        if int(0.01 * n) <= 0:
+        if int(0.01 * n) <= 0 or (e_num[c] == 0 and a_num[c] == 0):      # (n = 150: the counts are drawn from [0, 1))
             assert d is None and e_num[c] == 0 and a_num[c] == 0
             continue
         er, ai, nz = d
         lo, hi = int(0.001 * n), int(0.01 * n)
         assert lo <= er.size < max(hi, lo + 1) and lo <= ai.size < max(hi, lo + 1) and er.size == e_num[c] and ai.size == a_num[c]
-        assert np.all(np.diff(er) > 0) and er.min() >= 0 and er.max() < n
-        assert np.unique(ai).size == ai.size and ai.min() >= 0 and ai.max() < n
+        assert np.all(np.diff(er) > 0) and (er.size == 0 or (er.min() >= 0 and er.max() < n))
+        assert np.unique(ai).size == ai.size and (ai.size == 0 or (ai.min() >= 0 and ai.max() < n))
         # numpy emulation of the kernel
         want = max(int(e_num.max()), int(a_num.max()))
         want = want + 64 + want // 8
@@ -386,6 +386,15 @@ def test_device_decision_stream_equals_its_host_emulation_and_feeds_the_same_cha
     assert torch.allclose(v0, v1, atol=1e-5, rtol=0) and torch.equal(t0, t1)
     v2, _ = pipe.batch(ev, off, step=step + 1, frames=frames)
     assert not torch.allclose(v1, v2, atol=1e-3, rtol=0) and torch.isfinite(v2).all()
+    # (b') the device half as ONE captured graph: same outputs, batch after batch (a different step draws different rows)
+    a2 = make_args(crop_min=0.8, input_size=224, fix_events_num=60000, img_sensor_w=640, img_sensor_h=480, device="cuda")
+    pipe2 = GpuInputPipeline(a2, seed=11)
+    chain = pipe2.capture(ev, len(sizes), frames=frames)
+    for st in (step, step + 1, step):
+        ref_v, ref_t = pipe.run_prepared(ev, pipe.prepare(off, step=st, frame_size=(480, 640)), frames=frames)
+        got_v, got_t = chain.run(pipe2.prepare(off, step=st, frame_size=(480, 640)))
+        torch.cuda.synchronize()
+        assert torch.allclose(ref_v, got_v, atol=1e-5, rtol=0) and torch.equal(ref_t, got_t), st
     # (c) clip 3 alone, as sample 3 of the same step
     pb3 = pipe.prepare(np.array([0, sizes[3]], dtype=np.int64), step=step, first_sample=3)
     d3 = pipe.device_decisions(pb3, ev.device)[0]

@@ -12,10 +12,8 @@ clip = synthetic_events(4242, 150_000, width=640, height=480)
 ev = torch.from_numpy(np.concatenate([clip] * B, 0)).cuda()
 off = np.arange(0, (B + 1) * 150_000, 150_000, dtype=np.int64)
 frames = torch.randn(B, 1, 480, 640, device="cuda")
-pipe = GpuInputPipeline(pa, seed=1)
-drawn = [pipe.draw(off[1:] - off[:-1], step=s, frame_size=(480, 640)) for s in range(2)]
+pipe = GpuInputPipeline(pa, seed=1)          # device decision stream: counts on the host, rows and noise drawn by a kernel
 for i in range(10):
-    w, d, p, f = drawn[i % 2]
-    pipe.run(ev, off, w, d, p, frames=frames, frame_params=f)
+    pipe.run_prepared(ev, pipe.prepare(off, step=i, frame_size=(480, 640)), frames=frames)
 torch.cuda.synchronize()
 print("done")
