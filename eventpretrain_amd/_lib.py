@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVP_LIB") or os.path.join(_HERE, "libevtpretrain.so")     # EVP_LIB: another build of the same ABI (A/B runs)
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 2            # include/evtpretrain.h EVP_ABI_VERSION: checked when the library is loaded (EVP_LIB overrides included)
+ABI_VERSION = 3            # include/evtpretrain.h EVP_ABI_VERSION: checked when the library is loaded (EVP_LIB overrides included)
 EVP_F32, EVP_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_DGELU, ACT_RELU, ACT_DRELU = 0, 1, 2, 3, 4
 

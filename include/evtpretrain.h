@@ -31,8 +31,8 @@ enum { EVP_ACT_NONE = 0, EVP_ACT_GELU = 1, EVP_ACT_DGELU = 2, EVP_ACT_RELU = 3, 
 
 const char *evp_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: evp_dropout_fwd takes a device-side seed; evp_gemm_desc lost its
- * stream-K workspace fields in round 3). A host binding must compare evp_abi_version() with EVP_ABI_VERSION at load time. */
-#define EVP_ABI_VERSION 2
+ * stream-K workspace fields in round 3; 3: evp_events_draw_erase_add). A host binding must compare evp_abi_version() with EVP_ABI_VERSION at load time. */
+#define EVP_ABI_VERSION 3
 int evp_abi_version(void);
 /* Name of the code object's target ("gfx950"). */
 const char *evp_target_arch(void);
