@@ -12,12 +12,13 @@ def _pair(v):
 
 
 def _reject_dropout(**rates):
-    """Attention-probability dropout is the one regulariser not built: the probabilities never leave the fused attention kernels.
-    Every entry script of the reference runs it at 0 (main_pretrain.py:99, main_finetune_cls.py:152)."""
+    """Attention-probability dropout on the WINDOWED (Swin) attention is the one regulariser not built: its probabilities never leave
+    the window kernels. (The ViT blocks -- ViT and ConvViT backbones -- take it: ops.attention_dropout_fwd.) Every entry script of the
+    reference runs it at 0 (main_pretrain.py:99, main_finetune_cls.py:152)."""
     for k, v in rates.items():
         if v:
-            raise NotImplementedError(f"{k}={v}: dropout on the attention probabilities is not built (the reference's scripts run "
-                                      "attn_drop_rate = 0); drop_rate and drop_path_rate are")
+            raise NotImplementedError(f"{k}={v}: dropout on the windowed attention probabilities is not built (the reference's scripts "
+                                      "run attn_drop_rate = 0); drop_rate and drop_path_rate are, and attn_drop on the ViT blocks")
 
 
 class PatchEmbed(nn.Module):
@@ -54,8 +55,8 @@ class Attention(nn.Module):
 
     def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
         super().__init__()
-        _reject_dropout(attn_drop=attn_drop)
-        self.proj_drop_rate = float(proj_drop)      # applied by the block's fused function (ops.BlockDrop)
+        self.attn_drop_rate = float(attn_drop)      # vit_block.py:127,138: applied by the block's fused function through the
+        self.proj_drop_rate = float(proj_drop)      # materialised-probabilities path (ops.attention_dropout_fwd); ops.BlockDrop
         if qk_scale is not None:
             raise NotImplementedError("qk_scale override is not used on the pre-training path")
         if not qkv_bias:
@@ -84,6 +85,7 @@ class ViTBlock(nn.Module):
         # -- the pre-training recipe -- the block takes the fused path with the residual add inside the GEMM epilogue
         self.drop_path_rate = float(drop_path)
         self.drop_rate = float(drop)
+        self.attn_drop_rate = float(attn_drop)      # dropout on the attention probabilities (vit_block.py:127,138)
         self.norm1 = norm_layer(dim)
         self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
         self.norm2 = norm_layer(dim)

