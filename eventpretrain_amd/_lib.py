@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVP_LIB") or os.path.join(_HERE, "libevtpretrain.so")     # EVP_LIB: another build of the same ABI (A/B runs)
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 3            # include/evtpretrain.h EVP_ABI_VERSION: checked when the library is loaded (EVP_LIB overrides included)
+ABI_VERSION = 4            # include/evtpretrain.h EVP_ABI_VERSION: checked when the library is loaded (EVP_LIB overrides included)
 EVP_F32, EVP_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_DGELU, ACT_RELU, ACT_DRELU = 0, 1, 2, 3, 4
 
@@ -94,8 +94,8 @@ SIGNATURES = {
     "evp_infonce_queue": [_vp, _vp, _i64, _i, _i64, _f, _vp, _vp, _vp, _vp, _vp],
     "evp_enqueue_keys": [_vp, _vp, _i, _i, _i, _i, _i, _vp],
     "evp_enqueue_keys_dev": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "evp_window_attention_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
-    "evp_window_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "evp_window_attention_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _f, _vp],
+    "evp_window_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _f, _vp],
     "evp_window_attention_fused_np": [_i],
     "evp_window_bias_build": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "evp_window_attention_fused_fwd": [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],

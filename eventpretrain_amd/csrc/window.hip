@@ -61,7 +61,8 @@ __device__ __forceinline__ void wa_scores_softmax(const float *q, const float *k
 template <typename T>
 __global__ __launch_bounds__(WA_THREADS) void win_attn_fwd_kernel(const T *__restrict__ qkv, const float *__restrict__ table,
                                                                   const int32_t *__restrict__ rel, T *__restrict__ out,
-                                                                  float *__restrict__ probs, int nG, int N, int H, float scale) {
+                                                                  float *__restrict__ probs, int nG, int N, int H, float scale,
+                                                                  const uint8_t *__restrict__ keep, float keep_scale) {
   extern __shared__ __attribute__((aligned(16))) float wa_sm[];
   float *q = wa_sm, *k = q + N * WA_LD, *v = k + N * WA_LD, *S = v + N * WA_LD;
   const int bg = blockIdx.x / H, h = blockIdx.x - bg * H;
@@ -73,6 +74,11 @@ __global__ __launch_bounds__(WA_THREADS) void win_attn_fwd_kernel(const T *__res
   wa_load_rows(base + 2 * H * WA_DH, v, N, row, 1.0f);
   __syncthreads();
   wa_scores_softmax(q, k, S, table, rel + (int64_t)g * N * N, N, H, h);
+  if (keep) {  // attn_drop (swin_block.py:113,152): P <- P * keep / (1 - p); the returned map is the dropped one (:157)
+    const uint8_t *kp = keep + (int64_t)blockIdx.x * N * N;
+    for (int e = threadIdx.x; e < N * N; e += WA_THREADS) S[e] = kp[e] ? S[e] * keep_scale : 0.f;
+    __syncthreads();
+  }
   if (probs) {
     float *pp = probs + (int64_t)blockIdx.x * N * N;
     for (int e = threadIdx.x; e < N * N; e += WA_THREADS) pp[e] = S[e];
@@ -89,7 +95,8 @@ template <typename T>
 __global__ __launch_bounds__(WA_THREADS) void win_attn_bwd_kernel(const T *__restrict__ qkv, const float *__restrict__ table,
                                                                   const int32_t *__restrict__ rel, const T *__restrict__ out,
                                                                   const T *__restrict__ dout, T *__restrict__ dqkv,
-                                                                  float *__restrict__ dtable, int nG, int N, int H, int R, float scale) {
+                                                                  float *__restrict__ dtable, int nG, int N, int H, int R, float scale,
+                                                                  const uint8_t *__restrict__ keep, float keep_scale) {
   extern __shared__ __attribute__((aligned(16))) float wa_sm[];
   float *q = wa_sm, *k = q + N * WA_LD, *v = k + N * WA_LD, *dO = v + N * WA_LD, *S = dO + N * WA_LD;
   float *delta = S + N * N, *tab = delta + N;
@@ -117,11 +124,17 @@ __global__ __launch_bounds__(WA_THREADS) void win_attn_bwd_kernel(const T *__res
   __syncthreads();
   wa_scores_softmax(q, k, S, table, relg, N, H, h);
   T *dbase = dqkv + (int64_t)bg * N * row + h * WA_DH;
-  // dV[j][d] = sum_i P[i][j] dO[i][d]
+  // with attn_drop: O = P' V, P' = P * keep / (1 - p); dV takes P', dP = keep / (1 - p) * dP', and delta_i = dO_i . O_i still equals
+  // sum_j P_ij dP_ij
+  const uint8_t *kp = keep ? keep + (int64_t)blockIdx.x * N * N : nullptr;
+  // dV[j][d] = sum_i P'[i][j] dO[i][d]
   for (int e = threadIdx.x; e < N * WA_DH; e += WA_THREADS) {
     const int j = e >> 5, d = e & 31;
     float acc = 0.f;
-    for (int i = 0; i < N; ++i) acc = fmaf(S[i * N + j], dO[i * WA_LD + d], acc);
+    if (kp) {
+      for (int i = 0; i < N; ++i) acc = fmaf(kp[i * N + j] ? S[i * N + j] * keep_scale : 0.f, dO[i * WA_LD + d], acc);
+    } else
+      for (int i = 0; i < N; ++i) acc = fmaf(S[i * N + j], dO[i * WA_LD + d], acc);
     ElemIO<T>::st(dbase + (int64_t)j * row + 2 * H * WA_DH + d, acc);
   }
   __syncthreads();
@@ -131,6 +144,7 @@ __global__ __launch_bounds__(WA_THREADS) void win_attn_bwd_kernel(const T *__res
     float dp = 0.f;
 #pragma unroll
     for (int d = 0; d < WA_DH; ++d) dp = fmaf(dO[i * WA_LD + d], v[j * WA_LD + d], dp);
+    if (kp) dp = kp[e] ? dp * keep_scale : 0.f;
     const float ds = S[e] * (dp - delta[i]);
     S[e] = ds;
     const int r = relg[e];
@@ -162,7 +176,7 @@ static int wa_check(const char *fn, int Bg, int nG, int N, int H, int R, int dty
 }
 
 extern "C" int evp_window_attention_fwd(const void *qkv, const float *table, const int32_t *rel, void *out, float *probs, int Bg, int nG,
-                                        int N, int H, int R, float scale, int dtype, void *stream) {
+                                        int N, int H, int R, float scale, int dtype, const void *keep, float keep_scale, void *stream) {
   int rc = wa_check("evp_window_attention_fwd", Bg, nG, N, H, R, dtype);
   if (rc) return rc;
   EVP_CHECK_ARG(qkv && table && rel && out, EVP_EINVAL, "evp_window_attention_fwd: null pointer");
@@ -172,11 +186,13 @@ extern "C" int evp_window_attention_fwd(const void *qkv, const float *table, con
   if (dtype == EVP_F32) {
     auto kfn = win_attn_fwd_kernel<float>;
     if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(kfn, grid, dim3(WA_THREADS), smem, st, (const float *)qkv, table, rel, (float *)out, probs, nG, N, H, scale);
+    hipLaunchKernelGGL(kfn, grid, dim3(WA_THREADS), smem, st, (const float *)qkv, table, rel, (float *)out, probs, nG, N, H, scale,
+                       (const uint8_t *)keep, keep_scale);
   } else {
     auto kfn = win_attn_fwd_kernel<bf16_t>;
     if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(kfn, grid, dim3(WA_THREADS), smem, st, (const bf16_t *)qkv, table, rel, (bf16_t *)out, probs, nG, N, H, scale);
+    hipLaunchKernelGGL(kfn, grid, dim3(WA_THREADS), smem, st, (const bf16_t *)qkv, table, rel, (bf16_t *)out, probs, nG, N, H, scale,
+                       (const uint8_t *)keep, keep_scale);
   }
   EVP_CHECK_LAUNCH("evp_window_attention_fwd");
   return EVP_OK;
@@ -184,7 +200,7 @@ extern "C" int evp_window_attention_fwd(const void *qkv, const float *table, con
 
 extern "C" int evp_window_attention_bwd(const void *qkv, const float *table, const int32_t *rel, const void *out, const void *dout,
                                         void *dqkv, float *dtable, int Bg, int nG, int N, int H, int R, float scale, int dtype,
-                                        void *stream) {
+                                        const void *keep, float keep_scale, void *stream) {
   int rc = wa_check("evp_window_attention_bwd", Bg, nG, N, H, R, dtype);
   if (rc) return rc;
   EVP_CHECK_ARG(qkv && table && rel && out && dout && dqkv && dtable, EVP_EINVAL, "evp_window_attention_bwd: null pointer");
@@ -197,12 +213,12 @@ extern "C" int evp_window_attention_bwd(const void *qkv, const float *table, con
     auto kfn = win_attn_bwd_kernel<float>;
     if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(kfn, grid, dim3(WA_THREADS), smem, st, (const float *)qkv, table, rel, (const float *)out, (const float *)dout,
-                       (float *)dqkv, dtable, nG, N, H, R, scale);
+                       (float *)dqkv, dtable, nG, N, H, R, scale, (const uint8_t *)keep, keep_scale);
   } else {
     auto kfn = win_attn_bwd_kernel<bf16_t>;
     if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(kfn, grid, dim3(WA_THREADS), smem, st, (const bf16_t *)qkv, table, rel, (const bf16_t *)out, (const bf16_t *)dout,
-                       (bf16_t *)dqkv, dtable, nG, N, H, R, scale);
+                       (bf16_t *)dqkv, dtable, nG, N, H, R, scale, (const uint8_t *)keep, keep_scale);
   }
   EVP_CHECK_LAUNCH("evp_window_attention_bwd");
   return EVP_OK;

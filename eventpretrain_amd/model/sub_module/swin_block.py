@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from ... import _lib, ops
-from .vit_block import _pair, _reject_dropout
+from .vit_block import _pair
 
 
 def get_coordinates(h, w, device="cpu"):
@@ -67,7 +67,7 @@ class WindowAttention(nn.Module):
 
     def __init__(self, dim, window_size, num_heads, qkv_bias=True, qk_scale=None, attn_drop=0., proj_drop=0.):
         super().__init__()
-        _reject_dropout(attn_drop=attn_drop)
+        self.attn_drop_rate = float(attn_drop)      # swin_block.py:113,152: applied inside ops.SwinBlockFn (keep flags into the LDS kernels)
         self.proj_drop_rate = float(proj_drop)
         if qk_scale is not None:
             raise NotImplementedError("qk_scale override is not used on the pre-training path")
@@ -173,6 +173,7 @@ class SwinTransformerBlock(nn.Module):
         super().__init__()
         self.drop_path_rate = float(drop_path)      # swin_block.py:257,270-271: per group instance (x.shape[0]), training mode only
         self.drop_rate = float(drop)
+        self.attn_drop_rate = float(attn_drop)      # swin_block.py:113,152 (ops.draw_block_drop reads it)
         self.dim = dim
         self.input_resolution = input_resolution
         self.num_heads = num_heads

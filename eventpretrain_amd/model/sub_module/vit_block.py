@@ -11,16 +11,6 @@ def _pair(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
 
-def _reject_dropout(**rates):
-    """Attention-probability dropout on the WINDOWED (Swin) attention is the one regulariser not built: its probabilities never leave
-    the window kernels. (The ViT blocks -- ViT and ConvViT backbones -- take it: ops.attention_dropout_fwd.) Every entry script of the
-    reference runs it at 0 (main_pretrain.py:99, main_finetune_cls.py:152)."""
-    for k, v in rates.items():
-        if v:
-            raise NotImplementedError(f"{k}={v}: dropout on the windowed attention probabilities is not built (the reference's scripts "
-                                      "run attn_drop_rate = 0); drop_rate and drop_path_rate are, and attn_drop on the ViT blocks")
-
-
 class PatchEmbed(nn.Module):
     """Image to patch embedding: Conv2d(k=s=patch) -> LayerNorm over channels (eps 1e-5) -> GELU.
     forward(x) returns the reference's (B, D, H/p, W/p) layout; `tokens()` is the fused hot-path entry that also adds

@@ -8,6 +8,7 @@ Precision modes (set with `set_compute_dtype`):
 Every tensor handed to a kernel is allocated by PyTorch; all arithmetic happens in libevtpretrain.so.
 """
 import ctypes as C
+import math
 import os
 
 import numpy as np
@@ -764,7 +765,7 @@ class BlockDrop:
         self.u = (u1, u2)
         self.keep_prob = float(keep_prob)
         self.drop = float(drop)
-        self.attn_drop = float(attn_drop)           # dropout on the attention probabilities (vit_block.py:127,138): ViT blocks only
+        self.attn_drop = float(attn_drop)           # dropout on the attention probabilities (vit_block.py:127,138; swin_block.py:113,152)
         self.seed_dev = seed if torch.is_tensor(seed) else None
         self.seed = 0 if torch.is_tensor(seed) else int(seed)
         self.masks = masks            # optional explicit uint8 masks {"proj": .., "hidden": .., "fc2": ..} (tests: given-mask parity)
@@ -1721,8 +1722,12 @@ class SwinBlockFn(torch.autograd.Function):
         scale = dh ** -0.5
         # bf16 mode: the MFMA kernels of the ViT attention with the gathered bias as an additive matrix per (group, head); the
         # f32 LDS kernels stay the parity path and serve the blocks that return their probabilities
-        fused = _use_window_mfma and T == torch.bfloat16 and not want_attn and N <= 128
+        a_drop = rd is not None and rd.attn_drop > 0
+        fused = _use_window_mfma and T == torch.bfloat16 and not want_attn and N <= 128 and not a_drop
         lse = addm = addmT = None
+        keep, keep_scale = None, 1.0
+        if a_drop:           # swin_block.py:113,152: the LDS kernels hold the probabilities and take the keep flags; the MFMA form never does
+            keep, keep_scale = _attn_keep_mask(rd, (Bg, heads, N, N), dev), 1.0 / (1.0 - rd.attn_drop)
         if fused:
             NP = call("evp_window_attention_fused_np", N)
             addm = torch.empty(nG * heads * NP * NP, dtype=torch.float32, device=dev)
@@ -1732,7 +1737,7 @@ class SwinBlockFn(torch.autograd.Function):
             call("evp_window_attention_fused_fwd", ptr(qkv), ptr(addm), Bg, nG, N, heads, scale, ptr(att), ptr(lse), stream_ptr())
         else:
             call("evp_window_attention_fwd", ptr(qkv), ptr(tab), ptr(_chk(rel, torch.int32)), ptr(att), ptr(probs), Bg, nG, N, heads, R,
-                 scale, dt(qkv), stream_ptr())
+                 scale, dt(qkv), ptr(keep), keep_scale, stream_ptr())
         x1, mk_p = _branch_residual(att, wp, pb, x2d, M, D, D, rd, 0, N, "proj")
         ln2, mean2, rstd2 = layernorm_fwd(x1, n2w, n2b, eps, T)
         Hd = f1w.shape[0]
@@ -1750,6 +1755,7 @@ class SwinBlockFn(torch.autograd.Function):
         ctx.prm = (qkvw, qkvb, pw, pb, f1w, f1b, f2w, f2b)
         ctx.nprm = (n1w, n1b, n2w, n2b)
         ctx.win = (lse, addm, addmT)          # plain tensors of this node (not inputs / outputs): kept on ctx
+        ctx.keep = (keep, keep_scale)
         out = x2.view(Bg, N, D)
         if want_attn:
             ctx.mark_non_differentiable(probs)
@@ -1807,12 +1813,25 @@ class SwinBlockFn(torch.autograd.Function):
             call("evp_window_bias_reduce", ptr(dA), ptr(rel), Bg, nG, N, heads, R, ptr(dtable), stream_ptr())
         else:
             call("evp_window_attention_bwd", ptr(qkv), ptr(tab), ptr(rel), ptr(att), ptr(datt), ptr(dqkv), ptr(dtable), Bg, nG, N, heads,
-                 R, scale, dt(qkv), stream_ptr())
+                 R, scale, dt(qkv), ptr(ctx.keep[0]), ctx.keep[1], stream_ptr())
         dwq, dbq = _wgrad_bias(dqkv, ln1, 3 * D, D, M, qkvw_, qkvb_, need[5], need[6])
         dln1 = torch.empty(M, D, dtype=T, device=dev)
         gemm(dqkv, wq, dln1, M=M, N=D, K=3 * D, trans_b=True, ldb=D)
         g0, _, dn1w, dn1b = layernorm_bwd(dln1, x2d, n1w, mean1, rstd1, gres=g1, want_lp=bf, params=ctx.nprm[:2], side=bf)
         return (g0.view(Bg, N, D), dtable, None, dn1w, dn1b, dwq, dbq, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None, None, None, None)
+
+
+def _attn_keep_mask(rd, shape, dev):
+    """uint8 keep flags for dropout on attention probabilities of `shape`: rd.masks["attn"] when given, else drawn by evp_dropout_fwd from
+    rd's Philox stream (the same draw the ViT path makes in attention_dropout_fwd: flag e <- word e of the stream at rd's next offset)."""
+    if rd.masks is not None and "attn" in rd.masks:
+        m = _chk(rd.masks["attn"]).view(-1)
+        if m.numel() != math.prod(shape) or m.dtype != torch.uint8:
+            raise _lib.EvpError(f"attention keep mask: expected uint8 with {math.prod(shape)} elements, got {m.dtype} {tuple(m.shape)}")
+        return m
+    sub = BlockDrop(drop=rd.attn_drop, seed=rd.seed_dev if rd.seed_dev is not None else rd.seed)
+    sub._n = rd.next_offset(math.prod(shape))
+    return dropout_fwd(torch.ones(shape, dtype=torch.float32, device=dev), sub, "attn")[1]
 
 
 def swin_block(x, blk, rel, eps, want_attn=False, rd=None):

@@ -32,7 +32,7 @@ enum { EVP_ACT_NONE = 0, EVP_ACT_GELU = 1, EVP_ACT_DGELU = 2, EVP_ACT_RELU = 3, 
 const char *evp_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: evp_dropout_fwd takes a device-side seed; evp_gemm_desc lost its
  * stream-K workspace fields in round 3; 3: evp_events_draw_erase_add). A host binding must compare evp_abi_version() with EVP_ABI_VERSION at load time. */
-#define EVP_ABI_VERSION 3
+#define EVP_ABI_VERSION 4
 int evp_abi_version(void);
 /* Name of the code object's target ("gfx950"). */
 const char *evp_target_arch(void);
@@ -386,13 +386,16 @@ int evp_enqueue_keys_dev(float *queue, const float *keys, int64_t *queue_ptr, in
  * reference masks (different window, or padding: it zeroes their bias and adds -100, :140-149);
  * out dtype [Bg, N, H*32]; probs (may be NULL) float32 [Bg, H, N, N]. N <= 128, R <= 512. */
 int evp_window_attention_fwd(const void *qkv, const float *table, const int32_t *rel, void *out, float *probs, int Bg,
-                             int nG, int N, int H, int R, float scale, int dtype, void *stream);
-/* Backward of the above: recomputes P, writes dqkv (same layout as qkv) and dtable float32 [R, H] (zeroed here,
+                             int nG, int N, int H, int R, float scale, int dtype, const void *keep, float keep_scale, void *stream);
+/* `keep` (both calls; NULL = none): dropout on the probabilities (reference swin_block.py:113,152), uint8 [Bg, H, N, N] keep flags,
+ * P <- P * keep * keep_scale with keep_scale = 1 / (1 - p) before the product with V; `probs` then holds the dropped map, as the
+ * reference returns it (:157).
+ * Backward of the above: recomputes P, writes dqkv (same layout as qkv) and dtable float32 [R, H] (zeroed here,
  * accumulated with LDS-privatised atomics; masked pairs contribute nothing, as in the reference). `out` is the
  * forward output (used for rowsum(P*dP) = dO.O). */
 int evp_window_attention_bwd(const void *qkv, const float *table, const int32_t *rel, const void *out,
                              const void *dout, void *dqkv, float *dtable, int Bg, int nG, int N, int H, int R,
-                             float scale, int dtype, void *stream);
+                             float scale, int dtype, const void *keep, float keep_scale, void *stream);
 /* The same windowed attention on the MFMA kernels of evp_attention_fused_* (bf16, d_h = 32, N <= 128), in three calls per block:
  *   evp_window_bias_build   addm[g,h,i,j] = rel[g,i,j] >= 0 ? table[rel[g,i,j],h] : -100 and its transpose addmT[g,h,j,i], float32
  *                           [nG, H, NP, NP] each with NP = evp_window_attention_fused_np(N) (32 / 64 / 96 / 128), zero outside N x N;

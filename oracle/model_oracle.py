@@ -315,8 +315,9 @@ def swin_plan(coords, window, shift, n_tokens):
     return dict(mode="grouping", gather=gather, scatter=scatter, mask=mask, rel=rel, gs=gs)
 
 
-def window_attention(sd, pre, x, mask, rel, heads):
-    """swin_block.py:124-162: scaled q, + table[rel] (zeroed where masked) + mask, softmax, AV, proj."""
+def window_attention(sd, pre, x, mask, rel, heads, attn_mask=None, attn_p=0.0):
+    """swin_block.py:124-162: scaled q, + table[rel] (zeroed where masked) + mask, softmax, attn_drop (:152, for a GIVEN keep mask
+    [Bg, heads, N, N]), AV, proj. Returns the dropped map, as the reference does (:157)."""
     Bg, N, C = x.shape
     dh = C // heads
     qkv = F.linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"]).reshape(Bg, N, 3, heads, dh)
@@ -328,6 +329,8 @@ def window_attention(sd, pre, x, mask, rel, heads):
     nG = bias.shape[0]
     att = att.view(Bg // nG, nG, heads, N, N) + bias.permute(0, 3, 1, 2).unsqueeze(0) + mask.view(1, nG, 1, N, N)
     p = torch.softmax(att.view(Bg, heads, N, N), dim=-1)
+    if attn_mask is not None and attn_p > 0:
+        p = p * attn_mask.view_as(p) / (1.0 - attn_p)
     o = (p @ v).transpose(1, 2).reshape(Bg, N, C)
     return F.linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"]), p
 
@@ -336,12 +339,13 @@ def swin_block(sd, pre, x, plan, heads, eps=1e-6, drops=None):
     """swin_block.py:260-273 wrapped in GroupingModule.group/merge (swin_block.py:454-466).
     `drops` (training mode; swin_block.py:157,257,270-271, Mlp.drop): as in vit_block -- the DropPath draws are per row of the GROUPED
     tensor (one per batch item x group: the reference applies drop_path to the (B * n_groups, gs, C) tensor), masks "proj" / "hidden"
-    / "fc2" in the grouped element order."""
+    / "fc2" in the grouped element order; "attn" + "attn_p": keep mask and rate of the dropout on the attention probabilities."""
     B, n, C = x.shape
     if plan["mode"] == "grouping":
         x = x[:, plan["gather"]].reshape(-1, plan["gs"], C)
     a, p = window_attention(sd, pre + "attn.", layer_norm(x, sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], eps),
-                            plan["mask"], plan["rel"], heads)
+                            plan["mask"], plan["rel"], heads, attn_mask=None if drops is None else drops.get("attn"),
+                            attn_p=0.0 if drops is None else (drops.get("attn_p") or 0.0))
     s1 = s2 = 1.0
     if drops is not None:
         if drops.get("u1") is not None:

@@ -587,11 +587,11 @@ def test_graph_replay_clears_its_atomic_accumulators():
         dw = ops._wgrad(dy, x, n_out, k_in, M)
         cs = ops.colsum(dy)
         att = torch.empty(Bg * N, H * 32, device="cuda")
-        call("evp_window_attention_fwd", ptr(qkv), ptr(table), ptr(rel), ptr(att), 0, Bg, nG, N, H, R, 32 ** -0.5, dt(qkv), stream_ptr())
+        call("evp_window_attention_fwd", ptr(qkv), ptr(table), ptr(rel), ptr(att), 0, Bg, nG, N, H, R, 32 ** -0.5, dt(qkv), None, 1.0, stream_ptr())
         dqkv = torch.empty_like(qkv)
         dtable = torch.empty(R, H, device="cuda")
         call("evp_window_attention_bwd", ptr(qkv), ptr(table), ptr(rel), ptr(att), ptr(dout), ptr(dqkv), ptr(dtable), Bg, nG, N, H, R,
-             32 ** -0.5, dt(qkv), stream_ptr())
+             32 ** -0.5, dt(qkv), None, 1.0, stream_ptr())
         return dw, cs, dtable
 
     want = [t.clone() for t in work()]

@@ -449,3 +449,65 @@ def test_attention_probability_dropout_on_the_vit_block(dtype):
     for k, v in blk.named_parameters():
         ref = sd["b." + k].grad
         assert torch.allclose(v.grad.cpu(), ref, atol=5e-5 * ref.abs().max().item() + 1e-6, rtol=3e-3), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_probability_dropout_on_the_swin_block(dtype):
+    """The last refused regulariser: attn_drop > 0 on the WINDOWED attention (swin_block.py:113,152). The LDS window kernels take uint8
+    keep flags [Bg, heads, N, N] and scale the kept probabilities by 1 / (1 - p) before the product with V; the backward recomputes P
+    and applies the same flags. f32, GIVEN flags, with masked pairs, DropPath and proj / Mlp dropout: output, returned (dropped) map,
+    input gradient and every parameter gradient (incl. the bias table) equal the oracle's. bf16: drawn flags at the asked-for rate, a
+    finite step (the call leaves the MFMA window kernels for the LDS ones), eval mode deterministic."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.model.sub_module.swin_block import SwinTransformerBlock
+    from eventpretrain_amd.testing import det_fill_module_
+    from oracle import model_oracle as mo
+    ops.set_compute_dtype(dtype)
+    Bn, nG, N, D, heads, pa = 3, 2, 24, 64, 2, 0.25
+    Bg = Bn * nG
+    blk = SwinTransformerBlock(dim=D, input_resolution=(14, 14), num_heads=heads, window_size=7, shift_size=0, mlp_ratio=4., drop=0.1,
+                               attn_drop=pa, drop_path=0.3)
+    det_fill_module_(blk)
+    blk = blk.cuda().train()
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(Bg, N, D, generator=g)
+    rel = torch.randint(0, 169, (nG, N, N), generator=g)
+    blocked = torch.rand(nG, N, N, generator=g) < 0.3
+    blocked[:, torch.arange(N), torch.arange(N)] = False
+    rel_dev = torch.where(blocked, torch.full_like(rel, -1), rel).to(torch.int32).cuda()
+    if dtype == torch.bfloat16:
+        xt = x.cuda().requires_grad_(True)
+        y, attn = blk(xt, rel_dev, return_attn=True)
+        y.sum().backward()
+        torch.cuda.synchronize()
+        allowed = (~blocked).unsqueeze(0).unsqueeze(2).expand(Bn, nG, heads, N, N).reshape(Bg, heads, N, N).cuda()
+        kept = (attn[allowed] != 0).float().mean().item()
+        assert abs(kept - (1 - pa)) < 0.03, kept
+        assert torch.isfinite(y).all() and torch.isfinite(xt.grad).all()
+        y2 = blk(xt.detach(), rel_dev)                                  # no map asked for: still the LDS kernels (attn_drop), fresh flags
+        assert not torch.equal(y2, y.detach())
+        blk.eval()
+        assert torch.equal(blk(xt.detach(), rel_dev), blk(xt.detach(), rel_dev))
+        return
+    u1, u2, masks = _given_drops(Bg, Bg * N, {"proj": D, "hidden": 4 * D, "fc2": D}, 0.1, g)
+    am = (torch.rand(Bg, heads, N, N, generator=g) >= pa).to(torch.uint8)
+    masks["attn"] = am.reshape(-1)
+    rd = ops.BlockDrop(u1.cuda(), u2.cuda(), keep_prob=0.7, drop=0.1, seed=1, masks={k: v.cuda() for k, v in masks.items()}, attn_drop=pa)
+    xt = x.clone().cuda().requires_grad_(True)
+    y, attn = blk(xt, rel_dev, return_attn=True, block_drop=rd)
+    w = torch.randn(Bg, N, D, generator=g)
+    (y * w.cuda()).sum().backward()
+    sd = {"b." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in blk.state_dict().items() if v.is_floating_point()}
+    xo = x.clone().requires_grad_(True)
+    plan = dict(mode="plain", mask=torch.where(blocked, torch.tensor(-100.0), torch.tensor(0.0)), rel=rel)
+    drops = dict(u1=u1, u2=u2, keep_prob=0.7, p=0.1, proj=masks["proj"].float(), hidden=masks["hidden"].float(), fc2=masks["fc2"].float(),
+                 attn=am.float(), attn_p=pa)
+    yo, po = mo.swin_block(sd, "b.", xo, plan, heads, eps=blk.norm1.eps, drops=drops)
+    (yo * w).sum().backward()
+    assert torch.allclose(y.detach().cpu(), yo.detach(), atol=3e-5, rtol=1e-4), (y.detach().cpu() - yo.detach()).abs().max().item()
+    assert torch.allclose(attn.float().cpu(), po.detach(), atol=1e-6, rtol=1e-5)
+    assert torch.allclose(xt.grad.cpu(), xo.grad, atol=3e-5 * xo.grad.abs().max().item() + 1e-6, rtol=2e-3)
+    for k, v in blk.named_parameters():
+        ref = sd["b." + k].grad
+        assert torch.allclose(v.grad.cpu(), ref, atol=5e-5 * ref.abs().max().item() + 1e-6, rtol=3e-3), k

@@ -55,12 +55,12 @@ def test_window_attention_fwd_bwd(dtype, Bg, nG, N, H):
     qd, td, rd = qkv.to(dtype).cuda(), table.cuda(), torch.from_numpy(rel).cuda()
     out = torch.empty(Bg, N, H * dh, dtype=dtype, device="cuda")
     probs = torch.empty(Bg, H, N, N, dtype=torch.float32, device="cuda")
-    call("evp_window_attention_fwd", ptr(qd), ptr(td), ptr(rd), ptr(out), ptr(probs), Bg, nG, N, H, R, dh ** -0.5, dt(qd), stream_ptr())
+    call("evp_window_attention_fwd", ptr(qd), ptr(td), ptr(rd), ptr(out), ptr(probs), Bg, nG, N, H, R, dh ** -0.5, dt(qd), None, 1.0, stream_ptr())
     dqkv = torch.empty_like(qd)
     dtab = torch.full((R, H), 7.0, dtype=torch.float32, device="cuda")       # must be overwritten, not accumulated
     dd = dout.to(dtype).cuda()
     call("evp_window_attention_bwd", ptr(qd), ptr(td), ptr(rd), ptr(out), ptr(dd), ptr(dqkv), ptr(dtab), Bg, nG, N, H, R,
-         dh ** -0.5, dt(qd), stream_ptr())
+         dh ** -0.5, dt(qd), None, 1.0, stream_ptr())
     torch.cuda.synchronize()
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     assert torch.allclose(probs.cpu().double(), p_ref.detach(), atol=tol * 0.1 if dtype == torch.float32 else 1e-5, rtol=1e-4)
@@ -151,9 +151,9 @@ def test_window_attention_rejects_bad_shapes():
     t = torch.zeros(16, device="cuda")
     i = torch.zeros(16, dtype=torch.int32, device="cuda")
     with pytest.raises(EvpError):
-        call("evp_window_attention_fwd", ptr(t), ptr(t), ptr(i), ptr(t), None, 5, 2, 49, 3, 169, 1.0, 0, stream_ptr())   # Bg % nG
+        call("evp_window_attention_fwd", ptr(t), ptr(t), ptr(i), ptr(t), None, 5, 2, 49, 3, 169, 1.0, 0, None, 1.0, stream_ptr())   # Bg % nG
     with pytest.raises(EvpError):
-        call("evp_window_attention_fwd", ptr(t), ptr(t), ptr(i), ptr(t), None, 4, 2, 129, 3, 169, 1.0, 0, stream_ptr())  # N > 128
+        call("evp_window_attention_fwd", ptr(t), ptr(t), ptr(i), ptr(t), None, 4, 2, 129, 3, 169, 1.0, 0, None, 1.0, stream_ptr())  # N > 128
     with pytest.raises(EvpError):
         call("evp_gather_rows_f32", ptr(t), ptr(i), ptr(t), 1, 4, 4, 3, 0, stream_ptr())                                  # C % 4
 
