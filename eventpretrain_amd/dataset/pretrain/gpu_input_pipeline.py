@@ -14,12 +14,14 @@ previous step) and every byte of event / voxel data stays on the device:
 Decision streams: "device" (default, round 4) = Philox4x32-10 keyed by (seed, step, sample), the per-clip COUNTS, window starts and
 crop boxes computed on the host with array arithmetic (~1 ms per batch) and the erase / add ROWS and noise drawn by a kernel
 (evp_events_draw_erase_add) -- nothing per clip on the host, no decision tables to upload; "counter" = the same idea with numpy's own
-Philox generator, everything drawn on the host (~13 ms per 64-clip batch: more than a training step); "legacy" = the reference's process-global numpy stream consumed by the reference's own functions in the order
-tests/golden/loader_chain.npz was made with (oracle/gen_golden.py gen_chain): get_random_index -> events_augment on the running
-stream as pr_n_imagenet_dataset.py:82-89, then the seeded evg_augment / frame_augment pair of pr_ef_imagenet_dataset.py:187-206
-(`seed = np.random.randint(1000)` drawn at that point). It reproduces THAT composition under np.random.seed(s) -- neither dataset's
-__getitem__ draws in exactly this order (n-imagenet never re-seeds, ef-imagenet draws frame index and seed first), so
-the fixture pins the chain's functions and data path, not a dataset's stream position.
+Philox generator, everything drawn on the host (~13 ms per 64-clip batch: more than a training step); "legacy" = the reference's process-global numpy stream, in one of two orders (`legacy_order`):
+  "n-imagenet"  PretrainNImageNetDataset.__getitem__'s own order (pr_n_imagenet_dataset.py:82-89): sample after sample on the RUNNING
+                stream -- window, erase / add, evg_augment WITHOUT a seed; under np.random.seed(s) it reproduces what a DataLoader
+                worker of the reference draws (tests/golden/loader_chain_nimagenet.npz, made by the reference's functions in that order);
+  "chain"       the composition tests/golden/loader_chain.npz was made with (oracle/gen_golden.py gen_chain): the same events half, then
+                the SEEDED evg_augment / frame_augment pair of pr_ef_imagenet_dataset.py:187-206 (`seed = np.random.randint(1000)`
+                drawn at that point) -- it pins the chain's functions incl. the frame target, not a dataset's stream position (the
+                EF-ImageNet dataset loads ready-made voxel grids and draws frame index and seed first).
 
 Two ways to run a batch: `run(...)` does the host packing inline (simple, what the parity test drives); `prepare(...)` /
 `run_prepared(...)` split it -- every table of the batch (window bounds, erase / add indices, noise rows, offsets, crop rows for
@@ -47,12 +49,15 @@ class PreparedBatch:
 
 
 class GpuInputPipeline:
-    def __init__(self, args, seed=0, decision_stream="device", ring=4):
+    def __init__(self, args, seed=0, decision_stream="device", ring=4, legacy_order="chain"):
         """args: the reference's namespace (fix_events_num, img_sensor_h / _w, input_size, num_bins, crop_min). `ring`: pinned slots
         for prepared batches (how many may exist at once before their run_prepared)."""
         self.RING = int(ring)
         if decision_stream not in ("device", "counter", "legacy"):
             raise ValueError("decision_stream must be 'device', 'counter' or 'legacy'")
+        if legacy_order not in ("chain", "n-imagenet"):
+            raise ValueError("legacy_order must be 'chain' or 'n-imagenet'")
+        self.legacy_order = legacy_order
         self.args, self.seed, self.stream = args, int(seed), decision_stream
         self.sensor = (int(args.img_sensor_h), int(args.img_sensor_w))
         self.S = int(args.input_size)
@@ -75,6 +80,8 @@ class GpuInputPipeline:
         if self.stream == "legacy":
             # one sample after the other, the reference's call order (pr_n_imagenet_dataset.py:83-89 on the running stream; the
             # evg / frame pair re-seeded with np.random.randint(1000) as pr_ef_imagenet_dataset.py:187-195)
+            if self.legacy_order == "n-imagenet" and frame_size is not None:
+                raise ValueError("legacy_order 'n-imagenet' has no frame target (that dataset pairs the grid with a CLIP image)")
             dec = []
             for i, n in enumerate(int(v) for v in sizes):
                 if sample_seeds is not None:
@@ -85,6 +92,9 @@ class GpuInputPipeline:
                 else:
                     windows[i] = (0, n)
                 dec.append(ea.draw_erase_add(int(windows[i, 1] - windows[i, 0])))
+                if self.legacy_order == "n-imagenet":           # evg_augment(args, grid, size): no seed, the stream runs on (:88-89)
+                    params[i] = va.draw_evg_params(np.random, self.S, self.S, self.crop_min)
+                    continue
                 seed2 = np.random.randint(1000)
                 np.random.seed(seed2)                           # evg_augment(..., seed=seed) re-seeds the global stream (view_augment.py:66-67)
                 params[i] = va.draw_evg_params(np.random, self.S, self.S, self.crop_min)

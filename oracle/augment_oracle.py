@@ -60,6 +60,29 @@ def evg_transform(view, params, out_hw, negate=True):
 
 
 # ---- event-level augmentation (dataset/augmentation/events_augment.py) ------------------------------------------------
+def draw_window(rs, n, fix):
+    """get_random_index(is_train=True) (events_augment.py:5-20): a clip longer than `fix` events gives up one randint for the start of
+    a `fix`-long window [start, start + fix); a shorter one is taken whole and draws nothing."""
+    if n > fix:
+        s0 = int(rs.randint(0, n - fix))
+        return s0, s0 + fix
+    return 0, n
+
+
+def n_imagenet_sample(rs, events, fix, sensor_hw, S, bins, crop_min=0.8):
+    """The events half of PretrainNImageNetDataset.__getitem__ (dataset/pretrain/pr_n_imagenet_dataset.py:82-89) on the RUNNING stream
+    `rs` -- window, erase / add, rescale, voxel grid, evg_augment without a seed -- in the dataset's own draw order.
+    -> (window, rows after augmentation, evg params, voxel grid float32 [bins, S, S])."""
+    from .voxel_oracle import voxel_grid
+    sh, sw = sensor_hw
+    s0, s1 = draw_window(rs, events.shape[0], fix)
+    e = events[s0:s1].copy()
+    e = erase_add_apply(e, draw_erase_add(rs, e.shape[0]), (sh, sw))
+    g = voxel_grid(events_reshape(e, sw, sh, S, S), bins, (S, S))
+    prm = draw_evg_params(rs, S, S, crop_min)
+    return (s0, s1), e.shape[0], prm, evg_transform(g, prm, (S, S), negate=bins in (5, 6))
+
+
 def draw_erase_add(rs, n):
     """The decisions of erase_and_add_events (events_augment.py:31-44) from a numpy RandomState `rs`, in the reference's
     call order: erase count, erased rows (sorted), add count, three per-row normal noise columns (x: sd 1.5, y: sd 1.5,

@@ -14,7 +14,7 @@ module object supplying `to_2tuple`, `trunc_normal_` and a `DropPath` that is
 never executed (all drop rates are 0 -> nn.Identity, vit_block.py:241) is put
 in sys.modules for the duration of this script.
 
-Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin,swincon,augment,evaug,ftcls,density,autocast,conbase,swinbase,convbase,chain]
+Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin,swincon,augment,evaug,ftcls,density,autocast,conbase,swinbase,convbase,chain,chainnim]
 """
 import argparse
 import json
@@ -596,6 +596,43 @@ def gen_chain():
     save("loader_chain", **out)
 
 
+def gen_chain_nimagenet():
+    """The events half of PretrainNImageNetDataset.__getitem__ in ITS OWN draw order (dataset/pretrain/pr_n_imagenet_dataset.py:82-89;
+    ADVICE r3: gen_chain above re-seeds before evg_augment as the EF-ImageNet dataset does, which the N-ImageNet one never does):
+        np.random.seed(s) ONCE, then per sample on the running stream
+        get_random_index -> events[start:end] -> events_augment -> events_reshape -> events_to_voxel_grid -> evg_augment(seed=None)
+    for several samples in a row, as one DataLoader worker draws them. (The image half of that __getitem__ -- CLIP preprocessing of a
+    JPEG -- draws nothing from numpy and is outside the path.) Synthetic sensor-shaped clips (640 x 480)."""
+    _ref()
+    from dataset.augmentation.events_augment import events_augment, events_reshape, get_random_index
+    from dataset.augmentation.view_augment import evg_augment
+    from dataset.dataset_utils.events_to_voxel_grid import events_to_voxel_grid
+    from eventpretrain_amd.testing import synthetic_events
+    torch.set_num_threads(1)
+    out = {}
+    runs = [("r1", 211, 15_000, [40_000, 9_000, 61_000]), ("r2", 212, 100_000, [150_000, 120_000])]
+    for tag, seed, fix, sizes in runs:
+        a = make_args(crop_min=0.8, input_size=224, fix_events_num=fix, img_sensor_w=640, img_sensor_h=480)
+        a.num_bins = 5
+        np.random.seed(seed)
+        for i, n_ev in enumerate(sizes):
+            ev = synthetic_events(8000 + seed * 10 + i, n_ev, width=640, height=480)
+            s0, s1 = get_random_index(a, ev, is_train=True)
+            e = ev[s0:s1].copy()
+            e = events_augment(a, e, size=(480, 640))
+            n_aug = e.shape[0]
+            e = events_reshape(e, 640, 480, 224, 224)
+            evg = events_to_voxel_grid(a, e, size=(224, 224))
+            evg, tflag = evg_augment(a, evg, size=(224, 224))
+            evg = evg.contiguous()
+            k = f"{tag}_{i}"
+            out[f"{k}_window"], out[f"{k}_n_aug"], out[f"{k}_tflip"] = np.array([s0, s1]), np.array(n_aug), np.array(int(tflag))
+            out[f"{k}_evg_checksums"], out[f"{k}_evg_sample"] = checksums(evg), evg.flatten()[::7].clone()
+        out[f"{tag}_seed"], out[f"{tag}_fix"], out[f"{tag}_sizes"] = np.array(seed), np.array(fix), np.array(sizes)
+    out["tags"] = np.array(json.dumps([r[0] for r in runs]))
+    save("loader_chain_nimagenet", **out)
+
+
 def gen_augment():
     """evg_augment of the reference itself (dataset/augmentation/view_augment.py:84-95) under np.random.seed(seed), for
     sensor-shaped and input-shaped grids; the fixture keeps inputs' generator seeds, outputs and time-flip flags."""
@@ -902,7 +939,7 @@ def gen_swin_base():
 GENS = dict(voxel=gen_voxel, pos=gen_pos, mask=gen_mask, tiny=lambda: gen_composed("tiny"), small=gen_small,
             base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall, swin=gen_swin, swincon=gen_swincon, augment=gen_augment, evaug=gen_evaug, ftcls=gen_ftcls,
             frameaug=gen_frameaug, density=gen_density, autocast=gen_autocast, conbase=gen_con_base, swinbase=gen_swin_base,
-            convbase=gen_convbase, chain=gen_chain)
+            convbase=gen_convbase, chain=gen_chain, chainnim=gen_chain_nimagenet)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -7,6 +7,7 @@ import socket
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -511,3 +512,38 @@ def test_attention_probability_dropout_on_the_swin_block(dtype):
     for k, v in blk.named_parameters():
         ref = sd["b." + k].grad
         assert torch.allclose(v.grad.cpu(), ref, atol=5e-5 * ref.abs().max().item() + 1e-6, rtol=3e-3), k
+
+
+@pytest.mark.gpu
+def test_gpu_input_pipeline_in_the_n_imagenet_draw_order():
+    """decision_stream="legacy", legacy_order="n-imagenet" draws what PretrainNImageNetDataset.__getitem__ draws
+    (pr_n_imagenet_dataset.py:82-89) -- one np.random.seed, then sample after sample on the running stream, evg_augment unseeded -- and
+    the batched device chain reproduces the reference's per-sample outputs for the whole run in ONE call
+    (tests/golden/loader_chain_nimagenet.npz: the reference's own functions in that order)."""
+    from conftest import load_golden
+    from helpers import assert_checksums, jl
+    from eventpretrain_amd.dataset.pretrain.gpu_input_pipeline import GpuInputPipeline
+    from eventpretrain_amd.testing import make_args, synthetic_events
+    d = load_golden("loader_chain_nimagenet")
+    for tag in jl(d["tags"]):
+        seed, fix = int(d[f"{tag}_seed"]), int(d[f"{tag}_fix"])
+        sizes = [int(v) for v in d[f"{tag}_sizes"]]
+        a = make_args(crop_min=0.8, input_size=224, fix_events_num=fix, img_sensor_w=640, img_sensor_h=480, device="cuda")
+        clips = [synthetic_events(8000 + seed * 10 + i, n, width=640, height=480) for i, n in enumerate(sizes)]
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        ev = torch.from_numpy(np.concatenate(clips, 0)).cuda()
+        pipe = GpuInputPipeline(a, decision_stream="legacy", legacy_order="n-imagenet")
+        np.random.seed(seed)
+        windows, dec, params = pipe.draw(off[1:] - off[:-1], step=0)
+        vox, _ = pipe.run(ev, off, windows, dec, params)
+        torch.cuda.synchronize()
+        for i in range(len(sizes)):
+            k = f"{tag}_{i}"
+            assert windows[i].tolist() == d[f"{k}_window"].tolist(), k
+            n_aug = int(windows[i, 1] - windows[i, 0]) - (0 if dec[i] is None else dec[i][0].size - dec[i][1].size)
+            assert n_aug == int(d[f"{k}_n_aug"]) and int(params[i, 5]) == int(d[f"{k}_tflip"]), k
+            got = vox[i].cpu()
+            assert (got.flatten()[::7] - torch.from_numpy(d[f"{k}_evg_sample"])).abs().max().item() <= 1e-5, k
+            assert_checksums(got, d[f"{k}_evg_checksums"], 1e-5, k)
+    with pytest.raises(ValueError):
+        pipe.draw(off[1:] - off[:-1], step=0, frame_size=(480, 640))

@@ -377,6 +377,27 @@ def test_events_augment_matches_reference():
         assert np.array_equal(g, d[tag + "_voxel"]), tag
 
 
+def test_loader_chain_in_the_n_imagenet_draw_order():
+    """the events half of PretrainNImageNetDataset.__getitem__ in the dataset's OWN order (one seed, then sample after sample
+    on the running stream; evg_augment never re-seeds) -- the oracle's composition against the reference's functions run in that order
+    (tests/golden/loader_chain_nimagenet.npz, oracle/gen_golden.py gen_chain_nimagenet). One draw too many or too few anywhere in a
+    sample would shift every later sample's window."""
+    from oracle import augment_oracle as ao
+    from eventpretrain_amd.testing import synthetic_events
+    d = load_golden("loader_chain_nimagenet")
+    for tag in jl(d["tags"]):
+        seed, fix = int(d[f"{tag}_seed"]), int(d[f"{tag}_fix"])
+        rs = np.random.RandomState(seed)
+        for i, n_ev in enumerate(int(v) for v in d[f"{tag}_sizes"]):
+            ev = synthetic_events(8000 + seed * 10 + i, n_ev, width=640, height=480)
+            win, n_aug, prm, g = ao.n_imagenet_sample(rs, ev, fix, (480, 640), 224, 5)
+            k = f"{tag}_{i}"
+            assert list(win) == d[f"{k}_window"].tolist(), k
+            assert n_aug == int(d[f"{k}_n_aug"]) and prm[5] == int(d[f"{k}_tflip"]), k
+            assert np.array_equal(g.reshape(-1)[::7], d[f"{k}_evg_sample"]), k
+            assert_checksums(torch.from_numpy(g), d[f"{k}_evg_checksums"], 1e-12, k)
+
+
 def test_label_smoothing_formula():
     """The restated timm LabelSmoothingCrossEntropy against torch's built-in label_smoothing (same published formula)."""
     g = torch.Generator().manual_seed(5)
