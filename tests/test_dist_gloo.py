@@ -102,18 +102,14 @@ def _queue_policies(rank):
                 assert torch.equal(m.queue, q0), "buffers not taken from rank 0"
             m._dequeue_and_enqueue(keys)
             out[pol] = (int(m.queue_ptr), m.queue[0, 0, :].tolist())
-        # a per-step launch-geometry hook (Swin window plan) together with a reducer is refused: one rank falling back to an
-        # eager step while the others replay would leave the all-reduces unmatched
+        # a per-step launch-geometry hook (Swin window plan) together with a reducer: the replay-or-fall-back decision is collective
+        # (engine.GraphedStep._vote, a host-side MIN on a gloo group) -- one rank whose plan does not fit takes every rank to the eager
+        # data-parallel step, so the all-reduces stay matched (the CUDA form of the whole control flow: tests/dp_cuda_worker.py "swin")
+        from types import SimpleNamespace
         from eventpretrain_amd.engine import GraphedStep
-        from eventpretrain_amd.parallel import BucketedGradReducer
-        lin = torch.nn.Linear(4, 4)
-        red = BucketedGradReducer(list(lin.parameters()))
-        try:
-            GraphedStep(lin, None, lambda m_, x_, n_: (m_(x_).sum(),), [torch.zeros(2, 4)], noise_shape=(2, 4), reducer=red, use_graph=False,
-                        step_prepare=lambda noise: True)
-            out["prepare_with_reducer_refused"] = False
-        except ValueError:
-            out["prepare_with_reducer_refused"] = True
+        stub = SimpleNamespace(_vote_group=dist.group.WORLD)
+        out["vote"] = [GraphedStep._vote(stub, True), GraphedStep._vote(stub, rank != 1), GraphedStep._vote(stub, rank == 1),
+                       GraphedStep._vote(SimpleNamespace(_vote_group=None), rank == 1)]
     finally:
         ops.enqueue_keys_dev = real
     return {"queue_" + k: v for k, v in out.items()}
@@ -268,7 +264,7 @@ def test_world_size_2_gloo():
         ptr_, row = res[r]["queue_rank0_broadcast"]
         assert ptr_ == 2 and row[:2] == [1.0 + r, 2.0 + r]          # own keys on rank 0's (broadcast) queue
     assert res[0]["queue_all_gather"] == res[1]["queue_all_gather"]
-    assert res[0]["queue_prepare_with_reducer_refused"] and res[1]["queue_prepare_with_reducer_refused"]
+    assert res[0]["queue_vote"] == [True, False, False, False] and res[1]["queue_vote"] == [True, False, False, True]
     # overlapped plan without streams: chunks in order, flats summed over ranks ((1+2)*(i+1)), small gradients through the bucket
     for r in (0, 1):
         assert res[r]["plan_log"] == [0, 1]
@@ -281,3 +277,76 @@ def test_world_size_2_gloo():
     assert res[0]["epoch_w"] == pytest.approx(res[1]["epoch_w"], abs=0)
     assert res[0]["epoch_w"] == pytest.approx(res[0]["epoch_ref_w"], rel=1e-5, abs=1e-6)
     assert res[0]["epoch_norms"] == pytest.approx(res[0]["epoch_ref_norms"], rel=1e-5)
+
+
+def _worker_n(rank, world, port, resq):
+    """The rank-count-dependent parts at world sizes the scaling run uses (4, 8): reducer sums, mean scale, key gather order and
+    rank-offset labels, meter reduction, the collective vote."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        from types import SimpleNamespace
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from eventpretrain_amd.engine import GraphedStep
+        from eventpretrain_amd.model.pretrain.pr_hub_model import concat_all_gather
+        from eventpretrain_amd.parallel import BucketedGradReducer, ensure_mean_grad_scale
+        from eventpretrain_amd.utils import misc
+        from oracle import model_oracle as mo
+        out = {}
+        torch.manual_seed(rank)                                     # ranks start apart: the reducer's constructor broadcasts rank 0's values
+        params = [torch.nn.Parameter(torch.randn(s)) for s in [(129, 33), (7,), (2048,), (5, 5)]]
+        red = BucketedGradReducer(params)
+        out["p0"] = [p.detach().flatten()[0].item() for p in params]
+        sum(((rank + 1) * (i + 1)) * p.sum() for i, p in enumerate(params)).backward()
+        red.finish()
+        out["grads"] = [p.grad.flatten()[-1].item() for p in params]
+        opt = SimpleNamespace(grad_scale=1.0)
+        out["scale"] = ensure_mean_grad_scale(opt, red)
+        try:
+            ensure_mean_grad_scale(SimpleNamespace(grad_scale=0.5 if world != 2 else 0.25), red)
+            out["bad_scale_refused"] = False
+        except ValueError:
+            out["bad_scale_refused"] = True
+        out["mean"] = misc.all_reduce_mean(float(rank))
+        m = misc.SmoothedValue()
+        m.update(float(rank), n=rank + 1)
+        m.synchronize_between_processes()
+        out["meter"] = (m.count, m.total)
+        g = torch.Generator().manual_seed(5)
+        per = 3
+        qa, ka = torch.randn(world * per, 2, 8, generator=g), torch.randn(world * per, 2, 8, generator=g)
+        q, k = qa[per * rank:per * (rank + 1)], ka[per * rank:per * (rank + 1)]
+        k_all = concat_all_gather(k)
+        out["gather_ok"] = bool(torch.equal(k_all, ka))
+        out["nce"] = mo.info_nce_inbatch(q, k_all, 0.07, rank=rank).item()
+        out["nce_full"] = mo.info_nce_inbatch(qa, ka, 0.07, rank=0).item()
+        stub = SimpleNamespace(_vote_group=dist.group.WORLD)
+        out["vote"] = [GraphedStep._vote(stub, True), GraphedStep._vote(stub, rank != world - 1)]
+        resq.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_world_size_n_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_n, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tri = world * (world + 1) // 2
+    for r in range(world):
+        o = res[r]
+        assert o["p0"] == res[0]["p0"]                                        # rank 0's initial values everywhere
+        assert o["grads"] == pytest.approx([float(tri * (i + 1)) for i in range(4)])      # SUM over ranks; the mean rides on grad_scale
+        assert o["scale"] == pytest.approx(1.0 / world) and o["bad_scale_refused"]
+        assert o["mean"] == pytest.approx((world - 1) / 2)
+        assert o["meter"] == (tri, pytest.approx(sum(float(k) * (k + 1) for k in range(world))))
+        assert o["gather_ok"] and o["vote"] == [True, False]
+    assert sum(res[r]["nce"] for r in range(world)) / world == pytest.approx(res[0]["nce_full"], rel=1e-6)
