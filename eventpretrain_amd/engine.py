@@ -14,9 +14,13 @@ replay. Collectives stay outside the graphs. If capture fails the executor says 
 Replaces nothing in the reference (its loop is eager PyTorch, trainer/pretrain/pr_trainer.py:20-76); it is the
 MI355X-side answer to "launch-bound inner loop -> HIP graph". `trainer.pretrain.pr_trainer.pr_rec_one_epoch(...,
 step_executor=...)` uses it when given one."""
+import os
+
 import torch
 
 from . import ops
+
+_DP_BACKWARD_CUT_DEFAULT = "1"
 
 
 class BackwardCut:
@@ -116,7 +120,7 @@ class _GraphSeq:
 
 class GraphedStep:
     def __init__(self, model, optimizer, forward, static_inputs, noise_shape=None, generator=None, reducer=None,
-                 use_graph=True, warmup=2, wgrad_chunks=4, step_prepare=None, host_generator=None):
+                 use_graph=True, warmup=2, wgrad_chunks=4, step_prepare=None, host_generator=None, backward_cut=None):
         """forward(model, *static_inputs, noise) -> tuple whose first item is the loss. `static_inputs`: device tensors
         with the batch's shapes (overwritten by `step(...)` when new data is passed). `noise_shape`: (B, L) of the
         masking noise, or None when the model draws none (density masking, contrastive stage).
@@ -125,6 +129,9 @@ class GraphedStep:
         hook before anything is launched and copied to the static device buffer; False = the captured graph cannot serve
         this step, which then runs eagerly with the same noise."""
         self.model, self.opt, self.forward, self.reducer = model, optimizer, forward, reducer
+        # data-parallel form only: cut the backward at the encoder / decoder boundary (two graphs, the decoder's gradients all-reduced
+        # under the encoder's backward). None = the environment's EVP_DP_BACKWARD_CUT (see _capture for the default and why).
+        self.backward_cut = (os.environ.get("EVP_DP_BACKWARD_CUT", _DP_BACKWARD_CUT_DEFAULT) != "0") if backward_cut is None else bool(backward_cut)
         if reducer is not None:
             # the reducer SUMs over ranks: the mean must be in force before anything is captured or stepped (ADVICE r3 -- the epoch
             # loops hand their executor the scaler's reducer without ever calling the scaler)
@@ -274,7 +281,7 @@ class GraphedStep:
             # the loss -- and captured as two graphs, so that what is complete after the first -- the decoder's weight gradients, the
             # contrastive keys -- crosses xGMI on side streams while the second (the encoder's backward, ~3 ms) replays: the window
             # that hides the collective grows from the step's last ~2 ms to ~5 ms (unmeasured on more than one GPU)
-            cut = BackwardCut() if (self.multi and hasattr(self.model, "set_backward_cut")) else None
+            cut = BackwardCut() if (self.multi and self.backward_cut and hasattr(self.model, "set_backward_cut")) else None
             early_steps = ()
             import gc
             try:
