@@ -299,7 +299,11 @@ __global__ __launch_bounds__(1024) void draw_erase_add_kernel(const int64_t *win
   const int ke = (int)(erase_offsets[c + 1] - erase_offsets[c]), ka = (int)(add_offsets[c + 1] - add_offsets[c]);
   const uint64_t sample = (uint64_t)(first_sample + c);
   if (n <= 0) return;
-  if (ke > 0) draw_distinct<true>(keys, a, b, scratch, np2, n, ke, seed, step, sample, 1u, erase_idx + erase_offsets[c]);
+  // two workgroups per clip (blockIdx.y): the erase draw and the add draw + noise are independent streams of the same clip
+  if (blockIdx.y == 0) {
+    if (ke > 0) draw_distinct<true>(keys, a, b, scratch, np2, n, ke, seed, step, sample, 1u, erase_idx + erase_offsets[c]);
+    return;
+  }
   if (ka > 0) {
     draw_distinct<false>(keys, a, b, scratch, np2, n, ka, seed, step, sample, 2u, add_idx + add_offsets[c]);
     double *nz = add_noise + add_offsets[c] * 3;
@@ -380,7 +384,7 @@ extern "C" int evp_events_draw_erase_add(const int64_t *win_begin, const int64_t
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(draw_erase_add_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_events_draw_erase_add: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(draw_erase_add_kernel, dim3(n_clips), dim3(1024), smem, (hipStream_t)stream, win_begin, win_end, erase_offsets, add_offsets, seed, step,
+  hipLaunchKernelGGL(draw_erase_add_kernel, dim3(n_clips, 2), dim3(1024), smem, (hipStream_t)stream, win_begin, win_end, erase_offsets, add_offsets, seed, step,
                      first_sample, step_first_dev, np2, erase_idx, add_idx, add_noise);
   EVP_CHECK_LAUNCH("evp_events_draw_erase_add");
   return EVP_OK;

@@ -358,6 +358,7 @@ class CapturedChain:
         self.ws = torch.zeros(n_clips * self.kmax, 4, dtype=torch.float64, device=dev)
         self.ev = torch.zeros(n_clips * (fix + self.kmax), 4, dtype=torch.float64, device=dev)
         self._busy = None
+        self._aux = torch.cuda.Stream()
         # warm-up (allocator, kernel attributes) on a side stream, then capture
         import numpy as _np
         sizes = _np.full(n_clips, min(fix, int(events.shape[0]) // max(n_clips, 1)), dtype=_np.int64)
@@ -391,6 +392,15 @@ class CapturedChain:
         pw = (nc * 6 + 1) // 2
         o4 = 5 * (nc + 1)
         H, W = pipe.sensor
+        tgt = None
+        if self.frames is not None:
+            # the frame targets need only the uploaded table: a branch of their own beside the event chain (a parallel branch of the
+            # captured graph; 40 us of the chain's 420 us of kernels)
+            cur = torch.cuda.current_stream()
+            self._aux.wait_stream(cur)
+            with torch.cuda.stream(self._aux):
+                fp = d[o4 + pw:o4 + 2 * pw].view(torch.int32)[:nc * 6].view(nc, 6)
+                tgt = va.frame_augment_batch(self.frames, fp, (pipe.S, pipe.S))
         call("evp_events_draw_erase_add", ptr(tabs[0]), ptr(tabs[1]), nc, ptr(tabs[2]), ptr(tabs[3]), pipe.seed & (2 ** 64 - 1), 0, 0,
              ptr(d[self.n_tab:]), self.kmax, ptr(self.er), ptr(self.ai), ptr(self.nz), stream_ptr())
         call("evp_events_erase_add_win_f64", ptr(self.events), ptr(tabs[0]), ptr(tabs[1]), nc, ptr(self.er), ptr(tabs[2]), ptr(self.ai),
@@ -398,10 +408,8 @@ class CapturedChain:
         vox = voxel_grid_batch(self.ev, tabs[4], pipe.bins, (pipe.S, pipe.S), assume_sorted=True, scale=(pipe.S / W, pipe.S / H))
         p_dev = d[o4:o4 + pw].view(torch.int32)[:nc * 6].view(nc, 6)
         out = va.evg_augment_batch(vox, p_dev, (pipe.S, pipe.S))
-        tgt = None
         if self.frames is not None:
-            fp = d[o4 + pw:o4 + 2 * pw].view(torch.int32)[:nc * 6].view(nc, 6)
-            tgt = va.frame_augment_batch(self.frames, fp, (pipe.S, pipe.S))
+            torch.cuda.current_stream().wait_stream(self._aux)
         return out, tgt
 
     def run(self, pb):
