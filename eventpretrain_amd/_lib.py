@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EVP_LIB") or os.path.join(_HERE, "libevtpretrain.so")     # EVP_LIB: another build of the same ABI (A/B runs)
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 4            # include/evtpretrain.h EVP_ABI_VERSION: checked when the library is loaded (EVP_LIB overrides included)
+ABI_VERSION = 5            # include/evtpretrain.h EVP_ABI_VERSION: checked when the library is loaded (EVP_LIB overrides included)
 EVP_F32, EVP_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_DGELU, ACT_RELU, ACT_DRELU = 0, 1, 2, 3, 4
 
@@ -34,6 +34,7 @@ class GemmDesc(C.Structure):
 SIGNATURES = {
     "evp_voxel_scatter_f32": [_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "evp_voxel_scatter_scaled_f32": [_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp],
+    "evp_events_plan_batch": [_vp, _i, _i64, C.c_uint64, _vp, _i, _vp, _i, _i, _i, _i, C.c_double, _vp, _vp, _vp, _vp],
     "evp_events_sorted_check": [_vp, _vp, _i, _i, _vp, _vp],
     "evp_events_erase_add_f64": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp],
     "evp_events_draw_erase_add": [_vp, _vp, _i, _vp, _vp, C.c_uint64, C.c_uint64, _i64, _vp, _i, _vp, _vp, _vp, _vp],

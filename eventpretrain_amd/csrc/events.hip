@@ -320,6 +320,92 @@ __global__ __launch_bounds__(1024) void draw_erase_add_kernel(const int64_t *win
   }
 }
 
+
+// ---- the batch PLAN on the device: what GpuInputPipeline.prepare() computes on the host with numpy (window starts, the two counts per
+// clip and their prefix sums, the crop rows of the grid and of the frame target), one thread per clip from the same counter stream
+// (dataset/augmentation/events_augment.py philox_words / draw_erase_add_counts, view_augment.py draw_evg_params_batch -- the numpy forms are
+// the specification; this kernel repeats their float64 operations in their order, contraction off). With it a captured loader chain
+// needs nothing from the host per batch: `state` = (step, first sample) lives on the device and is advanced here.
+struct CropGeom { double area, a0, da; int W, H; };      // a0 = W / H * 3/4, da = W / H * 4/3 - a0 (computed by the caller in double)
+
+__device__ void plan_crop_row(const double *U, const CropGeom g, double crop_min, double one_minus, int32_t *row) {
+#pragma clang fp contract(off)
+  long cw1 = g.W, ch1 = g.H;
+  double ux = 0.0, uy = 0.0;
+  bool any = false;
+  for (int t = 0; t < 10 && !any; ++t) {
+    const double *T = U + t * 5;
+    const double target = (crop_min + T[0] * one_minus) * g.area;
+    const double aspect = g.a0 + T[1] * g.da;
+    long cw = (long)rint(sqrt(target * aspect)), ch = (long)rint(sqrt(target / aspect));
+    if ((long)(T[2] * 10.0) < 5) { const long tmp = cw; cw = ch; ch = tmp; }
+    if (cw < g.W && ch < g.H) { any = true; cw1 = cw; ch1 = ch; ux = T[3]; uy = T[4]; }
+  }
+  long x0 = 0, y0 = 0;
+  if (any) {
+    const long fx = g.W - cw1, fy = g.H - ch1;
+    x0 = (long)(ux * (double)(fx > 1 ? fx : 1));
+    y0 = (long)(uy * (double)(fy > 1 ? fy : 1));
+    const long mx = fx - 1 > 0 ? fx - 1 : 0, my = fy - 1 > 0 ? fy - 1 : 0;
+    x0 = x0 < mx ? x0 : mx;
+    y0 = y0 < my ? y0 : my;
+  }
+  row[0] = (int32_t)x0; row[1] = (int32_t)y0; row[2] = (int32_t)cw1; row[3] = (int32_t)ch1;
+  row[4] = U[50] < 0.5 ? 1 : 0;
+  row[5] = U[51] < 0.5 ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void plan_batch_kernel(const int64_t *clip_off, int nc, int64_t fix, uint64_t seed, int64_t *state, int advance,
+                                                         int64_t *cur, CropGeom grid, CropGeom frame, double crop_min, double one_minus,
+                                                         int64_t *tabs, int32_t *params, int32_t *fparams) {
+#pragma clang fp contract(off)
+  extern __shared__ int64_t plan_sm[];                 // [3][nc]: erase count, add count, rows out
+  const uint64_t step = (uint64_t)state[0];
+  const int64_t first = state[1];
+  for (int c = threadIdx.x; c < nc; c += blockDim.x) {
+    const uint64_t sample = (uint64_t)(first + c);
+    uint32_t w[4] = {0u, 0u, (uint32_t)sample, (uint32_t)(sample >> 32)};
+    ev_philox(w, (uint32_t)seed ^ (uint32_t)(step * 0x9E3779B97F4A7C15ull >> 32), (uint32_t)(seed >> 32) ^ (uint32_t)step);
+    const int64_t n = clip_off[c + 1] - clip_off[c];
+    const int64_t room = n > fix ? n - fix : 0;
+    const int64_t s0 = n > fix ? (int64_t)(((uint64_t)w[0] * (uint64_t)room) >> 32) : 0;
+    const int64_t s1 = n > fix ? s0 + fix : n;
+    const int64_t nw = s1 - s0;
+    const int64_t lo = (int64_t)(0.001 * (double)nw), hi = (int64_t)(0.01 * (double)nw);
+    const uint64_t span = hi > lo ? (uint64_t)(hi - lo) : 0ull;
+    int64_t e = lo + (int64_t)(((uint64_t)w[1] * span) >> 32), a = lo + (int64_t)(((uint64_t)w[2] * span) >> 32);
+    if (hi <= 0) e = a = 0;
+    tabs[c] = clip_off[c] + s0;
+    tabs[(nc + 1) + c] = clip_off[c] + s1;
+    plan_sm[c] = e; plan_sm[nc + c] = a; plan_sm[2 * nc + c] = nw - e + a;
+    double U[52];
+    for (int b = 0; b < 13; ++b) {
+      uint32_t q[4] = {(uint32_t)b, 4u, (uint32_t)sample, (uint32_t)(sample >> 32)};
+      ev_philox(q, (uint32_t)seed ^ (uint32_t)(step * 0x9E3779B97F4A7C15ull >> 32), (uint32_t)(seed >> 32) ^ (uint32_t)step);
+      for (int i = 0; i < 4; ++i) U[b * 4 + i] = (double)q[i] * 2.3283064365386963e-10;
+    }
+    plan_crop_row(U, grid, crop_min, one_minus, params + c * 6);
+    if (fparams) {
+      plan_crop_row(U, frame, crop_min, one_minus, fparams + c * 6);
+      fparams[c * 6 + 5] = params[c * 6 + 5];         // the time-flip flag is evg_augment's (pr_ef_imagenet_dataset.py:194-206)
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {                              // three prefix sums over the clips (a few dozen terms each)
+    int64_t *row = tabs + (2 + threadIdx.x) * (nc + 1);
+    const int64_t *v = plan_sm + threadIdx.x * nc;
+    int64_t run = 0;
+    row[0] = 0;
+    for (int c = 0; c < nc; ++c) { run += v[c]; row[c + 1] = run; }
+  }
+  if (threadIdx.x == 3) {
+    tabs[nc] = 0;
+    tabs[(nc + 1) + nc] = 0;
+    cur[0] = (int64_t)step;                           // what the draw kernel of THIS batch reads
+    cur[1] = first;
+    if (advance) state[0] = (int64_t)(step + 1);
+  }
+}
 }  // namespace
 
 static int erase_add_launch(const double *events, const int64_t *clip_begin, const int64_t *clip_end, int n_clips, const int64_t *erase_idx,
@@ -387,5 +473,28 @@ extern "C" int evp_events_draw_erase_add(const int64_t *win_begin, const int64_t
   hipLaunchKernelGGL(draw_erase_add_kernel, dim3(n_clips, 2), dim3(1024), smem, (hipStream_t)stream, win_begin, win_end, erase_offsets, add_offsets, seed, step,
                      first_sample, step_first_dev, np2, erase_idx, add_idx, add_noise);
   EVP_CHECK_LAUNCH("evp_events_draw_erase_add");
+  return EVP_OK;
+}
+
+extern "C" int evp_events_plan_batch(const int64_t *clip_offsets, int n_clips, int64_t fix_events_num, uint64_t seed, int64_t *state, int advance,
+                                     int64_t *step_first_out, int grid_h, int grid_w, int frame_h, int frame_w, double crop_min, int64_t *tabs,
+                                     int32_t *params, int32_t *frame_params, void *stream) {
+  EVP_CHECK_ARG(clip_offsets && state && step_first_out && tabs && params, EVP_EINVAL, "evp_events_plan_batch: null pointer");
+  EVP_CHECK_ARG(n_clips > 0 && n_clips <= 4096 && fix_events_num > 0 && grid_h > 0 && grid_w > 0, EVP_ESHAPE, "evp_events_plan_batch: bad shape");
+  EVP_CHECK_ARG(!frame_params || (frame_h > 0 && frame_w > 0), EVP_ESHAPE, "evp_events_plan_batch: frame size required with frame_params");
+  EVP_CHECK_ARG(crop_min > 0.0 && crop_min <= 1.0, EVP_EINVAL, "evp_events_plan_batch: crop_min must lie in (0, 1]");
+  auto geom = [](int H, int W) {
+    CropGeom g;
+    g.W = W; g.H = H;
+    g.area = (double)((int64_t)W * H);
+    const double wh = (double)W / (double)H;          // as the numpy form: W / H * ratio[0] + u * (W / H * ratio[1] - W / H * ratio[0])
+    g.a0 = wh * (3.0 / 4.0);
+    g.da = wh * (4.0 / 3.0) - wh * (3.0 / 4.0);
+    return g;
+  };
+  const CropGeom gg = geom(grid_h, grid_w), gf = frame_params ? geom(frame_h, frame_w) : gg;
+  hipLaunchKernelGGL(plan_batch_kernel, dim3(1), dim3(256), (size_t)3 * n_clips * sizeof(int64_t), (hipStream_t)stream, clip_offsets, n_clips,
+                     fix_events_num, seed, state, advance, step_first_out, gg, gf, crop_min, 1.0 - crop_min, tabs, params, frame_params);
+  EVP_CHECK_LAUNCH("evp_events_plan_batch");
   return EVP_OK;
 }

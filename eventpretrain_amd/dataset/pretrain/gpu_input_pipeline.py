@@ -304,15 +304,19 @@ class GpuInputPipeline:
             out.append(None if (e.stop == e.start and a.stop == a.start) else (er[e].copy(), ai[a].copy(), nz[a].copy()))
         return out
 
-    def capture(self, events, n_clips, frames=None):
+    def capture(self, events, n_clips, frames=None, clip_offsets=None):
         """The device half as ONE HIP graph (device decision stream): `events` is the buffer every batch's raw rows will sit in (fixed
         address: the loader uploads into it), `frames` likewise. Launched from Python the eight kernels of a batch cost more host time
         (~0.9 ms with the worker thread competing for the interpreter) than the GPU needs for them (~0.42 ms); replayed they cost one
         call. Every buffer gets its upper bound (windows of at most fix_events_num rows, counts below int(0.01 fix_events_num)); what
         varies per batch -- offsets, crop rows, (step, first sample) -- travels through one pinned table the graph's upload node
         re-reads. Returns a CapturedChain; its run(prepared) hands out the two STATIC output tensors (consume or clone them before the
-        next run)."""
-        return CapturedChain(self, events, int(n_clips), frames)
+        next run).
+        With `clip_offsets` (int64 [n_clips + 1], host or device) the chain is SELF-DRIVEN: the batch's plan (windows, counts, offsets,
+        crop rows) is computed by a kernel inside the graph (evp_events_plan_batch) from the clip offsets and a device-resident (step,
+        first sample) pair that the graph itself advances -- `run_next()` is one replay, with nothing prepared, packed or uploaded on the
+        host; `set_clip_offsets` / `set_state` change the inputs between replays."""
+        return CapturedChain(self, events, int(n_clips), frames, clip_offsets)
 
     def batch(self, events, clip_offsets, step, frames=None, first_sample=0, sample_seeds=None):
         """The whole chain for one batch: decisions on the host, data on the device."""
@@ -337,9 +341,10 @@ class GpuInputPipeline:
 
 
 class CapturedChain:
-    """GpuInputPipeline.capture: the chain's device half captured once, replayed per batch."""
+    """GpuInputPipeline.capture: the chain's device half captured once, replayed per batch -- with the batch's tables prepared on the host
+    (run(prepared)) or, self-driven, planned by a kernel of the graph (run_next())."""
 
-    def __init__(self, pipe, events, n_clips, frames):
+    def __init__(self, pipe, events, n_clips, frames, clip_offsets=None):
         if pipe.stream != "device":
             raise ValueError("CapturedChain needs decision_stream='device' (host-drawn decision lists change size per batch)")
         _lib.require_device()
@@ -350,7 +355,7 @@ class CapturedChain:
         pw = (n_clips * 6 + 1) // 2
         # table layout of a device-stream PreparedBatch: five offset rows | crop rows | frame crop rows; two more words: step, first sample
         self.n_tab = 5 * (n_clips + 1) + pw + (pw if frames is not None else 0)
-        self.h_tab = torch.zeros(self.n_tab + 2, dtype=torch.int64).pin_memory()      # what the graph's upload node reads
+        self.h_tab = torch.zeros(self.n_tab + 2, dtype=torch.int64).pin_memory()      # what the graph's upload node reads (prepared form)
         self.d_tab = torch.zeros(self.n_tab + 2, dtype=torch.int64, device=dev)
         self.er = torch.zeros(n_clips * self.kmax, dtype=torch.int64, device=dev)
         self.ai = torch.zeros(n_clips * self.kmax, dtype=torch.int64, device=dev)
@@ -358,22 +363,43 @@ class CapturedChain:
         self.ws = torch.zeros(n_clips * self.kmax, 4, dtype=torch.float64, device=dev)
         self.ev = torch.zeros(n_clips * (fix + self.kmax), 4, dtype=torch.float64, device=dev)
         self._busy = None
-        self._aux = torch.cuda.Stream()
+        self.self_driven = clip_offsets is not None
+        if self.self_driven:
+            self.d_off = torch.zeros(n_clips + 1, dtype=torch.int64, device=dev)
+            self.state = torch.zeros(2, dtype=torch.int64, device=dev)          # (step, first sample): advanced by the graph itself
+            self.set_clip_offsets(clip_offsets)
         # warm-up (allocator, kernel attributes) on a side stream, then capture
-        import numpy as _np
-        sizes = _np.full(n_clips, min(fix, int(events.shape[0]) // max(n_clips, 1)), dtype=_np.int64)
-        off = _np.concatenate([[0], _np.cumsum(sizes)]).astype(_np.int64)
-        pb = pipe.prepare(off, step=0, frame_size=None if frames is None else frames.shape[-2:])
+        sizes = np.full(n_clips, min(fix, int(events.shape[0]) // max(n_clips, 1)), dtype=np.int64)
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self._stage(pb)
+            if not self.self_driven:
+                self._stage(pipe.prepare(off, step=0, frame_size=None if frames is None else frames.shape[-2:]))
             self._launches()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=side):
             self.out, self.tgt = self._launches()
+        if self.self_driven:
+            self.set_state(0, 0)                      # the warm-up advanced it
+
+    def set_clip_offsets(self, clip_offsets):
+        """Self-driven chain: the clip offsets of the rows now in the event buffer (int64 [n_clips + 1], host or device). Every clip's
+        window is at most fix_events_num rows by construction, so any ascending offsets inside the captured buffer are valid."""
+        off = clip_offsets if torch.is_tensor(clip_offsets) else torch.from_numpy(np.ascontiguousarray(clip_offsets, dtype=np.int64))
+        if off.numel() != self.nc + 1 or off.dtype != torch.int64:
+            raise ValueError("CapturedChain.set_clip_offsets: int64 [n_clips + 1] expected")
+        if not off.is_cuda:
+            o = off.numpy()
+            if o[0] < 0 or (np.diff(o) < 0).any() or o[-1] > self.events.shape[0]:
+                raise ValueError("CapturedChain.set_clip_offsets: offsets must ascend inside the event buffer")
+        self.d_off.copy_(off)
+
+    def set_state(self, step, first_sample=0):
+        """Self-driven chain: the (step, first sample) the NEXT replay draws for (every replay then advances step by one)."""
+        self.state.copy_(torch.tensor([int(step), int(first_sample)], dtype=torch.int64))
 
     def _stage(self, pb):
         if pb.n_clips != self.nc or not pb.on_device or pb.n_words != self.n_tab:
@@ -385,22 +411,20 @@ class CapturedChain:
         h[self.n_tab], h[self.n_tab + 1] = pb.step, pb.first_sample
 
     def _launches(self):
-        pipe, nc, dev = self.pipe, self.nc, self.events.device
-        self.d_tab.copy_(self.h_tab, non_blocking=True)
+        pipe, nc = self.pipe, self.nc
         d = self.d_tab
         tabs = d[:5 * (nc + 1)].view(5, nc + 1)
         pw = (nc * 6 + 1) // 2
         o4 = 5 * (nc + 1)
         H, W = pipe.sensor
-        tgt = None
-        if self.frames is not None:
-            # the frame targets need only the uploaded table: a branch of their own beside the event chain (a parallel branch of the
-            # captured graph; 40 us of the chain's 420 us of kernels)
-            cur = torch.cuda.current_stream()
-            self._aux.wait_stream(cur)
-            with torch.cuda.stream(self._aux):
-                fp = d[o4 + pw:o4 + 2 * pw].view(torch.int32)[:nc * 6].view(nc, 6)
-                tgt = va.frame_augment_batch(self.frames, fp, (pipe.S, pipe.S))
+        fr = self.frames
+        if self.self_driven:
+            # the plan of the batch, on the device: windows, counts and their prefix sums, crop rows; (step, first sample) -> d[n_tab:]
+            call("evp_events_plan_batch", ptr(self.d_off), nc, int(pipe.args.fix_events_num), pipe.seed & (2 ** 64 - 1), ptr(self.state), 1,
+                 ptr(d[self.n_tab:]), pipe.S, pipe.S, 0 if fr is None else int(fr.shape[-2]), 0 if fr is None else int(fr.shape[-1]),
+                 float(pipe.crop_min), ptr(tabs), ptr(d[o4:]), None if fr is None else ptr(d[o4 + pw:]), stream_ptr())
+        else:
+            d.copy_(self.h_tab, non_blocking=True)        # an upload node of the graph
         call("evp_events_draw_erase_add", ptr(tabs[0]), ptr(tabs[1]), nc, ptr(tabs[2]), ptr(tabs[3]), pipe.seed & (2 ** 64 - 1), 0, 0,
              ptr(d[self.n_tab:]), self.kmax, ptr(self.er), ptr(self.ai), ptr(self.nz), stream_ptr())
         call("evp_events_erase_add_win_f64", ptr(self.events), ptr(tabs[0]), ptr(tabs[1]), nc, ptr(self.er), ptr(tabs[2]), ptr(self.ai),
@@ -408,12 +432,17 @@ class CapturedChain:
         vox = voxel_grid_batch(self.ev, tabs[4], pipe.bins, (pipe.S, pipe.S), assume_sorted=True, scale=(pipe.S / W, pipe.S / H))
         p_dev = d[o4:o4 + pw].view(torch.int32)[:nc * 6].view(nc, 6)
         out = va.evg_augment_batch(vox, p_dev, (pipe.S, pipe.S))
-        if self.frames is not None:
-            torch.cuda.current_stream().wait_stream(self._aux)
+        tgt = None
+        if fr is not None:
+            # (as a parallel branch of the graph the frame targets cost more than they hide: 408 vs 389 us per batch with fork + join)
+            fp = d[o4 + pw:o4 + 2 * pw].view(torch.int32)[:nc * 6].view(nc, 6)
+            tgt = va.frame_augment_batch(fr, fp, (pipe.S, pipe.S))
         return out, tgt
 
     def run(self, pb):
-        """One batch: the prepared tables into the pinned slot, one replay. -> (voxels, targets): static tensors."""
+        """One batch of the PREPARED form: the tables into the pinned slot, one replay. -> (voxels, targets): static tensors."""
+        if self.self_driven:
+            raise ValueError("CapturedChain.run: this chain plans its batches on the device; use run_next()")
         if self._busy is not None:
             self._busy.synchronize()                  # the previous replay is done: its upload node has read the pinned table and its
         self._stage(pb)                               # outputs have been consumed by whatever the caller queued behind it
@@ -421,4 +450,12 @@ class CapturedChain:
         ev = self._busy or torch.cuda.Event()
         ev.record()
         self._busy = ev
+        return self.out, self.tgt
+
+    def run_next(self):
+        """Self-driven chain: one replay = one batch; nothing else happens on the host. -> (voxels, targets): static tensors, overwritten
+        by the next replay in stream order."""
+        if not self.self_driven:
+            raise ValueError("CapturedChain.run_next: capture with clip_offsets for the self-driven form")
+        self.graph.replay()
         return self.out, self.tgt

@@ -31,8 +31,8 @@ enum { EVP_ACT_NONE = 0, EVP_ACT_GELU = 1, EVP_ACT_DGELU = 2, EVP_ACT_RELU = 3, 
 
 const char *evp_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: evp_dropout_fwd takes a device-side seed; evp_gemm_desc lost its
- * stream-K workspace fields in round 3; 3: evp_events_draw_erase_add). A host binding must compare evp_abi_version() with EVP_ABI_VERSION at load time. */
-#define EVP_ABI_VERSION 4
+ * stream-K workspace fields in round 3; 3: evp_events_draw_erase_add; 4: keep flags on the window attention; 5: evp_events_plan_batch). A host binding must compare evp_abi_version() with EVP_ABI_VERSION at load time. */
+#define EVP_ABI_VERSION 5
 int evp_abi_version(void);
 /* Name of the code object's target ("gfx950"). */
 const char *evp_target_arch(void);
@@ -103,6 +103,17 @@ int evp_events_erase_add_win_f64(const double *events, const int64_t *win_begin,
 int evp_events_draw_erase_add(const int64_t *win_begin, const int64_t *win_end, int n_clips, const int64_t *erase_offsets,
                               const int64_t *add_offsets, uint64_t seed, uint64_t step, int64_t first_sample, const int64_t *step_first_dev,
                               int max_per_clip, int64_t *erase_idx, int64_t *add_idx, double *add_noise, void *stream);
+/* The per-batch PLAN of the loader chain computed on the device -- what the host otherwise prepares per batch from the same counter stream
+ * (get_random_index's window start, events_augment.py:5-20; the two counts of erase_and_add_events, :31-38; evg_augment's / frame_augment's
+ * crop box and flip coins, view_augment.py:9-77): for clip c with n_c = clip_offsets[c+1] - clip_offsets[c] rows (device int64 [n_clips+1])
+ *   tabs int64 [5][n_clips+1]: window begin / end (absolute rows), exclusive prefix sums of the erase counts, the add counts and the rows out;
+ *   params / frame_params int32 [n_clips,6] = (x0, y0, w, h, hflip, tflip) for a grid_h x grid_w view / a frame_h x frame_w frame (same
+ *   uniforms, the frame's time flip = the grid's; frame_params may be NULL).
+ * state: device int64[2] = (step, first sample); copied to step_first_out (what evp_events_draw_erase_add's step_first_dev reads for this
+ * batch) and, with advance != 0, step += 1 -- a captured HIP graph of the chain then needs nothing from the host per batch. */
+int evp_events_plan_batch(const int64_t *clip_offsets, int n_clips, int64_t fix_events_num, uint64_t seed, int64_t *state, int advance,
+                          int64_t *step_first_out, int grid_h, int grid_w, int frame_h, int frame_w, double crop_min, int64_t *tabs,
+                          int32_t *params, int32_t *frame_params, void *stream);
 /* sorted_flags[c] = 1 if clip c's stamps are non-decreasing, else 0 (device int32 [n_clips]). */
 int evp_events_sorted_check(const double *events, const int64_t *clip_offsets, int n_clips, int is_txyp,
                             int32_t *sorted_flags, void *stream);

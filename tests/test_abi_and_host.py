@@ -30,7 +30,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert set(_lib.exported_symbols()) == set(names), set(_lib.exported_symbols()) ^ set(names)
     lib.evp_target_arch.restype = ctypes.c_char_p
     assert lib.evp_target_arch() == b"gfx950"
-    assert lib.evp_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.evp_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_code_object_is_gfx950():

@@ -547,3 +547,59 @@ def test_gpu_input_pipeline_in_the_n_imagenet_draw_order():
             assert_checksums(got, d[f"{k}_evg_checksums"], 1e-5, k)
     with pytest.raises(ValueError):
         pipe.draw(off[1:] - off[:-1], step=0, frame_size=(480, 640))
+
+
+@pytest.mark.gpu
+def test_self_driven_loader_chain_plans_its_batches_on_the_device():
+    """The batch plan on the device (evp_events_plan_batch): window starts, erase / add counts and their prefix sums, crop rows of the
+    grid and of the frame target -- bit for bit what GpuInputPipeline.prepare() computes on the host with numpy from the same counter
+    stream, over ragged clips (shorter than the window, shorter than 100 rows, empty) and several steps; then the self-driven captured
+    chain (capture(..., clip_offsets=...): nothing from the host per batch, the graph advances its own step) against the prepared form
+    batch by batch."""
+    from eventpretrain_amd._lib import call, ptr, stream_ptr
+    from eventpretrain_amd.dataset.pretrain.gpu_input_pipeline import GpuInputPipeline
+    from eventpretrain_amd.testing import make_args, synthetic_events
+    a = make_args(crop_min=0.8, input_size=224, fix_events_num=15_000, img_sensor_w=640, img_sensor_h=480, device="cuda")
+    sizes = [40_000, 9_000, 15_000, 15_001, 99, 0, 23_456, 100]
+    nc = len(sizes)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    pipe = GpuInputPipeline(a, seed=77)
+    d_off = torch.from_numpy(off).cuda()
+    for step, first in ((0, 0), (5, 64), (123456789, 3)):
+        pb = pipe.prepare(off, step=step, first_sample=first, frame_size=(480, 640))
+        w = pb.words.numpy()
+        o = pb.o
+        tabs_h = w[o[3]:o[4]].reshape(5, nc + 1).copy()
+        p_h = w[o[4]:o[5]].view(np.int32)[:nc * 6].reshape(nc, 6).copy()
+        f_h = w[o[5]:o[6]].view(np.int32)[:nc * 6].reshape(nc, 6).copy()
+        state = torch.tensor([step, first], dtype=torch.int64, device="cuda")
+        cur = torch.zeros(2, dtype=torch.int64, device="cuda")
+        tabs = torch.full((5, nc + 1), -7, dtype=torch.int64, device="cuda")
+        prm = torch.zeros(nc, 6, dtype=torch.int32, device="cuda")
+        fpr = torch.zeros(nc, 6, dtype=torch.int32, device="cuda")
+        call("evp_events_plan_batch", ptr(d_off), nc, 15_000, 77, ptr(state), 1, ptr(cur), 224, 224, 480, 640, 0.8, ptr(tabs), ptr(prm), ptr(fpr),
+             stream_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(tabs.cpu().numpy(), tabs_h), (step, tabs.cpu().numpy(), tabs_h)
+        assert np.array_equal(prm.cpu().numpy(), p_h) and np.array_equal(fpr.cpu().numpy(), f_h), step
+        assert cur.tolist() == [step, first] and state.tolist() == [step + 1, first]
+    # the self-driven chain against the prepared one, three batches in a row (K1 bins with LDS float adds: equal to f32 rounding)
+    sizes = [40_000, 30_000, 15_000, 22_000]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    ev = torch.from_numpy(np.concatenate([synthetic_events(60 + i, n, width=640, height=480) for i, n in enumerate(sizes)], 0)).cuda()
+    frames = torch.randn(4, 1, 480, 640, device="cuda")
+    prepared = pipe.capture(ev, 4, frames=frames)
+    driven = pipe.capture(ev, 4, frames=frames, clip_offsets=off)
+    driven.set_state(10, 8)
+    for k in range(3):
+        v1, t1 = prepared.run(pipe.prepare(off, step=10 + k, first_sample=8, frame_size=(480, 640)))
+        v1, t1 = v1.clone(), t1.clone()
+        v2, t2 = driven.run_next()
+        torch.cuda.synchronize()
+        assert torch.allclose(v1, v2, atol=1e-5, rtol=0) and torch.equal(t1, t2), k
+        assert float(v2.abs().sum()) > 0
+    assert driven.state.tolist() == [13, 8]
+    with pytest.raises(ValueError):
+        driven.run(pipe.prepare(off, step=0, frame_size=(480, 640)))
+    with pytest.raises(ValueError):
+        prepared.run_next()
