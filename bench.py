@@ -758,12 +758,13 @@ def main():
             torch.cuda.synchronize()
             wall = (time.perf_counter() - tw) / n_rep
             csec = c0.elapsed_time(c1) * 1e-3 / n_rep
-            cbytes = pipe.algorithmic_bytes(np.full(args.batch, 100_000)) + args.batch * (480 * 640 + S * S) * 4.0
+            cbytes = pipe.algorithmic_bytes(np.full(args.batch, 100_000), fused=chain.fused) + args.batch * (480 * 640 + S * S) * 4.0
             result["loader_chain"] = {"value": args.batch / csec, "unit": "clips/s", "us_per_batch": csec * 1e6, "wall_us_per_batch": wall * 1e6,
                                       "bound": "hbm", "achieved": cbytes / csec / 1e9, "peak": HBM_PEAK_GBS, "frac": cbytes / csec / 1e9 / HBM_PEAK_GBS,
                                       "algorithmic_bytes_per_batch": cbytes, "host_prepare_ms_per_batch": host_ms, "host_ms_per_batch_in_this_loop": 0.0, "decision_stream": pipe.stream + " (plan on the device)",
                                       "includes": "get_random_index (100k of 150k events) -> events_augment -> events_reshape -> "
                                                   "events_to_voxel_grid -> evg_augment + frame_augment, 640x480 sensor clips resident in HBM; "
+                                                  "the voxel grids binned straight from window rows + erase list + added rows (the merged clip is never written); "
                                                   "per batch ONE HIP-graph replay of 9 launches and nothing else on the host: the batch plan (windows, counts, "
                                                   "offsets, crop boxes), the erase / add rows and the noise are all drawn on the device from the counter stream; "
                                                   "host_prepare_ms_per_batch = what the host-planned form (prepare / run) would spend per batch on a worker thread"}

@@ -408,6 +408,22 @@ __global__ __launch_bounds__(256) void plan_batch_kernel(const int64_t *clip_off
 }
 }  // namespace
 
+static int build_added_launch(const double *events, const int64_t *clip_begin, int n_clips, const int64_t *add_idx, const double *add_noise,
+                              const int64_t *add_offsets, int max_add_per_clip, double sensor_w, double sensor_h, double *add_rows_ws, hipStream_t s,
+                              const char *who) {
+  int np2 = 1;
+  while (np2 < max_add_per_clip) np2 <<= 1;
+  const size_t smem = (size_t)np2 * sizeof(SortKey);
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(build_added_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "%s: cannot reserve %zu B of LDS: %s", who, smem, hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(build_added_kernel, dim3(n_clips), dim3(1024), smem, s, events, clip_begin, add_idx, add_noise, add_offsets, sensor_w, sensor_h,
+                     add_rows_ws);
+  EVP_CHECK_LAUNCH(who);
+  return EVP_OK;
+}
+
 static int erase_add_launch(const double *events, const int64_t *clip_begin, const int64_t *clip_end, int n_clips, const int64_t *erase_idx,
                             const int64_t *erase_offsets, const int64_t *add_idx, const double *add_noise, const int64_t *add_offsets,
                             int max_add_per_clip, double sensor_w, double sensor_h, double *add_rows_ws, const int64_t *out_offsets,
@@ -421,16 +437,8 @@ static int erase_add_launch(const double *events, const int64_t *clip_begin, con
   EVP_CHECK_ARG((((uintptr_t)events | (uintptr_t)out_events) & 15) == 0, EVP_EINVAL, "%s: event buffers must be 16-byte aligned", who);
   hipStream_t s = (hipStream_t)stream;
   if (max_add_per_clip > 0) {
-    int np2 = 1;
-    while (np2 < max_add_per_clip) np2 <<= 1;
-    const size_t smem = (size_t)np2 * sizeof(SortKey);
-    if (smem > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(build_added_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "%s: cannot reserve %zu B of LDS: %s", who, smem, hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(build_added_kernel, dim3(n_clips), dim3(1024), smem, s, events, clip_begin, add_idx, add_noise, add_offsets, sensor_w, sensor_h,
-                       add_rows_ws);
-    EVP_CHECK_LAUNCH(who);
+    int rc = build_added_launch(events, clip_begin, n_clips, add_idx, add_noise, add_offsets, max_add_per_clip, sensor_w, sensor_h, add_rows_ws, s, who);
+    if (rc) return rc;
   }
   hipLaunchKernelGGL(merge_kernel, dim3(64, n_clips), dim3(256), 0, s, events, clip_begin, clip_end, erase_idx, erase_offsets, add_offsets, add_rows_ws,
                      out_offsets, out_events);
@@ -453,6 +461,16 @@ extern "C" int evp_events_erase_add_win_f64(const double *events, const int64_t 
                                             const int64_t *out_offsets, double *out_events, void *stream) {
   return erase_add_launch(events, win_begin, win_end, n_clips, erase_idx, erase_offsets, add_idx, add_noise, add_offsets, max_add_per_clip, sensor_w,
                           sensor_h, add_rows_ws, out_offsets, out_events, stream, "evp_events_erase_add_win_f64");
+}
+
+extern "C" int evp_events_build_added_f64(const double *events, const int64_t *win_begin, int n_clips, const int64_t *add_idx, const double *add_noise,
+                                          const int64_t *add_offsets, int max_add_per_clip, double sensor_w, double sensor_h, double *add_rows,
+                                          void *stream) {
+  EVP_CHECK_ARG(events && win_begin && add_idx && add_noise && add_offsets && add_rows, EVP_EINVAL, "evp_events_build_added_f64: null pointer");
+  EVP_CHECK_ARG(n_clips > 0 && max_add_per_clip >= 0 && max_add_per_clip <= EA_MAX_ADD, EVP_ESHAPE, "evp_events_build_added_f64: bad shape");
+  if (max_add_per_clip == 0) return EVP_OK;
+  return build_added_launch(events, win_begin, n_clips, add_idx, add_noise, add_offsets, max_add_per_clip, sensor_w, sensor_h, add_rows,
+                            (hipStream_t)stream, "evp_events_build_added_f64");
 }
 
 extern "C" int evp_events_draw_erase_add(const int64_t *win_begin, const int64_t *win_end, int n_clips, const int64_t *erase_offsets,

@@ -246,6 +246,199 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_kernel(const double *eve
   if (inconsistent) flags[clip] = 0;       // every writer stores 0: no atomic needed
 }
 
+// ---- K1 fused with the event-level augmentation of the loader chain --------------------------------------------------------------
+// The chain's merge kernel writes the augmented clip (window minus the erased rows plus the added rows, time-sorted) only for K1 to
+// read it back four times. The voxel grid does not need that array: it is a SUM over the kept rows, and the only things the order
+// decides are t0 / t1 (first / last stamp of the merged clip). So: the workgroups stream the ORIGINAL window rows through the same
+// slab schedule, skip the erased ones by a bitmap in LDS (one bit per window row, behind the tile), and then run over the (at most
+// 1 %) added rows, which arrive built and time-sorted from build_added_kernel. t0 = min(first kept row, first added row), t1 likewise.
+// Verified like the plain form: a kept row outside the region its position implies flags the clip, the repair pass scans it whole.
+struct FusedInfo { double t0, dT; };
+
+__global__ __launch_bounds__(512) void voxel_cuts_fused_kernel(const double *events, const int64_t *win_begin, const int64_t *win_end,
+                                                               const int64_t *erase_idx, const int64_t *erase_off, const double *added,
+                                                               const int64_t *add_off, int bins, int64_t *cuts, int32_t *flags, FusedInfo *info) {
+  __shared__ double sh_t0, sh_dT;
+  __shared__ int64_t sh_first, sh_last;
+  const int c = blockIdx.x;
+  const int64_t beg = win_begin[c], n = win_end[c] - beg;
+  const double *ev = events + beg * 4;
+  int64_t *out = cuts + (int64_t)c * (bins + 2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int64_t e0 = erase_off[c], ke = erase_off[c + 1] - e0, a0 = add_off[c], ka = add_off[c + 1] - a0;
+  if (threadIdx.x == 0) {
+    const int64_t *E = erase_idx + e0;
+    int64_t first = 0, last = n - 1;
+    while (first < ke && E[first] == first) ++first;                        // leading rows that are all erased
+    for (int64_t q = 0; q < ke && E[ke - 1 - q] == last; ++q) --last;       // trailing ones
+    double t0 = 0.0, t1 = 0.0;
+    bool have = false;
+    if (n > 0 && first <= last) { t0 = ev[first * 4 + 2]; t1 = ev[last * 4 + 2]; have = true; }
+    if (ka > 0) {
+      const double ta = added[a0 * 4 + 2], tb = added[(a0 + ka - 1) * 4 + 2];
+      t0 = have ? fmin(t0, ta) : ta;
+      t1 = have ? fmax(t1, tb) : tb;
+      have = true;
+    }
+    double dT = t1 - t0;
+    if (dT == 0) dT = 1.0;
+    sh_t0 = t0; sh_dT = dT;
+    sh_first = first; sh_last = last;
+    info[c].t0 = t0; info[c].dT = dT;
+  }
+  __syncthreads();
+  const double t0 = sh_t0, dT = sh_dT;
+  if (n <= 0) {
+    for (int k = threadIdx.x; k <= bins + 1; k += blockDim.x) out[k] = 0;
+    if (threadIdx.x == 0) flags[c] = 1;
+    return;
+  }
+  for (int k = wave; k <= bins; k += nw) {
+    int64_t lo = 0, hi = n;
+    while (hi > lo) {
+      const int64_t step = (hi - lo + 63) / 64;
+      const int64_t idx = lo + (int64_t)lane * step;
+      bool pred = false;
+      if (idx < hi) pred = ts_of(ev[idx * 4 + 2], t0, dT, bins) >= (double)k;
+      const unsigned long long m = __ballot(pred);
+      if (m == 0ull) {
+        const int64_t last = lo + ((hi - 1 - lo) / step) * step;
+        lo = last + 1;
+      } else {
+        const int f = __ffsll((long long)m) - 1;
+        const int64_t pf = lo + (int64_t)f * step;
+        if (f > 0) lo = pf - step + 1;
+        hi = pf;
+      }
+    }
+    if (lane == 0) out[k] = lo;
+  }
+  if (threadIdx.x == 0) out[bins + 1] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // Sorted stamps put nothing but ERASED rows in front of cuts[0] (ts < 0: earlier than the first kept row) and behind cuts[bins]
+    // (later than the last kept one) -- the slabs never visit those two ranges, so a kept row there must send the clip to the repair
+    // pass; between them the bin kernel checks every kept row it normalises.
+    bool ok = out[0] <= sh_first && out[bins] >= sh_last + 1;
+    for (int k = 0; k < bins; ++k) ok = ok && out[k] <= out[k + 1];
+    flags[c] = ok ? 1 : 0;
+  }
+}
+
+// one visit of a row (original or added) by the workgroup of plane b / tile [pix0, pix1); returns false when a verified row is outside
+// `region` (region < -1: no check)
+__device__ __forceinline__ bool fused_visit(double x, double y, double t, double pd, int W, int64_t pix0, int64_t pix1, double t0, double dT,
+                                            double rT, bool clip_fast, double scale, double bd, double region, float *tile) {
+  int64_t pix;
+  if (__builtin_fabs(x) < 2147483648.0 && __builtin_fabs(y) < 2147483648.0) pix = (int64_t)(int)x + (int64_t)(int)y * (int64_t)W;
+  else pix = (int64_t)x + (int64_t)y * (int64_t)W;
+  if (pix < pix0 || pix >= pix1) return true;
+  const double a = scale * (t - t0);
+  const double ts = (clip_fast && in_safe_range(a)) ? div_by_clip_constant(a, dT, rT) : a / dT;
+  const double tf = floor(ts);
+  const bool good = region < -1.5 || tf == region;
+  if (!(tf >= 0.0)) return good;
+  float p = (float)pd;
+  if (p == 0.0f) p = -1.0f;
+  const float dt = (float)(ts - tf);
+  if (tf == bd) atomicAdd(&tile[pix - pix0], p * (1.0f - dt));
+  else if (tf + 1.0 == bd) atomicAdd(&tile[pix - pix0], p * dt);
+  return good;
+}
+
+__global__ __launch_bounds__(VB_THREADS) void voxel_bin_fused_kernel(const double *events, const int64_t *win_begin, const int64_t *win_end,
+                                                                     const int64_t *erase_idx, const int64_t *erase_off, const double *added,
+                                                                     const int64_t *add_off, const int64_t *cuts, const FusedInfo *info, int n_clips,
+                                                                     int bins, int H, int W, int mode, int tile_rows, int n_yt, int bm_words,
+                                                                     double sx, double sy, float *out, int32_t *flags) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *tile = reinterpret_cast<float *>(smem_raw);
+  uint32_t *bm = reinterpret_cast<uint32_t *>(smem_raw + (size_t)tile_rows * W * sizeof(float));     // erased-row bitmap of the window
+  const int n_j = bins > 1 ? bins - 1 : 1;
+  const int per_clip = n_j * n_yt;
+  int clip, sub;
+  if ((n_clips & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    clip = (slot / per_clip) * 8 + xcd;
+    sub = slot % per_clip;
+  } else {
+    clip = blockIdx.x / per_clip;
+    sub = blockIdx.x % per_clip;
+  }
+  const int ok = flags[clip];
+  if (mode == 2 ? !ok : ok) return;        // 2: fast pass for the clips whose cuts are a partition; 3: repair pass for the others
+  const bool sorted = mode == 2;
+  bool inconsistent = false;
+  const int j = sub / n_yt, yt = sub % n_yt;
+  const int y0 = yt * tile_rows, y1 = (y0 + tile_rows < H) ? y0 + tile_rows : H;
+  const int tile_elems = (y1 - y0) * W;
+  const int64_t pix0 = (int64_t)y0 * W, pix1 = (int64_t)y1 * W;
+  const int64_t beg = win_begin[clip], n = win_end[clip] - beg;
+  const double *ev = events + beg * 4;
+  const int64_t *cc = cuts + (int64_t)clip * (bins + 2);
+  const double t0 = info[clip].t0, dT = info[clip].dT;
+  const double rT = 1.0 / dT, scale = (double)(bins - 1);
+  const bool clip_fast = in_safe_range(dT);
+  const int64_t e0 = erase_off[clip], ke = erase_off[clip + 1] - e0, a0 = add_off[clip], ka = add_off[clip + 1] - a0;
+  for (int i = threadIdx.x; i < bm_words; i += VB_THREADS) bm[i] = 0u;
+  __syncthreads();
+  for (int64_t q = threadIdx.x; q < ke; q += VB_THREADS) {
+    const int64_t r = erase_idx[e0 + q];
+    if (r >= 0 && r < n && (r >> 5) < bm_words) atomicOr(&bm[r >> 5], 1u << (r & 31));
+  }
+  const int n_jobs = (j == 0 && bins > 1) ? 2 : 1;
+  for (int job = 0; job < n_jobs; ++job) {
+    const int b = job ? bins - 1 : j;
+    const bool swapped = (j > 0) && ((j & 1) == 0);
+    const double bd = (double)b;
+    __syncthreads();                       // the bitmap is complete / the previous plane's flush has read the tile
+    for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) tile[i] = 0.f;
+    __syncthreads();
+    if (n > 0) {
+      for (int part = 0; part < (sorted ? 2 : 1); ++part) {
+        const bool upper = (part == 0) == swapped;
+        const int64_t lo = sorted ? (upper ? cc[b] : cc[b > 0 ? b - 1 : 0]) : 0;
+        // the last plane also takes what lies behind cuts[bins]: kept rows with ts == bins - 1 sit in front of it, rows behind it are erased
+        const int64_t hi = sorted ? (upper ? cc[b + 1] : cc[b]) : n;
+        const double region = sorted ? (upper ? bd : bd - 1.0) : -2.0;
+        for (int64_t k0 = threadIdx.x; k0 < hi - lo; k0 += (int64_t)VB_THREADS * VB_UNROLL) {
+          double2 ra[VB_UNROLL], rb[VB_UNROLL];
+          bool live[VB_UNROLL];
+#pragma unroll
+          for (int u = 0; u < VB_UNROLL; ++u) {
+            const int64_t k = k0 + (int64_t)u * VB_THREADS;
+            live[u] = k < hi - lo;
+            const int64_t r = lo + (live[u] ? k : 0);
+            const double *row = ev + r * 4;
+            ra[u] = *reinterpret_cast<const double2 *>(row);
+            rb[u] = *reinterpret_cast<const double2 *>(row + 2);
+            if (live[u] && ((bm[r >> 5] >> (r & 31)) & 1u)) live[u] = false;       // erased
+          }
+#pragma unroll
+          for (int u = 0; u < VB_UNROLL; ++u) {
+            if (!live[u]) continue;
+            if (!fused_visit(ra[u].x * sx, ra[u].y * sy, rb[u].x, rb[u].y, W, pix0, pix1, t0, dT, rT, clip_fast, scale, bd, region, tile)) inconsistent = true;
+          }
+        }
+      }
+    }
+    // the added rows (built, clipped to the sensor and time-sorted by build_added_kernel): every workgroup of the clip looks at all of them
+    for (int64_t q = threadIdx.x; q < ka; q += VB_THREADS) {
+      const double *row = added + (a0 + q) * 4;
+      fused_visit(row[0] * sx, row[1] * sy, row[2], row[3], W, pix0, pix1, t0, dT, rT, clip_fast, scale, bd, -2.0, tile);
+    }
+    __syncthreads();
+    float *dst = out + (((int64_t)clip * bins + b) * H + y0) * W;
+    if ((W & 3) == 0) {
+      for (int i = threadIdx.x; i < tile_elems / 4; i += VB_THREADS)
+        reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(tile)[i];
+    } else {
+      for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) dst[i] = tile[i];
+    }
+  }
+  if (inconsistent) flags[clip] = 0;
+}
+
 // ---- two-pass form (algo 2): decode once, bin from packed records ------------------------------------------------
 // Pass A decodes every event exactly once (the float64 time normalisation with its division is the expensive part)
 // into three 4-byte streams: key = pix | floor(ts) << 24 | invalid << 31, and the two float32 contributions
@@ -468,5 +661,42 @@ extern "C" int evp_events_sorted_check(const double *events, const int64_t *clip
   EVP_CHECK_ARG(events && clip_offsets && sorted_flags && n_clips > 0, EVP_EINVAL, "evp_events_sorted_check: bad argument");
   hipLaunchKernelGGL(sorted_check_kernel, dim3(n_clips), dim3(256), 0, (hipStream_t)stream, events, clip_offsets, is_txyp, sorted_flags);
   EVP_CHECK_LAUNCH("evp_events_sorted_check");
+  return EVP_OK;
+}
+
+extern "C" int evp_voxel_scatter_fused_f32(const double *events, const int64_t *win_begin, const int64_t *win_end, int n_clips,
+                                           const int64_t *erase_idx, const int64_t *erase_offsets, const double *added_rows,
+                                           const int64_t *add_offsets, int64_t max_window, int bins, int H, int W, double scale_x, double scale_y,
+                                           int64_t *workspace, float *out, void *stream) {
+  EVP_CHECK_ARG(events && win_begin && win_end && erase_idx && erase_offsets && added_rows && add_offsets && workspace && out, EVP_EINVAL,
+                "evp_voxel_scatter_fused_f32: null pointer");
+  EVP_CHECK_ARG(n_clips > 0 && bins > 0 && bins <= 64 && H > 0 && W > 0 && max_window > 0, EVP_ESHAPE, "evp_voxel_scatter_fused_f32: bad shape");
+  EVP_CHECK_ARG(((uintptr_t)events & 15) == 0, EVP_EINVAL, "evp_voxel_scatter_fused_f32: events must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int bm_words = (int)((max_window + 31) / 32);
+  const size_t bm_bytes = (size_t)bm_words * 4;
+  EVP_CHECK_ARG(bm_bytes <= 48 * 1024, EVP_ESHAPE, "evp_voxel_scatter_fused_f32: windows of at most %d rows (got %lld)", 48 * 1024 * 8, (long long)max_window);
+  const int max_rows = (int)((100 * 1024) / ((size_t)W * sizeof(float)));
+  int tile_rows = max_rows < 1 ? 1 : (max_rows > H ? H : max_rows);
+  const int n_yt = (H + tile_rows - 1) / tile_rows;
+  tile_rows = (H + n_yt - 1) / n_yt;
+  const size_t smem = (size_t)tile_rows * W * sizeof(float) + bm_bytes;
+  EVP_CHECK_ARG(smem <= 160 * 1024, EVP_ESHAPE, "evp_voxel_scatter_fused_f32: tile of %d rows x %d + bitmap exceeds LDS", tile_rows, W);
+  int64_t *cuts = workspace;
+  FusedInfo *info = reinterpret_cast<FusedInfo *>(workspace + (int64_t)n_clips * (bins + 2));
+  int32_t *flags = reinterpret_cast<int32_t *>(workspace + (int64_t)n_clips * (bins + 2) + 2 * (int64_t)n_clips);
+  hipLaunchKernelGGL(voxel_cuts_fused_kernel, dim3(n_clips), dim3(512), 0, s, events, win_begin, win_end, erase_idx, erase_offsets, added_rows, add_offsets, bins,
+                     cuts, flags, info);
+  EVP_CHECK_LAUNCH("evp_voxel_scatter_fused_f32(cuts)");
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(voxel_bin_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    EVP_CHECK_ARG(e == hipSuccess, EVP_ELAUNCH, "evp_voxel_scatter_fused_f32: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
+  }
+  const int n_blocks = n_clips * (bins > 1 ? bins - 1 : 1) * n_yt;
+  for (int pass = 0; pass < 2; ++pass) {
+    hipLaunchKernelGGL(voxel_bin_fused_kernel, dim3(n_blocks), dim3(VB_THREADS), smem, s, events, win_begin, win_end, erase_idx, erase_offsets, added_rows,
+                       add_offsets, cuts, info, n_clips, bins, H, W, pass ? 3 : 2, tile_rows, n_yt, bm_words, scale_x, scale_y, out, flags);
+    EVP_CHECK_LAUNCH("evp_voxel_scatter_fused_f32(bin)");
+  }
   return EVP_OK;
 }

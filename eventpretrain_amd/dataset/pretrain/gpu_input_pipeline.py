@@ -304,7 +304,7 @@ class GpuInputPipeline:
             out.append(None if (e.stop == e.start and a.stop == a.start) else (er[e].copy(), ai[a].copy(), nz[a].copy()))
         return out
 
-    def capture(self, events, n_clips, frames=None, clip_offsets=None):
+    def capture(self, events, n_clips, frames=None, clip_offsets=None, fused_voxel=True):
         """The device half as ONE HIP graph (device decision stream): `events` is the buffer every batch's raw rows will sit in (fixed
         address: the loader uploads into it), `frames` likewise. Launched from Python the eight kernels of a batch cost more host time
         (~0.9 ms with the worker thread competing for the interpreter) than the GPU needs for them (~0.42 ms); replayed they cost one
@@ -315,8 +315,10 @@ class GpuInputPipeline:
         With `clip_offsets` (int64 [n_clips + 1], host or device) the chain is SELF-DRIVEN: the batch's plan (windows, counts, offsets,
         crop rows) is computed by a kernel inside the graph (evp_events_plan_batch) from the clip offsets and a device-resident (step,
         first sample) pair that the graph itself advances -- `run_next()` is one replay, with nothing prepared, packed or uploaded on the
-        host; `set_clip_offsets` / `set_state` change the inputs between replays."""
-        return CapturedChain(self, events, int(n_clips), frames, clip_offsets)
+        host; `set_clip_offsets` / `set_state` change the inputs between replays.
+        `fused_voxel` (default): the voxel grids are binned straight from the window rows, the erase list and the added rows
+        (evp_voxel_scatter_fused_f32) -- the merged clip, which only K1 would read, is never written."""
+        return CapturedChain(self, events, int(n_clips), frames, clip_offsets, fused_voxel)
 
     def batch(self, events, clip_offsets, step, frames=None, first_sample=0, sample_seeds=None):
         """The whole chain for one batch: decisions on the host, data on the device."""
@@ -331,20 +333,21 @@ class GpuInputPipeline:
         windows, dec, params, fparams = self.draw(offs[1:] - offs[:-1], step, first_sample, sample_seeds, frame_size=frames.shape[-2:])
         return self.run(events, offs, windows, dec, params, frames, fparams)
 
-    def algorithmic_bytes(self, sizes):
+    def algorithmic_bytes(self, sizes, fused=False):
         """HBM bytes the chain has to move for clips whose picked windows hold `sizes` rows (the figure bench.py prices the chain
         with): read the window (32 B / row) + write the augmented clip (32 B / row; +- 1 %) + K1 reads it again and writes the grid
-        once + the view augmentation reads the grid and writes the view."""
+        once + the view augmentation reads the grid and writes the view. `fused` (CapturedChain's default form): the augmented clip is
+        neither written nor read -- the window is read once, by K1."""
         n = float(np.sum(sizes))
         grid = self.bins * self.S * self.S * 4.0 * len(sizes)
-        return n * 32 + n * 32 + n * 32 + grid + grid + grid
+        return (n * 32 if fused else n * 32 + n * 32 + n * 32) + grid + grid + grid
 
 
 class CapturedChain:
     """GpuInputPipeline.capture: the chain's device half captured once, replayed per batch -- with the batch's tables prepared on the host
     (run(prepared)) or, self-driven, planned by a kernel of the graph (run_next())."""
 
-    def __init__(self, pipe, events, n_clips, frames, clip_offsets=None):
+    def __init__(self, pipe, events, n_clips, frames, clip_offsets=None, fused_voxel=True):
         if pipe.stream != "device":
             raise ValueError("CapturedChain needs decision_stream='device' (host-drawn decision lists change size per batch)")
         _lib.require_device()
@@ -361,7 +364,9 @@ class CapturedChain:
         self.ai = torch.zeros(n_clips * self.kmax, dtype=torch.int64, device=dev)
         self.nz = torch.zeros(n_clips * self.kmax * 3, dtype=torch.float64, device=dev)
         self.ws = torch.zeros(n_clips * self.kmax, 4, dtype=torch.float64, device=dev)
-        self.ev = torch.zeros(n_clips * (fix + self.kmax), 4, dtype=torch.float64, device=dev)
+        self.fused = bool(fused_voxel) and fix <= 48 * 1024 * 8
+        self.ev = None if self.fused else torch.zeros(n_clips * (fix + self.kmax), 4, dtype=torch.float64, device=dev)
+        self.kws = torch.zeros(n_clips * (pipe.bins + 5), dtype=torch.int64, device=dev) if self.fused else None
         self._busy = None
         self.self_driven = clip_offsets is not None
         if self.self_driven:
@@ -427,9 +432,18 @@ class CapturedChain:
             d.copy_(self.h_tab, non_blocking=True)        # an upload node of the graph
         call("evp_events_draw_erase_add", ptr(tabs[0]), ptr(tabs[1]), nc, ptr(tabs[2]), ptr(tabs[3]), pipe.seed & (2 ** 64 - 1), 0, 0,
              ptr(d[self.n_tab:]), self.kmax, ptr(self.er), ptr(self.ai), ptr(self.nz), stream_ptr())
-        call("evp_events_erase_add_win_f64", ptr(self.events), ptr(tabs[0]), ptr(tabs[1]), nc, ptr(self.er), ptr(tabs[2]), ptr(self.ai),
-             ptr(self.nz), ptr(tabs[3]), self.kmax, float(W), float(H), ptr(self.ws), ptr(tabs[4]), ptr(self.ev), stream_ptr())
-        vox = voxel_grid_batch(self.ev, tabs[4], pipe.bins, (pipe.S, pipe.S), assume_sorted=True, scale=(pipe.S / W, pipe.S / H))
+        if self.fused:
+            # the added rows built and time-sorted, then the grids straight from window rows + erase list + added rows (no merged clip)
+            call("evp_events_build_added_f64", ptr(self.events), ptr(tabs[0]), nc, ptr(self.ai), ptr(self.nz), ptr(tabs[3]), self.kmax, float(W),
+                 float(H), ptr(self.ws), stream_ptr())
+            vox = torch.empty(nc, pipe.bins, pipe.S, pipe.S, dtype=torch.float32, device=d.device)
+            call("evp_voxel_scatter_fused_f32", ptr(self.events), ptr(tabs[0]), ptr(tabs[1]), nc, ptr(self.er), ptr(tabs[2]), ptr(self.ws),
+                 ptr(tabs[3]), int(pipe.args.fix_events_num), pipe.bins, pipe.S, pipe.S, pipe.S / W, pipe.S / H, ptr(self.kws), ptr(vox),
+                 stream_ptr())
+        else:
+            call("evp_events_erase_add_win_f64", ptr(self.events), ptr(tabs[0]), ptr(tabs[1]), nc, ptr(self.er), ptr(tabs[2]), ptr(self.ai),
+                 ptr(self.nz), ptr(tabs[3]), self.kmax, float(W), float(H), ptr(self.ws), ptr(tabs[4]), ptr(self.ev), stream_ptr())
+            vox = voxel_grid_batch(self.ev, tabs[4], pipe.bins, (pipe.S, pipe.S), assume_sorted=True, scale=(pipe.S / W, pipe.S / H))
         p_dev = d[o4:o4 + pw].view(torch.int32)[:nc * 6].view(nc, 6)
         out = va.evg_augment_batch(vox, p_dev, (pipe.S, pipe.S))
         tgt = None

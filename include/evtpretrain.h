@@ -92,6 +92,11 @@ int evp_events_erase_add_win_f64(const double *events, const int64_t *win_begin,
                                  const int64_t *erase_idx, const int64_t *erase_offsets, const int64_t *add_idx, const double *add_noise,
                                  const int64_t *add_offsets, int max_add_per_clip, double sensor_w, double sensor_h, double *add_rows_ws,
                                  const int64_t *out_offsets, double *out_events, void *stream);
+/* Only the ADDED rows of the above (events_augment.py:40-49): add_rows[add_offsets[c] + r] = the copy of window row add_idx[.] of clip c plus
+ * its noise, x / y clipped to the sensor, the clip's rows sorted by stamp -- what evp_voxel_scatter_fused_f32 takes beside the window. */
+int evp_events_build_added_f64(const double *events, const int64_t *win_begin, int n_clips, const int64_t *add_idx, const double *add_noise,
+                               const int64_t *add_offsets, int max_add_per_clip, double sensor_w, double sensor_h, double *add_rows,
+                               void *stream);
 /* The DECISIONS of erase_and_add_events drawn on the device (events_augment.py:31-44: which rows to erase, which to copy, the three
  * normal noise columns of the copies): clip c (rows [win_begin[c], win_end[c]) of some event array, n_c of them) gets
  * erase_offsets[c+1] - erase_offsets[c] DISTINCT rows in erase_idx (ascending, clip-relative) and add_offsets[c+1] - add_offsets[c]
@@ -117,6 +122,17 @@ int evp_events_plan_batch(const int64_t *clip_offsets, int n_clips, int64_t fix_
 /* sorted_flags[c] = 1 if clip c's stamps are non-decreasing, else 0 (device int32 [n_clips]). */
 int evp_events_sorted_check(const double *events, const int64_t *clip_offsets, int n_clips, int is_txyp,
                             int32_t *sorted_flags, void *stream);
+
+/* K1 fused with the loader's event-level augmentation (events_augment.py:28-61 erase_and_add_events followed by events_reshape and
+ * events_to_voxel_grid): the voxel grids of the clips [win_begin[c], win_end[c]) of `events` MINUS the rows erase_idx (window-relative,
+ * ascending, erase_offsets [n_clips+1]) PLUS added_rows (float64 [.,4] x,y,t,p, time-sorted per clip as evp_events_erase_add_*'s workspace
+ * holds them, add_offsets [n_clips+1]) -- without writing the merged clip: the grid is a sum over the kept rows, the order only decides
+ * t0 / t1 (min / max stamp of the merged clip). max_window >= every window's rows (<= 393216: one bit per row in LDS). Window stamps
+ * non-decreasing is verified on the device; a clip that fails is redone by a full scan. workspace: n_clips * (bins + 5) int64. */
+int evp_voxel_scatter_fused_f32(const double *events, const int64_t *win_begin, const int64_t *win_end, int n_clips,
+                                const int64_t *erase_idx, const int64_t *erase_offsets, const double *added_rows,
+                                const int64_t *add_offsets, int64_t max_window, int bins, int H, int W, double scale_x, double scale_y,
+                                int64_t *workspace, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------ K2 masking
  * Replaces ViT.random_masking, model/backbone/vit.py:91-103 (argsort, argsort, slice, gather) with the noise as an

@@ -603,3 +603,100 @@ def test_self_driven_loader_chain_plans_its_batches_on_the_device():
         driven.run(pipe.prepare(off, step=0, frame_size=(480, 640)))
     with pytest.raises(ValueError):
         prepared.run_next()
+
+
+@pytest.mark.gpu
+def test_voxel_grid_fused_with_the_event_augmentation():
+    """evp_voxel_scatter_fused_f32: the grids of (window rows - erased rows + added rows) without writing the merged clip, against the
+    two-step form (evp_events_erase_add_win_f64, then K1 on its output). Cases: ordinary clips; the FIRST and LAST window rows erased
+    (t0 / t1 move to the next kept rows); added rows earlier than every window row and later than all (t0 / t1 come from them); an empty
+    window; a window shorter than the 1 % threshold (nothing erased or added); a window whose stamps are NOT sorted (device check ->
+    repair pass). Also through the captured chain: fused and merged forms of the same batches agree."""
+    from eventpretrain_amd._lib import call, ptr, stream_ptr
+    from eventpretrain_amd.dataset.dataset_utils.events_to_voxel_grid import voxel_grid_batch
+    from eventpretrain_amd.dataset.pretrain.gpu_input_pipeline import GpuInputPipeline
+    from eventpretrain_amd.testing import make_args, synthetic_events
+    rng = np.random.default_rng(5)
+    sizes = [30_000, 20_000, 0, 60, 25_000, 18_000]
+    clips = [synthetic_events(300 + i, n, width=640, height=480) for i, n in enumerate(sizes)]
+    clips[5] = clips[5][rng.permutation(sizes[5])]                                  # unsorted stamps
+    ev = torch.from_numpy(np.concatenate(clips, 0)).cuda()
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    win = np.stack([off[:-1] + np.array([100, 0, 0, 0, 7, 0]), off[1:] - np.array([50, 0, 0, 0, 0, 0])], 0)     # [2, nc] absolute rows
+    nwin = win[1] - win[0]
+    er, ai, nz = [], [], []
+    for c, n in enumerate(nwin):
+        if n < 100:
+            er.append(np.zeros(0, np.int64)), ai.append(np.zeros(0, np.int64)), nz.append(np.zeros((0, 3)))
+            continue
+        e = np.sort(rng.choice(n, size=int(0.005 * n), replace=False))
+        if c == 1:
+            e = np.unique(np.concatenate([[0, 1, 2, n - 1, n - 2], e]))              # leading and trailing rows erased
+        a = rng.choice(n, size=int(0.004 * n), replace=False)
+        z = rng.normal(size=(a.size, 3)) * np.array([1.5, 1.5, 0.001])
+        if c == 4:
+            a[:2] = [0, n - 1]
+            z[0, 2], z[1, 2] = -0.01, 0.01                                           # an added row before every stamp, one after all
+        er.append(e.astype(np.int64)), ai.append(a.astype(np.int64)), nz.append(z)
+    nc = len(sizes)
+    cum = lambda xs: np.concatenate([[0], np.cumsum([len(x) for x in xs])]).astype(np.int64)
+    e_off, a_off = cum(er), cum(ai)
+    out_off = np.concatenate([[0], np.cumsum(nwin - np.diff(e_off) + np.diff(a_off))]).astype(np.int64)
+    dev = lambda x, dt=torch.int64: torch.from_numpy(np.ascontiguousarray(x)).to(dt).cuda()
+    d_wb, d_we, d_eo, d_ao, d_oo = dev(win[0]), dev(win[1]), dev(e_off), dev(a_off), dev(out_off)
+    d_er, d_ai = dev(np.concatenate(er)), dev(np.concatenate(ai))
+    d_nz = dev(np.concatenate(nz).reshape(-1), torch.float64)
+    kmax = int(max(np.diff(a_off).max(), 1))
+    ws = torch.zeros(int(a_off[-1]) + 1, 4, dtype=torch.float64, device="cuda")
+    merged = torch.zeros(int(out_off[-1]) + 1, 4, dtype=torch.float64, device="cuda")
+    call("evp_events_erase_add_win_f64", ptr(ev), ptr(d_wb), ptr(d_we), nc, ptr(d_er), ptr(d_eo), ptr(d_ai), ptr(d_nz), ptr(d_ao), kmax, 640.0, 480.0,
+         ptr(ws), ptr(d_oo), ptr(merged), stream_ptr())
+    want = voxel_grid_batch(merged[:int(out_off[-1])].contiguous() if out_off[-1] else merged[:0], d_oo, 5, (224, 224), assume_sorted=True, scale=(224 / 640, 224 / 480))
+    ws2 = torch.zeros_like(ws)
+    call("evp_events_build_added_f64", ptr(ev), ptr(d_wb), nc, ptr(d_ai), ptr(d_nz), ptr(d_ao), kmax, 640.0, 480.0, ptr(ws2), stream_ptr())
+    got = torch.full((nc, 5, 224, 224), 7.0, device="cuda")
+    kws = torch.zeros(nc * 10, dtype=torch.int64, device="cuda")
+    call("evp_voxel_scatter_fused_f32", ptr(ev), ptr(d_wb), ptr(d_we), nc, ptr(d_er), ptr(d_eo), ptr(ws2), ptr(d_ao), int(nwin.max()), 5, 224, 224,
+         224 / 640, 224 / 480, ptr(kws), ptr(got), stream_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(ws, ws2)
+    flags = kws[nc * 9:].view(torch.int32)[:nc].tolist()
+    assert flags == [1, 1, 1, 1, 1, 0], flags                                       # only the shuffled clip went to the repair pass
+    for c in range(nc - 1):
+        assert torch.allclose(got[c], want[c], atol=2e-5, rtol=0), (c, (got[c] - want[c]).abs().max().item())
+    assert float(got[2].abs().sum()) == 0 and float(got[0].abs().sum()) > 0
+    # the shuffled clip is outside the op's contract (windows are time-sorted, as events_augment_batch requires); what the repair pass
+    # computes is the sum over kept + added rows with t0 / t1 from the first / last kept row by POSITION and the added rows' extremes
+    c = nc - 1
+    w_rows = clips[c][win[0][c] - off[c]:win[1][c] - off[c]]
+    keep = np.ones(w_rows.shape[0], bool)
+    keep[er[c]] = False
+    add_rows = ws2[int(a_off[c]):int(a_off[c + 1])].cpu().numpy()
+    kept = w_rows[keep]
+    t0 = min(kept[0, 2], add_rows[:, 2].min()); t1 = max(kept[-1, 2], add_rows[:, 2].max())
+    rows = np.concatenate([kept, add_rows], 0)
+    ts = 4.0 * (rows[:, 2] - t0) / (t1 - t0)
+    tf = np.floor(ts)
+    pix = (rows[:, 0] * (224 / 640)).astype(np.int64) + (rows[:, 1] * (224 / 480)).astype(np.int64) * 224
+    pol = np.where(rows[:, 3] == 0, -1.0, rows[:, 3]).astype(np.float32)
+    dt = (ts - tf).astype(np.float32)
+    ref = np.zeros(5 * 224 * 224, np.float64)
+    okl = (tf >= 0) & (tf < 5)
+    np.add.at(ref, (tf[okl].astype(np.int64)) * 50176 + pix[okl], (pol * (1 - dt))[okl])
+    okr = (tf >= 0) & (tf + 1 < 5)
+    np.add.at(ref, (tf[okr].astype(np.int64) + 1) * 50176 + pix[okr], (pol * dt)[okr])
+    assert np.abs(got[c].cpu().numpy().reshape(-1) - ref).max() <= 2e-5
+    # the captured chain, fused against merged, same batches
+    a = make_args(crop_min=0.8, input_size=224, fix_events_num=15_000, img_sensor_w=640, img_sensor_h=480, device="cuda")
+    sz = [40_000, 30_000, 15_000, 9_000]
+    off2 = np.concatenate([[0], np.cumsum(sz)]).astype(np.int64)
+    ev2 = torch.from_numpy(np.concatenate([synthetic_events(80 + i, n, width=640, height=480) for i, n in enumerate(sz)], 0)).cuda()
+    pipe = GpuInputPipeline(a, seed=3)
+    ch_f = pipe.capture(ev2, 4, clip_offsets=off2)
+    ch_m = pipe.capture(ev2, 4, clip_offsets=off2, fused_voxel=False)
+    assert ch_f.fused and not ch_m.fused
+    for k in range(3):
+        vf, _ = ch_f.run_next()
+        vm, _ = ch_m.run_next()
+        torch.cuda.synchronize()
+        assert torch.allclose(vf, vm, atol=2e-5, rtol=0), (k, (vf - vm).abs().max().item())

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The loader chain alone (bench.py's `loader_chain` workload: 64 clips of 150 k events on a 640 x 480 sensor, 100 k-event windows),
-10 batches -- run under `rocprofv3 --kernel-trace --stats` for the per-kernel split."""
+10 replays of the self-driven captured chain (+ its warm-up launches) -- run under `rocprofv3 --kernel-trace --stats` for the per-kernel split."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,8 +12,10 @@ clip = synthetic_events(4242, 150_000, width=640, height=480)
 ev = torch.from_numpy(np.concatenate([clip] * B, 0)).cuda()
 off = np.arange(0, (B + 1) * 150_000, 150_000, dtype=np.int64)
 frames = torch.randn(B, 1, 480, 640, device="cuda")
-pipe = GpuInputPipeline(pa, seed=1)          # device decision stream: counts on the host, rows and noise drawn by a kernel
+pipe = GpuInputPipeline(pa, seed=1)          # device decision stream; the self-driven captured chain is what bench.py times
+chain = pipe.capture(ev, B, frames=frames, clip_offsets=off)
+torch.cuda.synchronize()
 for i in range(10):
-    pipe.run_prepared(ev, pipe.prepare(off, step=i, frame_size=(480, 640)), frames=frames)
+    chain.run_next()
 torch.cuda.synchronize()
 print("done")
