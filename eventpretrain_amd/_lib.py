@@ -35,7 +35,7 @@ SIGNATURES = {
     "evp_voxel_scatter_f32": [_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "evp_voxel_scatter_scaled_f32": [_vp, _vp, _i, _i64, _i, _i, _i, _i, _i, _i, _i, _d, _d, _vp, _vp, _vp],
     "evp_events_build_added_f64": [_vp, _vp, _i, _vp, _vp, _vp, _i, _d, _d, _vp, _vp],
-    "evp_voxel_scatter_fused_f32": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _d, _d, _vp, _vp, _vp],
+    "evp_voxel_scatter_fused_f32": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _d, _d, _vp, _i, _i, _i, _vp, _vp, _vp],
     "evp_events_plan_batch": [_vp, _i, _i64, C.c_uint64, _vp, _i, _vp, _i, _i, _i, _i, C.c_double, _vp, _vp, _vp, _vp],
     "evp_events_sorted_check": [_vp, _vp, _i, _i, _vp, _vp],
     "evp_events_erase_add_f64": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _d, _d, _vp, _vp, _vp, _vp],

@@ -350,7 +350,8 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_fused_kernel(const doubl
                                                                      const int64_t *erase_idx, const int64_t *erase_off, const double *added,
                                                                      const int64_t *add_off, const int64_t *cuts, const FusedInfo *info, int n_clips,
                                                                      int bins, int H, int W, int mode, int tile_rows, int n_yt, int bm_words,
-                                                                     double sx, double sy, float *out, int32_t *flags) {
+                                                                     double sx, double sy, float *out, int32_t *flags, const int32_t *view_params,
+                                                                     int Hout, int Wout, int negate) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float *tile = reinterpret_cast<float *>(smem_raw);
   uint32_t *bm = reinterpret_cast<uint32_t *>(smem_raw + (size_t)tile_rows * W * sizeof(float));     // erased-row bitmap of the window
@@ -428,12 +429,37 @@ __global__ __launch_bounds__(VB_THREADS) void voxel_bin_fused_kernel(const doubl
       fused_visit(row[0] * sx, row[1] * sy, row[2], row[3], W, pix0, pix1, t0, dT, rT, clip_fast, scale, bd, -2.0, tile);
     }
     __syncthreads();
-    float *dst = out + (((int64_t)clip * bins + b) * H + y0) * W;
-    if ((W & 3) == 0) {
-      for (int i = threadIdx.x; i < tile_elems / 4; i += VB_THREADS)
-        reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(tile)[i];
+    if (view_params) {
+      // flush THROUGH the view augmentation (view_augment.py:9-77 as csrc/augment.hip restates it: crop box, float32 nearest resize, the
+      // horizontal flip on the resized view, time flip = reversed plane order and, for polarity grids, the sign): an output pixel reads one
+      // grid pixel, so this workgroup writes exactly the output rows whose source row lies in its tile -- the raw grid is never stored
+      const int32_t *pr = view_params + (int64_t)clip * 6;
+      const int px0 = pr[0], py0 = pr[1], pw = pr[2], ph = pr[3], hflip = pr[4], tflip = pr[5];
+      const float vsy = (float)ph / (float)Hout, vsx = (float)pw / (float)Wout;
+      const float sgn = (tflip && negate) ? -1.0f : 1.0f;
+      float *plane = out + ((int64_t)clip * bins + (tflip ? bins - 1 - b : b)) * Hout * Wout;
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      for (int y = wave; y < Hout; y += VB_THREADS / 64) {          // a wave per output row: the row test is wave-uniform
+        int ys = (int)floorf((float)y * vsy);
+        ys = py0 + (ys < ph - 1 ? ys : ph - 1);
+        if (ys < y0 || ys >= y1) continue;
+        const float *src = tile + (ys - y0) * W;
+        float *dst = plane + (int64_t)y * Wout;
+        for (int x = lane; x < Wout; x += 64) {
+          const int xr = hflip ? Wout - 1 - x : x;
+          int xs = (int)floorf((float)xr * vsx);
+          xs = px0 + (xs < pw - 1 ? xs : pw - 1);
+          dst[x] = sgn * src[xs];
+        }
+      }
     } else {
-      for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) dst[i] = tile[i];
+      float *dst = out + (((int64_t)clip * bins + b) * H + y0) * W;
+      if ((W & 3) == 0) {
+        for (int i = threadIdx.x; i < tile_elems / 4; i += VB_THREADS)
+          reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(tile)[i];
+      } else {
+        for (int i = threadIdx.x; i < tile_elems; i += VB_THREADS) dst[i] = tile[i];
+      }
     }
   }
   if (inconsistent) flags[clip] = 0;
@@ -667,11 +693,13 @@ extern "C" int evp_events_sorted_check(const double *events, const int64_t *clip
 extern "C" int evp_voxel_scatter_fused_f32(const double *events, const int64_t *win_begin, const int64_t *win_end, int n_clips,
                                            const int64_t *erase_idx, const int64_t *erase_offsets, const double *added_rows,
                                            const int64_t *add_offsets, int64_t max_window, int bins, int H, int W, double scale_x, double scale_y,
-                                           int64_t *workspace, float *out, void *stream) {
+                                           const int32_t *view_params, int view_h, int view_w, int negate_on_time_flip, int64_t *workspace,
+                                           float *out, void *stream) {
   EVP_CHECK_ARG(events && win_begin && win_end && erase_idx && erase_offsets && added_rows && add_offsets && workspace && out, EVP_EINVAL,
                 "evp_voxel_scatter_fused_f32: null pointer");
   EVP_CHECK_ARG(n_clips > 0 && bins > 0 && bins <= 64 && H > 0 && W > 0 && max_window > 0, EVP_ESHAPE, "evp_voxel_scatter_fused_f32: bad shape");
   EVP_CHECK_ARG(((uintptr_t)events & 15) == 0, EVP_EINVAL, "evp_voxel_scatter_fused_f32: events must be 16-byte aligned");
+  EVP_CHECK_ARG(!view_params || (view_h > 0 && view_w > 0), EVP_ESHAPE, "evp_voxel_scatter_fused_f32: view size required with view_params");
   hipStream_t s = (hipStream_t)stream;
   const int bm_words = (int)((max_window + 31) / 32);
   const size_t bm_bytes = (size_t)bm_words * 4;
@@ -695,7 +723,8 @@ extern "C" int evp_voxel_scatter_fused_f32(const double *events, const int64_t *
   const int n_blocks = n_clips * (bins > 1 ? bins - 1 : 1) * n_yt;
   for (int pass = 0; pass < 2; ++pass) {
     hipLaunchKernelGGL(voxel_bin_fused_kernel, dim3(n_blocks), dim3(VB_THREADS), smem, s, events, win_begin, win_end, erase_idx, erase_offsets, added_rows,
-                       add_offsets, cuts, info, n_clips, bins, H, W, pass ? 3 : 2, tile_rows, n_yt, bm_words, scale_x, scale_y, out, flags);
+                       add_offsets, cuts, info, n_clips, bins, H, W, pass ? 3 : 2, tile_rows, n_yt, bm_words, scale_x, scale_y, out, flags, view_params,
+                       view_h, view_w, negate_on_time_flip);
     EVP_CHECK_LAUNCH("evp_voxel_scatter_fused_f32(bin)");
   }
   return EVP_OK;

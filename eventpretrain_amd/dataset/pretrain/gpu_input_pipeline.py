@@ -336,11 +336,11 @@ class GpuInputPipeline:
     def algorithmic_bytes(self, sizes, fused=False):
         """HBM bytes the chain has to move for clips whose picked windows hold `sizes` rows (the figure bench.py prices the chain
         with): read the window (32 B / row) + write the augmented clip (32 B / row; +- 1 %) + K1 reads it again and writes the grid
-        once + the view augmentation reads the grid and writes the view. `fused` (CapturedChain's default form): the augmented clip is
-        neither written nor read -- the window is read once, by K1."""
+        once + the view augmentation reads the grid and writes the view. `fused` (CapturedChain's default form): neither the augmented
+        clip nor the raw grid exists -- the window is read once, the augmented view written once."""
         n = float(np.sum(sizes))
         grid = self.bins * self.S * self.S * 4.0 * len(sizes)
-        return (n * 32 if fused else n * 32 + n * 32 + n * 32) + grid + grid + grid
+        return (n * 32 + grid) if fused else (n * 32 + n * 32 + n * 32 + grid + grid + grid)
 
 
 class CapturedChain:
@@ -433,19 +433,22 @@ class CapturedChain:
         call("evp_events_draw_erase_add", ptr(tabs[0]), ptr(tabs[1]), nc, ptr(tabs[2]), ptr(tabs[3]), pipe.seed & (2 ** 64 - 1), 0, 0,
              ptr(d[self.n_tab:]), self.kmax, ptr(self.er), ptr(self.ai), ptr(self.nz), stream_ptr())
         if self.fused:
-            # the added rows built and time-sorted, then the grids straight from window rows + erase list + added rows (no merged clip)
+            # the added rows built and time-sorted (in the draw kernel's add workgroup they buy nothing: 261 vs 262 us per batch), then the
+            # grids straight from window rows + erase list + added rows (no merged clip) ...
             call("evp_events_build_added_f64", ptr(self.events), ptr(tabs[0]), nc, ptr(self.ai), ptr(self.nz), ptr(tabs[3]), self.kmax, float(W),
                  float(H), ptr(self.ws), stream_ptr())
-            vox = torch.empty(nc, pipe.bins, pipe.S, pipe.S, dtype=torch.float32, device=d.device)
+            # ... and they leave through the view augmentation (crop / nearest resize / flips), so the raw grids are never stored either
+            p_dev = d[o4:o4 + pw].view(torch.int32)[:nc * 6].view(nc, 6)
+            out = torch.empty(nc, pipe.bins, pipe.S, pipe.S, dtype=torch.float32, device=d.device)
             call("evp_voxel_scatter_fused_f32", ptr(self.events), ptr(tabs[0]), ptr(tabs[1]), nc, ptr(self.er), ptr(tabs[2]), ptr(self.ws),
-                 ptr(tabs[3]), int(pipe.args.fix_events_num), pipe.bins, pipe.S, pipe.S, pipe.S / W, pipe.S / H, ptr(self.kws), ptr(vox),
-                 stream_ptr())
+                 ptr(tabs[3]), int(pipe.args.fix_events_num), pipe.bins, pipe.S, pipe.S, pipe.S / W, pipe.S / H, ptr(p_dev), pipe.S, pipe.S,
+                 int(pipe.bins in (5, 6)), ptr(self.kws), ptr(out), stream_ptr())
         else:
             call("evp_events_erase_add_win_f64", ptr(self.events), ptr(tabs[0]), ptr(tabs[1]), nc, ptr(self.er), ptr(tabs[2]), ptr(self.ai),
                  ptr(self.nz), ptr(tabs[3]), self.kmax, float(W), float(H), ptr(self.ws), ptr(tabs[4]), ptr(self.ev), stream_ptr())
             vox = voxel_grid_batch(self.ev, tabs[4], pipe.bins, (pipe.S, pipe.S), assume_sorted=True, scale=(pipe.S / W, pipe.S / H))
-        p_dev = d[o4:o4 + pw].view(torch.int32)[:nc * 6].view(nc, 6)
-        out = va.evg_augment_batch(vox, p_dev, (pipe.S, pipe.S))
+            p_dev = d[o4:o4 + pw].view(torch.int32)[:nc * 6].view(nc, 6)
+            out = va.evg_augment_batch(vox, p_dev, (pipe.S, pipe.S))
         tgt = None
         if fr is not None:
             # (as a parallel branch of the graph the frame targets cost more than they hide: 408 vs 389 us per batch with fork + join)

@@ -128,11 +128,15 @@ int evp_events_sorted_check(const double *events, const int64_t *clip_offsets, i
  * ascending, erase_offsets [n_clips+1]) PLUS added_rows (float64 [.,4] x,y,t,p, time-sorted per clip as evp_events_erase_add_*'s workspace
  * holds them, add_offsets [n_clips+1]) -- without writing the merged clip: the grid is a sum over the kept rows, the order only decides
  * t0 / t1 (min / max stamp of the merged clip). max_window >= every window's rows (<= 393216: one bit per row in LDS). Window stamps
- * non-decreasing is verified on the device; a clip that fails is redone by a full scan. workspace: n_clips * (bins + 5) int64. */
+ * non-decreasing is verified on the device; a clip that fails is redone by a full scan. workspace: n_clips * (bins + 5) int64.
+ * view_params (optional, device int32 [n_clips,6] as evp_view_augment_f32 takes them): the grids leave THROUGH the view augmentation --
+ * out is then float32 [n_clips, bins, view_h, view_w] = evp_view_augment_f32 of the grids, which are never stored; NULL: out holds the
+ * grids [n_clips, bins, H, W]. */
 int evp_voxel_scatter_fused_f32(const double *events, const int64_t *win_begin, const int64_t *win_end, int n_clips,
                                 const int64_t *erase_idx, const int64_t *erase_offsets, const double *added_rows,
                                 const int64_t *add_offsets, int64_t max_window, int bins, int H, int W, double scale_x, double scale_y,
-                                int64_t *workspace, float *out, void *stream);
+                                const int32_t *view_params, int view_h, int view_w, int negate_on_time_flip, int64_t *workspace, float *out,
+                                void *stream);
 
 /* ------------------------------------------------------------------------------------------------ K2 masking
  * Replaces ViT.random_masking, model/backbone/vit.py:91-103 (argsort, argsort, slice, gather) with the noise as an

@@ -657,7 +657,17 @@ def test_voxel_grid_fused_with_the_event_augmentation():
     got = torch.full((nc, 5, 224, 224), 7.0, device="cuda")
     kws = torch.zeros(nc * 10, dtype=torch.int64, device="cuda")
     call("evp_voxel_scatter_fused_f32", ptr(ev), ptr(d_wb), ptr(d_we), nc, ptr(d_er), ptr(d_eo), ptr(ws2), ptr(d_ao), int(nwin.max()), 5, 224, 224,
-         224 / 640, 224 / 480, ptr(kws), ptr(got), stream_ptr())
+         224 / 640, 224 / 480, None, 0, 0, 0, ptr(kws), ptr(got), stream_ptr())
+    # the same grids leaving THROUGH the view augmentation (crop / nearest resize / flips; every flag combination, a 96 x 128 view too)
+    from eventpretrain_amd.dataset.augmentation.view_augment import evg_augment_batch
+    vp = torch.tensor([[10, 20, 180, 170, 0, 0], [0, 0, 224, 224, 1, 0], [3, 5, 200, 210, 0, 1], [50, 40, 100, 150, 1, 1], [0, 30, 224, 190, 1, 1],
+                       [7, 7, 190, 200, 0, 1]], dtype=torch.int32, device="cuda")
+    for (vh, vw) in ((224, 224), (96, 128)):
+        viewed = torch.full((nc, 5, vh, vw), 7.0, device="cuda")
+        call("evp_voxel_scatter_fused_f32", ptr(ev), ptr(d_wb), ptr(d_we), nc, ptr(d_er), ptr(d_eo), ptr(ws2), ptr(d_ao), int(nwin.max()), 5, 224, 224,
+             224 / 640, 224 / 480, ptr(vp), vh, vw, 1, ptr(kws), ptr(viewed), stream_ptr())
+        want_v = evg_augment_batch(got, vp, (vh, vw))
+        assert torch.allclose(viewed, want_v, atol=2e-5, rtol=0), (vh, (viewed - want_v).abs().max().item())
     torch.cuda.synchronize()
     assert torch.equal(ws, ws2)
     flags = kws[nc * 9:].view(torch.int32)[:nc].tolist()
