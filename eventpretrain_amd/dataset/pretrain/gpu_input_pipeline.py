@@ -304,7 +304,7 @@ class GpuInputPipeline:
             out.append(None if (e.stop == e.start and a.stop == a.start) else (er[e].copy(), ai[a].copy(), nz[a].copy()))
         return out
 
-    def capture(self, events, n_clips, frames=None, clip_offsets=None, fused_voxel=True):
+    def capture(self, events, n_clips, frames=None, clip_offsets=None, fused_voxel=True, out=None, tgt_out=None):
         """The device half as ONE HIP graph (device decision stream): `events` is the buffer every batch's raw rows will sit in (fixed
         address: the loader uploads into it), `frames` likewise. Launched from Python the eight kernels of a batch cost more host time
         (~0.9 ms with the worker thread competing for the interpreter) than the GPU needs for them (~0.42 ms); replayed they cost one
@@ -317,8 +317,10 @@ class GpuInputPipeline:
         first sample) pair that the graph itself advances -- `run_next()` is one replay, with nothing prepared, packed or uploaded on the
         host; `set_clip_offsets` / `set_state` change the inputs between replays.
         `fused_voxel` (default): the voxel grids are binned straight from the window rows, the erase list and the added rows
-        (evp_voxel_scatter_fused_f32) -- the merged clip, which only K1 would read, is never written."""
-        return CapturedChain(self, events, int(n_clips), frames, clip_offsets, fused_voxel)
+        (evp_voxel_scatter_fused_f32) -- the merged clip, which only K1 would read, is never written.
+        `out` / `tgt_out`: tensors the chain writes its grids [n_clips, bins, S, S] / targets [n_clips, C, S, S] INTO -- the static inputs
+        of a step executor, say, which then needs no copy between the two graphs."""
+        return CapturedChain(self, events, int(n_clips), frames, clip_offsets, fused_voxel, out, tgt_out)
 
     def batch(self, events, clip_offsets, step, frames=None, first_sample=0, sample_seeds=None):
         """The whole chain for one batch: decisions on the host, data on the device."""
@@ -347,7 +349,7 @@ class CapturedChain:
     """GpuInputPipeline.capture: the chain's device half captured once, replayed per batch -- with the batch's tables prepared on the host
     (run(prepared)) or, self-driven, planned by a kernel of the graph (run_next())."""
 
-    def __init__(self, pipe, events, n_clips, frames, clip_offsets=None, fused_voxel=True):
+    def __init__(self, pipe, events, n_clips, frames, clip_offsets=None, fused_voxel=True, out=None, tgt_out=None):
         if pipe.stream != "device":
             raise ValueError("CapturedChain needs decision_stream='device' (host-drawn decision lists change size per batch)")
         _lib.require_device()
@@ -368,6 +370,11 @@ class CapturedChain:
         self.ev = None if self.fused else torch.zeros(n_clips * (fix + self.kmax), 4, dtype=torch.float64, device=dev)
         self.kws = torch.zeros(n_clips * (pipe.bins + 5), dtype=torch.int64, device=dev) if self.fused else None
         self._busy = None
+        for t_, shp, who in ((out, (n_clips, pipe.bins, pipe.S, pipe.S), "out"),
+                             (tgt_out, None if frames is None else (n_clips, frames.shape[1], pipe.S, pipe.S), "tgt_out")):
+            if t_ is not None and (shp is None or tuple(t_.shape) != shp or t_.dtype != torch.float32 or not t_.is_contiguous() or t_.device != dev):
+                raise ValueError(f"CapturedChain: {who} must be a contiguous float32 tensor of shape {shp} on the events' device")
+        self._out_given, self._tgt_given = out, tgt_out
         self.self_driven = clip_offsets is not None
         if self.self_driven:
             self.d_off = torch.zeros(n_clips + 1, dtype=torch.int64, device=dev)
@@ -439,7 +446,7 @@ class CapturedChain:
                  float(H), ptr(self.ws), stream_ptr())
             # ... and they leave through the view augmentation (crop / nearest resize / flips), so the raw grids are never stored either
             p_dev = d[o4:o4 + pw].view(torch.int32)[:nc * 6].view(nc, 6)
-            out = torch.empty(nc, pipe.bins, pipe.S, pipe.S, dtype=torch.float32, device=d.device)
+            out = self._out_given if self._out_given is not None else torch.empty(nc, pipe.bins, pipe.S, pipe.S, dtype=torch.float32, device=d.device)
             call("evp_voxel_scatter_fused_f32", ptr(self.events), ptr(tabs[0]), ptr(tabs[1]), nc, ptr(self.er), ptr(tabs[2]), ptr(self.ws),
                  ptr(tabs[3]), int(pipe.args.fix_events_num), pipe.bins, pipe.S, pipe.S, pipe.S / W, pipe.S / H, ptr(p_dev), pipe.S, pipe.S,
                  int(pipe.bins in (5, 6)), ptr(self.kws), ptr(out), stream_ptr())
@@ -448,12 +455,12 @@ class CapturedChain:
                  ptr(self.nz), ptr(tabs[3]), self.kmax, float(W), float(H), ptr(self.ws), ptr(tabs[4]), ptr(self.ev), stream_ptr())
             vox = voxel_grid_batch(self.ev, tabs[4], pipe.bins, (pipe.S, pipe.S), assume_sorted=True, scale=(pipe.S / W, pipe.S / H))
             p_dev = d[o4:o4 + pw].view(torch.int32)[:nc * 6].view(nc, 6)
-            out = va.evg_augment_batch(vox, p_dev, (pipe.S, pipe.S))
+            out = va.evg_augment_batch(vox, p_dev, (pipe.S, pipe.S), out=self._out_given)
         tgt = None
         if fr is not None:
             # (as a parallel branch of the graph the frame targets cost more than they hide: 408 vs 389 us per batch with fork + join)
             fp = d[o4 + pw:o4 + 2 * pw].view(torch.int32)[:nc * 6].view(nc, 6)
-            tgt = va.frame_augment_batch(fr, fp, (pipe.S, pipe.S))
+            tgt = va.frame_augment_batch(fr, fp, (pipe.S, pipe.S), out=self._tgt_given)
         return out, tgt
 
     def run(self, pb):

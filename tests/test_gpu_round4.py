@@ -710,3 +710,73 @@ def test_voxel_grid_fused_with_the_event_augmentation():
         vm, _ = ch_m.run_next()
         torch.cuda.synchronize()
         assert torch.allclose(vf, vm, atol=2e-5, rtol=0), (k, (vf - vm).abs().max().item())
+
+
+@pytest.mark.gpu
+def test_self_driven_chain_feeds_the_graphed_step():
+    """Raw events -> training step with two graph replays per batch and no host work in between: the self-driven loader chain's static
+    outputs (augmented grids, frame targets) are handed to GraphedStep.step(), which copies them into its own static inputs in stream
+    order before the next chain replay overwrites them. The losses equal those of the same batches cloned and stepped one by one with
+    a host synchronisation between every stage (same weights, same noise stream), and they fall."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.dataset.pretrain.gpu_input_pipeline import GpuInputPipeline
+    from eventpretrain_amd.engine import GraphedStep
+    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
+    from eventpretrain_amd.optim import FusedAdamW
+    from eventpretrain_amd.testing import det_fill_module_, make_args, synthetic_events
+    ops.set_compute_dtype(torch.bfloat16)
+    B, S = 4, 64
+    a = make_args(model_size="tiny", pr_phase="rec", patch_size=16, device="cuda", input_size=S, crop_min=0.8, fix_events_num=15_000,
+                  img_sensor_w=640, img_sensor_h=480)
+    sizes = [40_000, 30_000, 15_000, 22_000]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    ev = torch.from_numpy(np.concatenate([synthetic_events(90 + i, n, width=640, height=480) for i, n in enumerate(sizes)], 0)).cuda()
+    frames = torch.randn(B, 1, 480, 640, device="cuda")
+    pipe = GpuInputPipeline(a, seed=11)
+    runs = []
+    for mode in ("queued", "synced"):
+        m = hub.pretrain_hub_model_tiny_patch16_64(a, emb_frames_dim=512, queue_length=1024, T=0.07)
+        det_fill_module_(m)
+        m = m.cuda().train()
+        opt = FusedAdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.95))
+        chain = pipe.capture(ev, B, frames=frames, clip_offsets=off)
+        gen = torch.Generator(device="cuda").manual_seed(7)
+        sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        ex = GraphedStep(m, opt, lambda mm, x, y, noise: mm(x, y, is_rec=True, noise=noise), [chain.out.clone(), chain.tgt.clone()],
+                         noise_shape=(B, (S // 16) ** 2), generator=gen, warmup=2)
+        assert ex.note == "hip-graph", ex.note
+        m.load_state_dict(sd0)
+        ex.resync_weights()
+        opt.reset_state()
+        gen.manual_seed(7)
+        chain.set_state(0, 0)
+        losses = []
+        for k in range(6):
+            v, t = chain.run_next()
+            if mode == "synced":
+                torch.cuda.synchronize()
+                v, t = v.clone(), t.clone()
+                torch.cuda.synchronize()
+            losses.append(ex.step(v, t).clone())
+            if mode == "synced":
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        runs.append([float(l) for l in losses])
+    assert all(math.isfinite(l) for l in runs[0])
+    assert runs[0] == pytest.approx(runs[1], rel=2e-3), runs          # (K1 bins with LDS float adds: inputs equal to f32 rounding)
+    assert len(set(round(l, 5) for l in runs[0])) > 1
+    # no copy at all: the chain writes INTO the executor's static inputs (same trajectory from the same start)
+    m.load_state_dict(sd0)
+    ex.resync_weights()
+    opt.reset_state()
+    gen.manual_seed(7)
+    direct = pipe.capture(ev, B, frames=frames, clip_offsets=off, out=ex.inputs[0], tgt_out=ex.inputs[1])
+    direct.set_state(0, 0)
+    losses = []
+    for k in range(6):
+        direct.run_next()
+        losses.append(ex.step().clone())
+    torch.cuda.synchronize()
+    assert [float(l) for l in losses] == pytest.approx(runs[1], rel=2e-3)
+    with pytest.raises(ValueError):
+        pipe.capture(ev, B, frames=frames, clip_offsets=off, out=torch.empty(B, 5, S, S + 1, device="cuda"))
