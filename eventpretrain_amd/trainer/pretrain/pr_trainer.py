@@ -145,7 +145,10 @@ def _loop(args, model, data_loader, optimizer, epoch, loss_scaler, log_writer, l
     auto = auto and step_executor is None
     on_gpu = str(args.device).startswith("cuda")
     deferred = None            # _DeferredLosses once a step executor runs the steps and per-step syncs are not asked for
-    if on_gpu and getattr(args, "prefetch_to_device", True) and not getattr(args, "sync_every_step", False):
+    if on_gpu and getattr(args, "prefetch_to_device", True) and not getattr(args, "sync_every_step", False) \
+            and not getattr(data_loader, "yields_device_batches", False):
+        # (a loader whose batches are already device tensors it will overwrite -- dataset.pretrain.gpu_event_loader -- must not be
+        # asked for batch i + 1 before batch i has been consumed)
         data_loader = _DevicePrefetcher(data_loader, args.device)
     for it, batch in enumerate(logger.log_every(args, data_loader, args.print_freq, header)):
         if it % args.accum_iter == 0:

@@ -780,3 +780,51 @@ def test_self_driven_chain_feeds_the_graphed_step():
     assert [float(l) for l in losses] == pytest.approx(runs[1], rel=2e-3)
     with pytest.raises(ValueError):
         pipe.capture(ev, B, frames=frames, clip_offsets=off, out=torch.empty(B, 5, S, S + 1, device="cuda"))
+
+
+@pytest.mark.gpu
+def test_gpu_event_loader_is_a_drop_in_for_the_epoch_loop():
+    """dataset.pretrain.gpu_event_loader.GpuEventLoader: raw event clips in, the trainers' dict batches out -- per batch one upload and
+    one replay of the self-driven chain. (a) Its batches equal the chain run directly on the same packed clips (same counter stream:
+    step, first sample); a short last batch is dropped. (b) pr_rec_one_epoch takes it in a DataLoader's place (captured step executor,
+    deferred losses): finite falling losses over two epochs, the step counter carried across epochs."""
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.dataset.pretrain.gpu_event_loader import GpuEventLoader
+    from eventpretrain_amd.dataset.pretrain.gpu_input_pipeline import GpuInputPipeline
+    from eventpretrain_amd.model.pretrain import pr_hub_model as hub
+    from eventpretrain_amd.optim import FusedAdamW
+    from eventpretrain_amd.testing import det_fill_module_, make_args, synthetic_events
+    from eventpretrain_amd.trainer.pretrain.pr_trainer import pr_rec_one_epoch
+    from eventpretrain_amd.utils.misc import NativeScalerWithGradNormCount
+    B, S = 4, 64
+    a = make_args(model_size="tiny", pr_phase="rec", patch_size=16, device="cuda", input_size=S, crop_min=0.8, fix_events_num=15_000,
+                  img_sensor_w=640, img_sensor_h=480)
+    a.lr, a.min_lr, a.warmup_epochs, a.epochs, a.batch_size, a.print_freq, a.log_freq = 1e-3, 1e-6, 0, 2, B, 100, 100
+    sizes = [40_000, 9_000, 15_000, 22_000, 31_000, 18_000, 12_345, 27_000, 5_000, 20_000]          # 10 clips: 2 batches of 4, 2 left over
+    g = torch.Generator().manual_seed(3)
+    samples = [(synthetic_events(400 + i, n, width=640, height=480), torch.randn(1, 480, 640, generator=g), f"clip{i}") for i, n in enumerate(sizes)]
+    loader = GpuEventLoader(a, samples, batch_size=B, n_batches=3, seed=21, first_sample=8, frame_shape=(1, 480, 640), step0=5,
+                            max_events_per_clip=40_000)          # (the default capacity, 2 x fix_events_num, would cut the 40 k clip)
+    got = [(b["events_voxel_grid"].clone(), b["sub_frame"].clone(), list(b["image_name"])) for b in loader]
+    assert len(got) == 2 and got[1][2] == ["clip4", "clip5", "clip6", "clip7"] and loader.step == 7
+    pipe = GpuInputPipeline(a, seed=21)
+    for k in range(2):
+        clips = [samples[4 * k + i][0] for i in range(4)]
+        off = np.concatenate([[0], np.cumsum([c.shape[0] for c in clips])]).astype(np.int64)
+        ev = torch.from_numpy(np.concatenate(clips, 0)).cuda()
+        fr = torch.stack([samples[4 * k + i][1] for i in range(4)]).cuda()
+        ch = pipe.capture(ev, B, frames=fr, clip_offsets=off)
+        ch.set_state(5 + k, 8)
+        v, t = ch.run_next()
+        torch.cuda.synchronize()
+        assert torch.allclose(got[k][0], v, atol=2e-5, rtol=0) and torch.equal(got[k][1], t), k
+    ops.set_compute_dtype(torch.bfloat16)
+    m = hub.pretrain_hub_model_tiny_patch16_64(a, emb_frames_dim=512, queue_length=1024, T=0.07)
+    det_fill_module_(m)
+    m = m.cuda().train()
+    opt = FusedAdamW(m.parameters(), lr=a.lr, betas=(0.9, 0.95))
+    loader = GpuEventLoader(a, samples[:8], batch_size=B, n_batches=2, seed=21, frame_shape=(1, 480, 640))
+    stats = [pr_rec_one_epoch(a, m, loader, opt, ep, NativeScalerWithGradNormCount()) for ep in range(2)]
+    assert getattr(m, "_evp_auto_executor", None) is not None and m._evp_auto_executor[1].note == "hip-graph"
+    assert all(math.isfinite(s_["reconstruct_loss"]) for s_ in stats) and stats[1]["reconstruct_loss"] < stats[0]["reconstruct_loss"]
+    assert loader.step == 4
