@@ -828,3 +828,55 @@ def test_gpu_event_loader_is_a_drop_in_for_the_epoch_loop():
     assert getattr(m, "_evp_auto_executor", None) is not None and m._evp_auto_executor[1].note == "hip-graph"
     assert all(math.isfinite(s_["reconstruct_loss"]) for s_ in stats) and stats[1]["reconstruct_loss"] < stats[0]["reconstruct_loss"]
     assert loader.step == 4
+
+
+@pytest.mark.gpu
+def test_fused_voxel_conserves_polarity_mass_at_full_size():
+    """BASELINE-size check of the fused loader chain through a size-independent property: every kept or added event puts p * (1 - dt) and
+    p * dt (p = +-1) into two neighbouring planes -- or all of p into one -- so a clip's grid sums to the polarity sum of its window minus
+    the erased rows plus the added rows. 64 clips x 150 k events on a 640 x 480 sensor, 100 k-event windows, the decisions drawn on the
+    device by the self-driven chain (whose own output, the augmented view, must hold the same non-zero values: crop + nearest resize +
+    flips only move and repeat pixels -- checked as a bound on its extreme values)."""
+    from eventpretrain_amd._lib import call, ptr, stream_ptr
+    from eventpretrain_amd.dataset.pretrain.gpu_input_pipeline import GpuInputPipeline
+    from eventpretrain_amd.testing import make_args, synthetic_events
+    B, S = 64, 224
+    a = make_args(crop_min=0.8, input_size=S, fix_events_num=100_000, img_sensor_w=640, img_sensor_h=480, device="cuda")
+    base = synthetic_events(4242, 150_000, width=640, height=480)
+    clips = []
+    rng = np.random.default_rng(0)
+    for i in range(B):
+        e = base.copy()
+        e[:, 0] = (e[:, 0] + rng.integers(0, 640)) % 640
+        e[:, 1] = (e[:, 1] + rng.integers(0, 480)) % 480
+        if i % 3 == 0:
+            e[:, 3] = 1.0 - e[:, 3]
+        clips.append(e)
+    ev = torch.from_numpy(np.concatenate(clips, 0)).cuda()
+    off = np.arange(0, (B + 1) * 150_000, 150_000, dtype=np.int64)
+    pipe = GpuInputPipeline(a, seed=5)
+    chain = pipe.capture(ev, B, clip_offsets=off)
+    chain.set_state(17, 128)
+    view, _ = chain.run_next()
+    torch.cuda.synchronize()
+    nc = B
+    tabs = chain.d_tab[:5 * (nc + 1)].view(5, nc + 1)
+    raw = torch.empty(B, 5, S, S, device="cuda")
+    call("evp_voxel_scatter_fused_f32", ptr(ev), ptr(tabs[0]), ptr(tabs[1]), nc, ptr(chain.er), ptr(tabs[2]), ptr(chain.ws), ptr(tabs[3]), 100_000, 5, S, S,
+         S / 640, S / 480, None, 0, 0, 0, ptr(chain.kws), ptr(raw), stream_ptr())
+    torch.cuda.synchronize()
+    wb, we, eo, ao = (tabs[k].cpu().numpy() for k in range(4))
+    pol = torch.where(ev[:, 3] == 0, torch.tensor(-1.0, dtype=torch.float64, device="cuda"), ev[:, 3])
+    er, ws = chain.er.cpu().numpy(), chain.ws
+    got = raw.double().sum(dim=(1, 2, 3)).cpu().numpy()
+    for c in range(B):
+        n_w = int(we[c] - wb[c])
+        ke, ka = int(eo[c + 1] - eo[c]), int(ao[c + 1] - ao[c])
+        assert n_w == 100_000 and 100 <= ke < 1000 and 100 <= ka < 1000, (c, n_w, ke, ka)
+        win = pol[int(wb[c]):int(we[c])]
+        erased = win[torch.from_numpy(er[int(eo[c]):int(eo[c + 1])]).cuda()]
+        added_p = ws[int(ao[c]):int(ao[c + 1]), 3]
+        added = torch.where(added_p == 0, torch.tensor(-1.0, dtype=torch.float64, device="cuda"), added_p)
+        want = float(win.sum() - erased.sum() + added.sum())
+        assert abs(got[c] - want) <= 0.05, (c, got[c], want)
+    assert torch.isfinite(view).all() and float(view.abs().max()) <= float(raw.abs().max()) + 1e-6 and float(view.abs().sum()) > 0
