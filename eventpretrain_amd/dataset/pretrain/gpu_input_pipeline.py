@@ -392,7 +392,7 @@ class CapturedChain:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):      # (RCCL's watchdog thread may poll its events meanwhile)
             self.out, self.tgt = self._launches()
         if self.self_driven:
             self.set_state(0, 0)                      # the warm-up advanced it
