@@ -762,6 +762,8 @@ def main():
             result["loader_chain"] = {"value": args.batch / csec, "unit": "clips/s", "us_per_batch": csec * 1e6, "wall_us_per_batch": wall * 1e6,
                                       "bound": "hbm", "achieved": cbytes / csec / 1e9, "peak": HBM_PEAK_GBS, "frac": cbytes / csec / 1e9 / HBM_PEAK_GBS,
                                       "algorithmic_bytes_per_batch": cbytes, "host_prepare_ms_per_batch": host_ms, "host_ms_per_batch_in_this_loop": 0.0, "decision_stream": pipe.stream + " (plan on the device)",
+                                      "note": "frac prices the bytes this form moves (window rows read once + augmented views written once + frames): the merged clip "
+                                              "and the raw grids of the round-3 form (898 MB per batch, 655 us) are no longer written or read, so bytes fell faster than time",
                                       "includes": "get_random_index (100k of 150k events) -> events_augment -> events_reshape -> "
                                                   "events_to_voxel_grid -> evg_augment + frame_augment, 640x480 sensor clips resident in HBM; "
                                                   "the voxel grids binned straight from window rows + erase list + added rows (the merged clip is never written); "
