@@ -14,7 +14,7 @@ module object supplying `to_2tuple`, `trunc_normal_` and a `DropPath` that is
 never executed (all drop rates are 0 -> nn.Identity, vit_block.py:241) is put
 in sys.modules for the duration of this script.
 
-Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin,swincon,augment,evaug,ftcls,density,autocast,conbase,swinbase,convbase,chain,chainnim]
+Usage:  python oracle/gen_golden.py [--only voxel,pos,mask,tiny,small,base,train,con,convsmall,swin,swincon,augment,evaug,ftcls,density,autocast,conbase,swinbase,convbase,chain,chainnim,trainbf16]
 """
 import argparse
 import json
@@ -407,7 +407,14 @@ def gen_swin():
 
 
 # --------------------------------------------------------------------------- trainer trajectory
-def gen_train():
+def gen_train_bf16():
+    """The same 5 steps with the model's forward under torch.autocast("cpu", bfloat16) -- what the reference's loop is on a GPU, where
+    its `with torch.cuda.amp.autocast():` (trainer/pretrain/pr_trainer.py:26) is live (on the CPU that context is a no-op, so
+    train_tiny.npz is an fp32 trajectory). Yardstick for the build's bf16 mode over several optimiser steps: losses only."""
+    gen_train(autocast_bf16=True)
+
+
+def gen_train(autocast_bf16=False):
     """5 optimiser steps of the reference's own pr_rec_one_epoch (trainer/pretrain/pr_trainer.py:9-89) with
     param_groups_lrd + AdamW(betas=(0.9,0.95)) as main_pretrain.py:323-343 sets them up, on the tiny model."""
     _ref()
@@ -427,6 +434,12 @@ def gen_train():
             self.backbone, self.pretrain_rec_decoder = hub.backbone, hub.pretrain_rec_decoder
 
         def forward(self, x, y, is_rec=True):
+            if autocast_bf16:
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    emb_l1, emb_l2, emb_lh, mask, ids_restore = self.backbone(x, mask=True)
+                    pred = self.pretrain_rec_decoder(emb_lh, ids_restore)
+                    loss = _rec_loss_ref(a, cfg["patch"], pred.float(), y, mask)
+                return loss.float(), emb_l1, emb_l2, emb_lh, pred, mask, ids_restore
             emb_l1, emb_l2, emb_lh, mask, ids_restore = self.backbone(x, mask=True)
             pred = self.pretrain_rec_decoder(emb_lh, ids_restore)
             loss = _rec_loss_ref(a, cfg["patch"], pred, y, mask)
@@ -465,6 +478,10 @@ def gen_train():
         stats = pr_rec_one_epoch(a, model, batches, opt, 0, scaler, log_writer=None)
     finally:
         torch.rand = real_rand
+    if autocast_bf16:
+        print("  bf16-autocast losses", losses)
+        save("train_tiny_bf16", losses=np.array(losses), lrs=np.array(lrs))
+        return
     out = dict(losses=np.array(losses), lrs=np.array(lrs), noise=torch.stack(noises),
                stats=np.array(json.dumps(stats)), lr=np.array(a.lr), min_lr=np.array(a.min_lr),
                warmup_epochs=np.array(a.warmup_epochs), epochs=np.array(a.epochs),
@@ -939,7 +956,7 @@ def gen_swin_base():
 GENS = dict(voxel=gen_voxel, pos=gen_pos, mask=gen_mask, tiny=lambda: gen_composed("tiny"), small=gen_small,
             base=lambda: gen_composed("base"), train=gen_train, con=gen_con, convsmall=gen_convsmall, swin=gen_swin, swincon=gen_swincon, augment=gen_augment, evaug=gen_evaug, ftcls=gen_ftcls,
             frameaug=gen_frameaug, density=gen_density, autocast=gen_autocast, conbase=gen_con_base, swinbase=gen_swin_base,
-            convbase=gen_convbase, chain=gen_chain, chainnim=gen_chain_nimagenet)
+            convbase=gen_convbase, chain=gen_chain, chainnim=gen_chain_nimagenet, trainbf16=gen_train_bf16)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

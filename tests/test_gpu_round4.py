@@ -880,3 +880,47 @@ def test_fused_voxel_conserves_polarity_mass_at_full_size():
         want = float(win.sum() - erased.sum() + added.sum())
         assert abs(got[c] - want) <= 0.05, (c, got[c], want)
     assert torch.isfinite(view).all() and float(view.abs().max()) <= float(raw.abs().max()) + 1e-6 and float(view.abs().sum()) > 0
+
+
+@pytest.mark.gpu
+def test_bf16_trajectory_against_the_reference_under_autocast():
+    """The throughput mode over several OPTIMISER steps: 5 steps of pr_rec_one_epoch + FusedAdamW in bf16 mode on the tiny model against
+    the reference's own trainer with its forward under torch.autocast(bfloat16) (tests/golden/train_tiny_bf16.npz; on a GPU the
+    reference's loop runs under autocast, trainer/pretrain/pr_trainer.py:26) and against its fp32 trajectory (train_tiny.npz). The bar:
+    the build's bf16 losses are as close to the reference's fp32 losses as the reference's own bf16 run is (x 2), at every step."""
+    from conftest import load_golden
+    from test_gpu_model import _hub
+    from eventpretrain_amd import ops
+    from eventpretrain_amd.optim import FusedAdamW
+    from eventpretrain_amd.testing import det_normalish
+    from eventpretrain_amd.trainer.pretrain.pr_trainer import pr_rec_one_epoch
+    from eventpretrain_amd.utils import lr_decay as lrd
+    from eventpretrain_amd.utils.misc import NativeScalerWithGradNormCount
+    d, db = load_golden("train_tiny"), load_golden("train_tiny_bf16")
+    cfg = dict(input=64, patch=16, dim=192, depth=12, heads=3, dec_dim=128, dec_depth=4, dec_heads=4, mask_ratio=0.5, B=2)
+    ops.set_compute_dtype(torch.bfloat16)
+    a, m = _hub("tiny", cfg)
+    a.batch_size, a.epochs, a.warmup_epochs, a.accum_iter = 2, int(d["epochs"]), int(d["warmup_epochs"]), 1
+    a.lr, a.min_lr = float(d["lr"]), float(d["min_lr"])
+    a.graph_step = False                    # the given noise sequence is fed through the forward
+    opt = FusedAdamW(lrd.param_groups_lrd(a, m, a.weight_decay, layer_decay=1), lr=a.lr, betas=(0.9, 0.95))
+    n = len(d["losses"])
+    noises = iter(torch.from_numpy(d["noise"]))
+    losses = []
+    fwd = m.forward
+
+    def forward(x, y, is_rec=True):
+        r = fwd(x, y, is_rec=True, noise=next(noises).cuda())
+        losses.append(r[0].item())
+        return r
+
+    m.forward = forward
+    batches = [dict(events_voxel_grid=det_normalish(f"train.voxels.{s}", (2, 5, 64, 64)) * 0.5,
+                    sub_frame=det_normalish(f"train.sub_frame.{s}", (2, 1, 64, 64)), image_name=[f"s{s}"] * 2) for s in range(n)]
+    pr_rec_one_epoch(a, m, batches, opt, 0, NativeScalerWithGradNormCount())
+    got, ref32, ref16 = np.array(losses), d["losses"], db["losses"]
+    own = np.abs(ref16 - ref32) / ref32                      # the reference's own bf16-vs-fp32 distance per step
+    mine = np.abs(got - ref32) / ref32
+    print("[bf16 trajectory] build vs reference fp32:", mine, "| reference autocast vs its fp32:", own, "| build vs reference autocast:", np.abs(got - ref16) / ref16)
+    assert np.all(mine <= 2.0 * own + 2e-4), (mine, own)
+    assert np.all(np.abs(got - ref16) / ref16 <= 2.0 * own + 2e-4)
