@@ -23,10 +23,16 @@ Philox generator, everything drawn on the host (~13 ms per 64-clip batch: more t
                 drawn at that point) -- it pins the chain's functions incl. the frame target, not a dataset's stream position (the
                 EF-ImageNet dataset loads ready-made voxel grids and draws frame index and seed first).
 
-Two ways to run a batch: `run(...)` does the host packing inline (simple, what the parity test drives); `prepare(...)` /
+Ways to run a batch, slowest first: `run(...)` does the host packing inline (simple, what the parity tests drive); `prepare(...)` /
 `run_prepared(...)` split it -- every table of the batch (window bounds, erase / add indices, noise rows, offsets, crop rows for
 grids and frames) is validated and packed into ONE pinned buffer by `prepare`, which a worker thread runs one batch ahead
-(`prepare_async`); `run_prepared` is then one H2D copy and seven launches, nothing else on the host."""
+(`prepare_async`); `capture(...)` -> CapturedChain replays the device half as one HIP graph, and with `clip_offsets` the chain is
+SELF-DRIVEN: the plan itself (windows, counts, prefix sums, crop rows) is computed by a kernel of the graph (evp_events_plan_batch, bit
+for bit the numpy form above) from a device-resident (step, first sample) pair the graph advances -- nothing per batch on the host.
+The captured chain's default voxel stage is FUSED with the event augmentation and the view augmentation
+(evp_voxel_scatter_fused_f32): it streams the original window rows, skips the erased ones, adds the built rows and flushes through
+crop / resize / flips, so neither the merged clip nor the raw grids are ever written (round 4: 449 -> 262 us per 64-clip batch).
+dataset.pretrain.gpu_event_loader.GpuEventLoader puts that chain at the DataLoader's place in the epoch loops."""
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
