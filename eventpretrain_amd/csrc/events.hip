@@ -498,7 +498,8 @@ extern "C" int evp_events_plan_batch(const int64_t *clip_offsets, int n_clips, i
                                      int64_t *step_first_out, int grid_h, int grid_w, int frame_h, int frame_w, double crop_min, int64_t *tabs,
                                      int32_t *params, int32_t *frame_params, void *stream) {
   EVP_CHECK_ARG(clip_offsets && state && step_first_out && tabs && params, EVP_EINVAL, "evp_events_plan_batch: null pointer");
-  EVP_CHECK_ARG(n_clips > 0 && n_clips <= 4096 && fix_events_num > 0 && grid_h > 0 && grid_w > 0, EVP_ESHAPE, "evp_events_plan_batch: bad shape");
+  EVP_CHECK_ARG(n_clips > 0 && n_clips <= 2048 && fix_events_num > 0 && grid_h > 0 && grid_w > 0, EVP_ESHAPE,
+                "evp_events_plan_batch: bad shape (at most 2048 clips per batch: three int64 rows of the batch live in 48 KiB of LDS)");
   EVP_CHECK_ARG(!frame_params || (frame_h > 0 && frame_w > 0), EVP_ESHAPE, "evp_events_plan_batch: frame size required with frame_params");
   EVP_CHECK_ARG(crop_min > 0.0 && crop_min <= 1.0, EVP_EINVAL, "evp_events_plan_batch: crop_min must lie in (0, 1]");
   auto geom = [](int H, int W) {
