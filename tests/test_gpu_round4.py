@@ -583,6 +583,25 @@ def test_self_driven_loader_chain_plans_its_batches_on_the_device():
         assert np.array_equal(tabs.cpu().numpy(), tabs_h), (step, tabs.cpu().numpy(), tabs_h)
         assert np.array_equal(prm.cpu().numpy(), p_h) and np.array_equal(fpr.cpu().numpy(), f_h), step
         assert cur.tolist() == [step, first] and state.tolist() == [step + 1, first]
+    # many more samples for the float64 crop arithmetic (sqrt, rint, the two products): 16 steps x 64 clips, grid and frame rows
+    rng = np.random.default_rng(1)
+    for step in range(200, 216):
+        sz = rng.integers(0, 60_000, size=64)
+        off64 = np.concatenate([[0], np.cumsum(sz)]).astype(np.int64)
+        pb = pipe.prepare(off64, step=step, first_sample=64 * step, frame_size=(480, 640))
+        w, o = pb.words.numpy(), pb.o
+        d_off64 = torch.from_numpy(off64).cuda()
+        state = torch.tensor([step, 64 * step], dtype=torch.int64, device="cuda")
+        cur = torch.zeros(2, dtype=torch.int64, device="cuda")
+        tabs = torch.zeros(5, 65, dtype=torch.int64, device="cuda")
+        prm, fpr = torch.zeros(64, 6, dtype=torch.int32, device="cuda"), torch.zeros(64, 6, dtype=torch.int32, device="cuda")
+        call("evp_events_plan_batch", ptr(d_off64), 64, 15_000, 77, ptr(state), 0, ptr(cur), 224, 224, 480, 640, 0.8, ptr(tabs), ptr(prm), ptr(fpr),
+             stream_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(tabs.cpu().numpy(), w[o[3]:o[4]].reshape(5, 65)), step
+        assert np.array_equal(prm.cpu().numpy(), w[o[4]:o[5]].view(np.int32)[:384].reshape(64, 6)), step
+        assert np.array_equal(fpr.cpu().numpy(), w[o[5]:o[6]].view(np.int32)[:384].reshape(64, 6)), step
+        assert state.tolist() == [step, 64 * step]                     # advance = 0 leaves the state alone
     # the self-driven chain against the prepared one, three batches in a row (K1 bins with LDS float adds: equal to f32 rounding)
     sizes = [40_000, 30_000, 15_000, 22_000]
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
